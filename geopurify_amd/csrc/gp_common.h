@@ -1,0 +1,75 @@
+// Shared helpers for the gfx950 kernels behind include/geopurify_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/geopurify_hip.h"
+
+#define GP_WAVE 64
+
+extern "C" void gp_set_error(const char *fmt, ...);
+
+#define GP_CHECK_ARG(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            gp_set_error(__VA_ARGS__);         \
+            return GP_EINVAL;                  \
+        }                                      \
+    } while (0)
+
+#define GP_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            gp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                     \
+            return GP_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+#define GP_CHECK_LAUNCH() GP_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t gp_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline size_t gp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// carve a sub-buffer out of a caller workspace (256-byte aligned)
+struct GpCarver {
+    char *base;
+    size_t size, off;
+    GpCarver(void *p, size_t n) : base(static_cast<char *>(p)), size(n), off(0) {}
+    template <typename T>
+    T *take(size_t count) {
+        size_t bytes = gp_align_up(count * sizeof(T), 256);
+        char *r = base ? base + off : nullptr;
+        off += bytes;
+        return reinterpret_cast<T *>(r);
+    }
+    bool ok() const { return off <= size; }
+};
+
+__device__ __forceinline__ int gp_lane() { return threadIdx.x & 63; }
+
+// order LDS/global accesses of the lanes of ONE wave (no cross-wave meaning)
+__device__ __forceinline__ void gp_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float gp_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gp_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int gp_wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,160 @@
+// Exact 1-NN fill (sklearn KDTree k=1 semantics), classify/argmax, IoU histograms (row 13).
+#include "gp_common.h"
+
+namespace {
+
+constexpr int NN_TILE = 1024;
+
+// brute force in fp64: d2 = ((dx*dx + dy*dy) + dz*dz), strict '<' keeps the lowest reference index.
+// grid = (query blocks, reference splits); partial results are combined by nn1_reduce_kernel.
+__global__ void __launch_bounds__(256)
+nn1_partial_kernel(const float *__restrict__ ref, int64_t n_ref, const float *__restrict__ qry, int64_t n_q,
+                   int splits, double *__restrict__ pd, int64_t *__restrict__ pi) {
+    __shared__ double sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
+    int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int sp = blockIdx.y;
+    int64_t per = (n_ref + splits - 1) / splits;
+    int64_t r0 = sp * per, r1 = r0 + per < n_ref ? r0 + per : n_ref;
+    double qx = 0, qy = 0, qz = 0;
+    if (q < n_q) { qx = qry[q * 3]; qy = qry[q * 3 + 1]; qz = qry[q * 3 + 2]; }
+    double best = INFINITY;
+    int64_t bi = -1;
+    for (int64_t t0 = r0; t0 < r1; t0 += NN_TILE) {
+        int64_t cnt = r1 - t0 < NN_TILE ? r1 - t0 : NN_TILE;
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += 256) {
+            sx[j] = ref[(t0 + j) * 3]; sy[j] = ref[(t0 + j) * 3 + 1]; sz[j] = ref[(t0 + j) * 3 + 2];
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            double dx = qx - sx[j], dy = qy - sy[j], dz = qz - sz[j];
+            double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; bi = t0 + j; }
+        }
+    }
+    if (q < n_q) { pd[(int64_t)sp * n_q + q] = best; pi[(int64_t)sp * n_q + q] = bi; }
+}
+
+__global__ void nn1_reduce_kernel(const double *__restrict__ pd, const int64_t *__restrict__ pi, int64_t n_q, int splits,
+                                  int64_t *__restrict__ nn) {
+    int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= n_q) return;
+    double best = INFINITY;
+    int64_t bi = -1;
+    for (int s = 0; s < splits; ++s) {                            // ascending splits = ascending index ranges
+        double d = pd[(int64_t)s * n_q + q];
+        if (d < best) { best = d; bi = pi[(int64_t)s * n_q + q]; }
+    }
+    nn[q] = bi;
+}
+
+int nn1_splits(int64_t n_ref, int64_t n_q) {
+    int64_t qblocks = (n_q + 255) / 256;
+    int s = (int)(2048 / (qblocks > 0 ? qblocks : 1));
+    if (s < 1) s = 1;
+    int64_t maxs = (n_ref + NN_TILE - 1) / NN_TILE;
+    if (s > maxs) s = (int)maxs;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// classify: one wave per point.  logits_c = scale * <f/|f|, t_c>; first maximum wins.
+__global__ void classify_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t n,
+                                const float *__restrict__ text, int C, float scale, int64_t *__restrict__ pred,
+                                uint8_t *__restrict__ zero_row) {
+    int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (p >= n) return;
+    int lane = gp_lane();
+    float ss = 0.f, sa = 0.f;
+    for (int c = lane; c < d; c += 64) { float v = feat[p * ld + c]; ss += v * v; }
+    ss = gp_wave_sum(ss);
+    float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = lane; c < d; c += 64) sa += fabsf(feat[p * ld + c] / nrm);
+    sa = gp_wave_sum(sa);
+    float bestv = -INFINITY;
+    int bestc = 0;
+    for (int k = 0; k < C; ++k) {
+        float dot = 0.f;
+        for (int c = lane; c < d; c += 64) dot += (feat[p * ld + c] / nrm) * text[(int64_t)k * d + c];
+        dot = gp_wave_sum(dot) * scale;
+        if (dot > bestv) { bestv = dot; bestc = k; }
+    }
+    if (lane == 0) {
+        pred[p] = bestc;
+        if (zero_row) zero_row[p] = (sa == 0.f) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void iou_hist_kernel(const int64_t *__restrict__ pred, const int64_t *__restrict__ target, int64_t n, int C,
+                                const int64_t ig0, const int64_t ig1, const int64_t ig2, const int64_t ig3, int nig,
+                                unsigned long long *__restrict__ counts) {
+    extern __shared__ unsigned int sh[];                           // [3*C]
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = pred[i], t = target[i];
+        if ((nig > 0 && t == ig0) || (nig > 1 && t == ig1) || (nig > 2 && t == ig2) || (nig > 3 && t == ig3)) p = t;
+        if (p == t && p >= 0 && p < C) atomicAdd(&sh[p], 1u);
+        if (p >= 0 && p < C) atomicAdd(&sh[C + p], 1u);
+        if (t >= 0 && t < C) atomicAdd(&sh[2 * C + t], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)
+        if (sh[i]) atomicAdd(&counts[i], (unsigned long long)sh[i]);
+}
+
+}  // namespace
+
+extern "C" size_t gp_nn1_workspace_bytes(int64_t n_ref, int64_t n_query) {
+    if (n_ref <= 0 || n_query <= 0) return 0;
+    int s = nn1_splits(n_ref, n_query);
+    GpCarver cv(nullptr, 0);
+    cv.take<double>((size_t)s * n_query);
+    cv.take<int64_t>((size_t)s * n_query);
+    return cv.off;
+}
+
+extern "C" int gp_nn1_f64(const float *ref_xyz, int64_t n_ref, const float *query_xyz, int64_t n_query, int64_t *nn,
+                          void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(ref_xyz && query_xyz && nn && workspace, "gp_nn1_f64: null argument");
+    GP_CHECK_ARG(n_ref > 0, "gp_nn1_f64: empty reference set (the reference's KDTree raises here too)");
+    if (n_query == 0) return GP_OK;
+    int s = nn1_splits(n_ref, n_query);
+    GpCarver cv(workspace, workspace_bytes);
+    double *pd = cv.take<double>((size_t)s * n_query);
+    int64_t *pi = cv.take<int64_t>((size_t)s * n_query);
+    if (!cv.ok()) { gp_set_error("gp_nn1_f64: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
+    hipStream_t st = gp_stream(stream_);
+    dim3 grid((unsigned)((n_query + 255) / 256), (unsigned)s);
+    nn1_partial_kernel<<<grid, 256, 0, st>>>(ref_xyz, n_ref, query_xyz, n_query, s, pd, pi);
+    nn1_reduce_kernel<<<(int)((n_query + 255) / 256), 256, 0, st>>>(pd, pi, n_query, s, nn);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int64_t n, const float *text_norm, int32_t c,
+                                  float logit_scale, int64_t *pred, uint8_t *zero_row, void *stream_) {
+    GP_CHECK_ARG(feat && text_norm && pred && n > 0 && d > 0 && c > 0, "gp_classify_argmax: null/empty argument");
+    classify_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
+                                                                               pred, zero_row);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_iou_hist_i64(const int64_t *pred, const int64_t *target, int64_t n, int32_t num_classes,
+                               const int64_t *ignore_ids_host, int32_t num_ignore, int64_t *counts, void *stream_) {
+    GP_CHECK_ARG(pred && target && counts && n > 0, "gp_iou_hist_i64: null/empty argument");
+    GP_CHECK_ARG(num_classes > 0 && num_classes <= 4096, "gp_iou_hist_i64: num_classes=%d out of range", num_classes);
+    GP_CHECK_ARG(num_ignore >= 0 && num_ignore <= 4, "gp_iou_hist_i64: at most 4 ignore ids");
+    int64_t ig[4] = {0, 0, 0, 0};
+    for (int i = 0; i < num_ignore; ++i) ig[i] = ignore_ids_host[i];
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    iou_hist_kernel<<<blocks, 256, 3 * num_classes * sizeof(unsigned int), gp_stream(stream_)>>>(
+        pred, target, n, num_classes, ig[0], ig[1], ig[2], ig[3], num_ignore,
+        reinterpret_cast<unsigned long long *>(counts));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}

@@ -1,0 +1,253 @@
+// Rows 8, 11, 12 (+ final gather, row L2 norm): point->voxel mean, cosine-affinity softmax,
+// affinity pooling in ELL form.  All HBM/L2-bandwidth-bound gathers: one wave per destination row,
+// 16 B per lane coalesced row segments, wave-uniform neighbour indices and weights in SGPRs.
+#include "gp_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// scatter_mean in CSR form.  One wave per voxel; lanes stride the feature columns in float4 (or
+// scalar for the tail).  Sum order = ascending point id (the order of `order` inside a segment),
+// i.e. the order of a sequential index_add_, then one correctly rounded division by the count.
+__global__ void scatter_mean_csr_kernel(const float *__restrict__ src, int64_t ld_src, int d,
+                                        const int64_t *__restrict__ order, const int64_t *__restrict__ seg,
+                                        int64_t nv, const int32_t *__restrict__ row_map,
+                                        float *__restrict__ out, int64_t ld_out, int col0) {
+    int64_t v = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (v >= nv) return;
+    v = __builtin_amdgcn_readfirstlane((int)v);
+    int lane = gp_lane();
+    int64_t b = seg[v], e = seg[v + 1];
+    int64_t orow = row_map ? row_map[v] : v;
+    float inv_cnt_den = (float)(e - b < 1 ? 1 : e - b);
+    for (int c = lane; c < d; c += 64) {
+        float acc = 0.f;
+        for (int64_t j = b; j < e; ++j) acc += src[order[j] * ld_src + c];
+        out[orow * ld_out + col0 + c] = acc / inv_cnt_den;
+    }
+}
+
+// vectorised variant for d % 4 == 0, 16-byte aligned rows
+__global__ void scatter_mean_csr_v4_kernel(const float *__restrict__ src, int64_t ld_src, int d,
+                                           const int64_t *__restrict__ order, const int64_t *__restrict__ seg,
+                                           int64_t nv, const int32_t *__restrict__ row_map,
+                                           float *__restrict__ out, int64_t ld_out, int col0) {
+    int64_t v = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (v >= nv) return;
+    v = __builtin_amdgcn_readfirstlane((int)v);
+    int lane = gp_lane();
+    int64_t b = seg[v], e = seg[v + 1];
+    int64_t orow = row_map ? row_map[v] : v;
+    float den = (float)(e - b < 1 ? 1 : e - b);
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t j = b; j < e; ++j) {
+            float4 t = *reinterpret_cast<const float4 *>(src + order[j] * ld_src + c);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        acc.x /= den; acc.y /= den; acc.z /= den; acc.w /= den;
+        *reinterpret_cast<float4 *>(out + orow * ld_out + col0 + c) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float *__restrict__ src, int64_t ld_src, int d,
+                                   const int64_t *__restrict__ index, int64_t n,
+                                   const int32_t *__restrict__ row_map, float *__restrict__ out, int64_t ld_out) {
+    int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (p >= n) return;
+    int lane = gp_lane();
+    int64_t r = index[p];
+    if (row_map) r = row_map[r];
+    if ((d & 3) == 0 && (ld_src & 3) == 0 && (ld_out & 3) == 0) {
+        for (int c = lane * 4; c < d; c += 256)
+            *reinterpret_cast<float4 *>(out + p * ld_out + c) = *reinterpret_cast<const float4 *>(src + r * ld_src + c);
+    } else {
+        for (int c = lane; c < d; c += 64) out[p * ld_out + c] = src[r * ld_src + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void l2norm_rows_kernel(float *__restrict__ x, int64_t ld, int d, int64_t n) {
+    int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    int lane = gp_lane();
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) { float v = x[r * ld + c]; ss += v * v; }
+    ss = gp_wave_sum(ss);
+    float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = lane; c < d; c += 64) x[r * ld + c] = x[r * ld + c] / nrm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// affinity: one wave per voxel row.  4 lanes share a neighbour (each reads d/4 contiguous floats),
+// 16 neighbours per pass; dot products reduced with two shuffles; softmax over K with wave reductions.
+template <int D>
+__global__ void affinity_softmax_kernel(const float *__restrict__ e, int64_t ld_e, const int32_t *__restrict__ nbr,
+                                        int k, int64_t nv, float sharpen, float *__restrict__ w) {
+    int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (i >= nv) return;
+    int lane = gp_lane();
+    int sub = lane & 3, grp = lane >> 2;          // 16 groups of 4 lanes
+    constexpr int SEG = D / 4;                     // floats per lane
+    float ei[SEG];
+    const float *erow = e + i * ld_e + sub * SEG;
+#pragma unroll
+    for (int c = 0; c < SEG; c += 4) {
+        float4 t = *reinterpret_cast<const float4 *>(erow + c);
+        ei[c] = t.x; ei[c + 1] = t.y; ei[c + 2] = t.z; ei[c + 3] = t.w;
+    }
+    // logits for neighbours j = pass*16 + grp, kept by lane `sub==0` of each group; K <= 128 -> 8 passes
+    float logit[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        int j = p * 16 + grp;
+        float dot = 0.f;
+        if (j < k) {
+            int64_t r = nbr[i * k + j];
+            const float *nrow = e + r * ld_e + sub * SEG;
+#pragma unroll
+            for (int c = 0; c < SEG; c += 4) {
+                float4 t = *reinterpret_cast<const float4 *>(nrow + c);
+                dot += ei[c] * t.x + ei[c + 1] * t.y + ei[c + 2] * t.z + ei[c + 3] * t.w;
+            }
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        logit[p] = (j < k) ? dot * sharpen : -INFINITY;
+        mx = fmaxf(mx, logit[p]);
+    }
+    mx = gp_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        logit[p] = (logit[p] == -INFINITY) ? 0.f : expf(logit[p] - mx);
+        if (sub == 0) sum += logit[p];
+    }
+    sum = gp_wave_sum(sum);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        int j = p * 16 + grp;
+        if (sub == 0 && j < k) w[i * k + j] = logit[p] / sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling v1: one wave per (row, 256-column slab).  The neighbour row index and weight are wave
+// uniform (scalar loads); each lane moves 16 B of every neighbour row -> 1 KiB coalesced per request.
+template <int UNROLL>
+__global__ void __launch_bounds__(256) pool_ell_kernel(const float *__restrict__ x, int64_t ld_x,
+                                                       const int32_t *__restrict__ nbr, const float *__restrict__ w,
+                                                       int k, int64_t nv, int d, float *__restrict__ y, int64_t ld_y,
+                                                       int slabs) {
+    int64_t wid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    int64_t row = wid / slabs;
+    int slab = (int)(wid - row * slabs);
+    if (row >= nv) return;
+    row = __builtin_amdgcn_readfirstlane((int)row);
+    slab = __builtin_amdgcn_readfirstlane(slab);
+    int lane = gp_lane();
+    int c = slab * 256 + lane * 4;
+    bool act = c < d;
+    const int32_t *nb = nbr + row * k;
+    const float *wr = w + row * k;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = 0;
+    for (; j + UNROLL <= k; j += UNROLL) {
+        float4 t[UNROLL];
+        float ww[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            int64_t r = nb[j + u];
+            ww[u] = wr[j + u];
+            t[u] = act ? *reinterpret_cast<const float4 *>(x + r * ld_x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc.x = fmaf(ww[u], t[u].x, acc.x);
+            acc.y = fmaf(ww[u], t[u].y, acc.y);
+            acc.z = fmaf(ww[u], t[u].z, acc.z);
+            acc.w = fmaf(ww[u], t[u].w, acc.w);
+        }
+    }
+    for (; j < k; ++j) {
+        int64_t r = nb[j];
+        float wj = wr[j];
+        if (act) {
+            float4 t = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+            acc.x = fmaf(wj, t.x, acc.x); acc.y = fmaf(wj, t.y, acc.y);
+            acc.z = fmaf(wj, t.z, acc.z); acc.w = fmaf(wj, t.w, acc.w);
+        }
+    }
+    if (act) *reinterpret_cast<float4 *>(y + row * ld_y + c) = acc;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int gp_scatter_mean_csr(const float *src, int64_t ld_src, int32_t d, const int64_t *order,
+                                   const int64_t *seg_start, int64_t nv, const int32_t *row_map, float *out,
+                                   int64_t ld_out, int32_t col0, void *stream_) {
+    GP_CHECK_ARG(src && order && seg_start && out && nv > 0 && d > 0, "gp_scatter_mean_csr: null/empty argument");
+    hipStream_t s = gp_stream(stream_);
+    int64_t threads = nv * 64;
+    int blocks = (int)((threads + 255) / 256);
+    bool v4 = (d % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && (col0 % 4 == 0) &&
+              ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (v4)
+        scatter_mean_csr_v4_kernel<<<blocks, 256, 0, s>>>(src, ld_src, d, order, seg_start, nv, row_map, out, ld_out, col0);
+    else
+        scatter_mean_csr_kernel<<<blocks, 256, 0, s>>>(src, ld_src, d, order, seg_start, nv, row_map, out, ld_out, col0);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_gather_rows(const float *src, int64_t ld_src, int32_t d, const int64_t *index, int64_t n,
+                              const int32_t *row_map, float *out, int64_t ld_out, void *stream_) {
+    GP_CHECK_ARG(src && index && out && n > 0 && d > 0, "gp_gather_rows: null/empty argument");
+    int blocks = (int)((n * 64 + 255) / 256);
+    gather_rows_kernel<<<blocks, 256, 0, gp_stream(stream_)>>>(src, ld_src, d, index, n, row_map, out, ld_out);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream_) {
+    GP_CHECK_ARG(x && n > 0 && d > 0, "gp_l2norm_rows: null/empty argument");
+    int blocks = (int)((n * 64 + 255) / 256);
+    l2norm_rows_kernel<<<blocks, 256, 0, gp_stream(stream_)>>>(x, ld, d, n);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k,
+                                   int64_t nv, float sharpen, float *w, void *stream_) {
+    GP_CHECK_ARG(e && nbr && w && nv > 0, "gp_affinity_softmax: null/empty argument");
+    GP_CHECK_ARG(k > 0 && k <= 128, "gp_affinity_softmax: k=%d not in 1..128", k);
+    GP_CHECK_ARG(ld_e % 4 == 0 && (uintptr_t)e % 16 == 0, "gp_affinity_softmax: rows must be 16-byte aligned");
+    int blocks = (int)((nv * 64 + 255) / 256);
+    hipStream_t s = gp_stream(stream_);
+    switch (d) {
+        case 128: affinity_softmax_kernel<128><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
+        case 64: affinity_softmax_kernel<64><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
+        case 32: affinity_softmax_kernel<32><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
+        case 16: affinity_softmax_kernel<16><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
+        default: gp_set_error("gp_affinity_softmax: embedding dim %d not in {16,32,64,128}", d); return GP_EINVAL;
+    }
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_pool_ell(const float *x, int64_t ld_x, const int32_t *nbr, const float *w, int32_t k, int64_t nv,
+                           int32_t d, float *y, int64_t ld_y, void *stream_) {
+    GP_CHECK_ARG(x && nbr && w && y && nv > 0 && k > 0, "gp_pool_ell: null/empty argument");
+    GP_CHECK_ARG(d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0, "gp_pool_ell: d/ld must be multiples of 4");
+    GP_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "gp_pool_ell: x/y must be 16-byte aligned");
+    GP_CHECK_ARG(x != y, "gp_pool_ell: x and y must not alias");
+    int slabs = (d + 255) / 256;
+    int64_t waves = nv * slabs;
+    int blocks = (int)((waves * 64 + 255) / 256);
+    pool_ell_kernel<8><<<blocks, 256, 0, gp_stream(stream_)>>>(x, ld_x, nbr, w, k, nv, d, y, ld_y, slabs);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}

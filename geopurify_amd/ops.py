@@ -1,0 +1,316 @@
+"""Tensor-level wrappers over the C-ABI (include/geopurify_hip.h).
+
+Every function takes/returns torch CUDA tensors but hands the library raw device pointers, sizes
+and the current HIP stream.  PyTorch is plumbing here: allocation and stream ownership only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous CUDA {dtype}, got {t.dtype} cuda={t.is_cuda} contig={t.is_contiguous()}")
+    return t
+
+
+def _dbl16(m):
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(16))
+    return (ctypes.c_double * 16)(*a.tolist())
+
+
+# ------------------------------------------------------------------------------------------ rows 1-3
+def voxelize(coords, rigid):
+    """coords f64 [N,3] cuda; rigid 4x4 (host).  Returns dict with coords_aug f64 [Nv,3], inds,
+    inds_reconstruct, order, seg_start (CSR of each voxel's points), nv.  One host sync (nv)."""
+    lib = _lib.load()
+    _chk(coords, torch.float64, "coords")
+    n = coords.shape[0]
+    dev = coords.device
+    ws = _ws(lib.gp_voxelize_workspace_bytes(n), dev)
+    ca = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    inds = torch.empty(n, dtype=torch.int64, device=dev)
+    inv = torch.empty(n, dtype=torch.int64, device=dev)
+    order = torch.empty(n, dtype=torch.int64, device=dev)
+    seg = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    nvd = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(lib.gp_voxelize_f64(_ptr(coords), n, _dbl16(rigid), _ptr(ca), _ptr(inds), _ptr(inv), _ptr(nvd),
+                              _ptr(order), _ptr(seg), _ptr(ws), ws.numel(), _stream()), "gp_voxelize_f64")
+    nv = int(nvd.item())
+    return {"coords_aug": ca[:nv], "inds": inds[:nv], "inds_reconstruct": inv, "order": order,
+            "seg_start": seg[:nv + 1], "nv": nv}
+
+
+def fnv_hash(coords):
+    lib = _lib.load()
+    _chk(coords, torch.float64, "coords")
+    out = torch.empty(coords.shape[0], dtype=torch.int64, device=coords.device)   # bit pattern of uint64
+    check(lib.gp_fnv_hash_f64(_ptr(coords), coords.shape[0], _ptr(out), _stream()), "gp_fnv_hash_f64")
+    return out
+
+
+def project_points(coords, w2c, fx, fy, cx, cy, depth, width, height, cut_bound, vis_thres, want_weight=False):
+    lib = _lib.load()
+    _chk(coords, torch.float64, "coords")
+    n = coords.shape[0]
+    if depth is not None:
+        _chk(depth, torch.float64, "depth")
+        assert depth.shape == (height, width)
+    mapping = torch.empty((n, 3), dtype=torch.int64, device=coords.device)
+    weight = torch.empty(n, dtype=torch.float64, device=coords.device) if want_weight else None
+    check(lib.gp_project_points_f64(_ptr(coords), n, _dbl16(w2c), float(fx), float(fy), float(cx), float(cy),
+                                    _ptr(depth), int(width), int(height), int(cut_bound), float(vis_thres),
+                                    _ptr(mapping), _ptr(weight), _stream()), "gp_project_points_f64")
+    return (mapping, weight) if want_weight else mapping
+
+
+# ------------------------------------------------------------------------------------------ order / grid
+def morton_order(coords_i32):
+    lib = _lib.load()
+    _chk(coords_i32, torch.int32, "coords")
+    nv = coords_i32.shape[0]
+    dev = coords_i32.device
+    ws = _ws(lib.gp_morton_order_workspace_bytes(nv), dev)
+    perm = torch.empty(nv, dtype=torch.int32, device=dev)
+    rank = torch.empty(nv, dtype=torch.int32, device=dev)
+    check(lib.gp_morton_order(_ptr(coords_i32), nv, _ptr(perm), _ptr(rank), _ptr(ws), ws.numel(), _stream()),
+          "gp_morton_order")
+    return perm, rank
+
+
+class Grid:
+    """Opaque lattice grid buffer (device) + the host-side origin/extent it was built with."""
+
+    def __init__(self, buf, origin, extent, nv):
+        self.buf, self.origin, self.extent, self.nv = buf, origin, extent, nv
+
+    def status(self):
+        return int(self.buf[36:40].view(torch.int32).item())      # GpGridHeader.status
+
+
+def grid_build(coords_sorted, origin=None, extent=None):
+    """coords_sorted i32 [nv,3] in Morton order.  origin/extent (host ints) are computed with one
+    sync if not given."""
+    lib = _lib.load()
+    _chk(coords_sorted, torch.int32, "coords")
+    nv = coords_sorted.shape[0]
+    if origin is None or extent is None:
+        lo = coords_sorted.amin(0)
+        hi = coords_sorted.amax(0)
+        lohi = torch.stack([lo, hi]).cpu().tolist()
+        origin = lohi[0]
+        extent = [lohi[1][a] - lohi[0][a] + 1 for a in range(3)]
+    o = (ctypes.c_int32 * 3)(*[int(v) for v in origin])
+    e = (ctypes.c_int32 * 3)(*[int(v) for v in extent])
+    nbytes = lib.gp_grid_bytes(nv, e)
+    if nbytes == 0:
+        raise _lib.GeoPurifyHipError("gp_grid_bytes: invalid extent")
+    buf = _ws(nbytes, coords_sorted.device)
+    check(lib.gp_grid_build(_ptr(coords_sorted), nv, o, e, _ptr(buf), buf.numel(), _stream()), "gp_grid_build")
+    return Grid(buf, list(origin), list(extent), nv)
+
+
+def kernel_map_build(grid, coords_sorted):
+    lib = _lib.load()
+    nv = coords_sorted.shape[0]
+    nm = torch.empty((27, nv), dtype=torch.int32, device=coords_sorted.device)
+    check(lib.gp_kernel_map_build(_ptr(grid.buf), _ptr(coords_sorted), nv, _ptr(nm), _stream()), "gp_kernel_map_build")
+    return nm
+
+
+# ------------------------------------------------------------------------------------------ rows 8-12
+def scatter_mean_csr(src, d, order, seg_start, nv, out, col0=0, row_map=None):
+    lib = _lib.load()
+    _chk(src, torch.float32, "src")
+    check(lib.gp_scatter_mean_csr(_ptr(src), src.stride(0), int(d), _ptr(order), _ptr(seg_start), int(nv),
+                                  _ptr(row_map), _ptr(out), out.stride(0), int(col0), _stream()),
+          "gp_scatter_mean_csr")
+    return out
+
+
+def gather_rows(src, d, index, out=None, row_map=None):
+    lib = _lib.load()
+    n = index.shape[0]
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=src.device)
+    check(lib.gp_gather_rows(_ptr(src), src.stride(0), int(d), _ptr(index), n, _ptr(row_map), _ptr(out),
+                             out.stride(0), _stream()), "gp_gather_rows")
+    return out
+
+
+def sparse_conv(x, nbr_map, w, scale=None, shift=None, residual=None, relu=False, out=None):
+    """x fp32 [nv, >=cin] (row stride = x.stride(0)); w fp32 [27,cin,cout] or [cin,cout]."""
+    lib = _lib.load()
+    nv = x.shape[0]
+    if w.dim() == 3:
+        kv, cin, cout = w.shape
+    else:
+        kv, (cin, cout) = 1, w.shape
+    _chk(w, torch.float32, "w")
+    if out is None:
+        out = torch.empty((nv, cout), dtype=torch.float32, device=x.device)
+    check(lib.gp_sparse_conv(_ptr(x), x.stride(0), _ptr(nbr_map) if kv > 1 else None, nv, _ptr(w), int(kv),
+                             int(cin), int(cout), _ptr(scale), _ptr(shift), _ptr(residual),
+                             residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
+                             out.stride(0), _stream()), "gp_sparse_conv")
+    return out
+
+
+def l2norm_rows_(x, d=None):
+    lib = _lib.load()
+    d = x.shape[1] if d is None else d
+    check(lib.gp_l2norm_rows(_ptr(x), x.stride(0), int(d), x.shape[0], _stream()), "gp_l2norm_rows")
+    return x
+
+
+def knn_lattice(grid, coords_sorted, ids, k):
+    lib = _lib.load()
+    nv = coords_sorted.shape[0]
+    dev = coords_sorted.device
+    ws = _ws(lib.gp_knn_workspace_bytes(nv), dev)
+    nbr = torch.empty((nv, k), dtype=torch.int32, device=dev)
+    check(lib.gp_knn_lattice(_ptr(grid.buf), _ptr(coords_sorted), _ptr(ids), nv, int(k), _ptr(nbr), _ptr(ws),
+                             ws.numel(), _stream()), "gp_knn_lattice")
+    return nbr
+
+
+def affinity_softmax(e, nbr, sharpen=20.0, d=None):
+    lib = _lib.load()
+    nv, k = nbr.shape
+    d = e.shape[1] if d is None else d
+    w = torch.empty((nv, k), dtype=torch.float32, device=e.device)
+    check(lib.gp_affinity_softmax(_ptr(e), e.stride(0), int(d), _ptr(nbr), int(k), nv, float(sharpen), _ptr(w),
+                                  _stream()), "gp_affinity_softmax")
+    return w
+
+
+def pool_ell(x, nbr, w, d, out):
+    lib = _lib.load()
+    nv, k = nbr.shape
+    check(lib.gp_pool_ell(_ptr(x), x.stride(0), _ptr(nbr), _ptr(w), int(k), nv, int(d), _ptr(out), out.stride(0),
+                          _stream()), "gp_pool_ell")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ rows 5-7
+def lift_dense_accum(feat2d, pt, x, y, sum_, cnt):
+    lib = _lib.load()
+    d, H, W = feat2d.shape
+    check(lib.gp_lift_dense_accum(_ptr(feat2d), d, H, W, _ptr(pt), _ptr(x), _ptr(y), pt.shape[0], _ptr(sum_),
+                                  sum_.stride(0), _ptr(cnt), _stream()), "gp_lift_dense_accum")
+
+
+def lift_dense_finish(sum_, d, cnt):
+    lib = _lib.load()
+    n = sum_.shape[0]
+    seen = torch.empty(n, dtype=torch.uint8, device=sum_.device)
+    check(lib.gp_lift_dense_finish(_ptr(sum_), sum_.stride(0), int(d), _ptr(cnt), n, _ptr(seen), _stream()),
+          "gp_lift_dense_finish")
+    return seen
+
+
+def lift_masks_view(pred_masks, scores, taps, out_hw, x, y, want_logit=False, workspace=None):
+    """pred_masks fp32 [Q,h,w]; scores fp32 [Q]; taps = (x0 i32 [W], wx f32 [W,4], y0 i32 [H], wy f32 [H,4])."""
+    lib = _lib.load()
+    Q, h, w = pred_masks.shape
+    n_v = x.shape[0]
+    dev = pred_masks.device
+    need = lib.gp_lift_masks_workspace_bytes(Q, h, w)
+    if workspace is None or workspace.numel() < need:
+        workspace = _ws(need, dev)
+    seg = torch.empty(n_v, dtype=torch.int32, device=dev)
+    lg = torch.empty(n_v, dtype=torch.float32, device=dev) if want_logit else None
+    tx0, twx, ty0, twy = taps
+    check(lib.gp_lift_masks_view(_ptr(pred_masks), Q, h, w, _ptr(scores), _ptr(tx0), _ptr(twx), _ptr(ty0), _ptr(twy),
+                                 int(out_hw[0]), int(out_hw[1]), _ptr(x), _ptr(y), n_v, _ptr(seg), _ptr(lg),
+                                 _ptr(workspace), workspace.numel(), _stream()), "gp_lift_masks_view")
+    return (seg, lg) if want_logit else seg
+
+
+def segment_tables(mask_embed, text_norm, logit_scale, f_seg, logit_seg):
+    lib = _lib.load()
+    Q, d = mask_embed.shape
+    C = text_norm.shape[0]
+    check(lib.gp_segment_tables(_ptr(mask_embed), Q, d, _ptr(text_norm), C, float(logit_scale), _ptr(f_seg),
+                                _ptr(logit_seg), _stream()), "gp_segment_tables")
+
+
+def pv_count(pt, cnt):
+    lib = _lib.load()
+    check(lib.gp_pv_count(_ptr(pt), pt.shape[0], _ptr(cnt), _stream()), "gp_pv_count")
+
+
+def exclusive_scan_i64(x):
+    lib = _lib.load()
+    n = x.shape[0]
+    out = torch.empty_like(x)
+    ws = _ws(lib.gp_scan_workspace_bytes(n), x.device)
+    check(lib.gp_exclusive_scan_i64(_ptr(x), n, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gp_exclusive_scan_i64")
+    return out
+
+
+def pv_fill(pt, seg, view, pv_start, cursor, pv_view, pv_seg):
+    lib = _lib.load()
+    check(lib.gp_pv_fill(_ptr(pt), _ptr(seg), pt.shape[0], int(view), _ptr(pv_start), _ptr(cursor), _ptr(pv_view),
+                         _ptr(pv_seg), _stream()), "gp_pv_fill")
+
+
+def fuse_views_top3(pv_start, pv_view, pv_seg, n, f_seg, logit_seg, out):
+    lib = _lib.load()
+    V, Q, d = f_seg.shape
+    C = logit_seg.shape[2]
+    seen = torch.empty(n, dtype=torch.uint8, device=out.device)
+    check(lib.gp_fuse_views_top3(_ptr(pv_start), _ptr(pv_view), _ptr(pv_seg), int(n), _ptr(f_seg), _ptr(logit_seg),
+                                 Q, d, C, _ptr(out), out.stride(0), _ptr(seen), _stream()), "gp_fuse_views_top3")
+    return seen
+
+
+def nn1(ref_xyz, query_xyz):
+    """Exact nearest reference index per query (fp32 coords, fp64 distances)."""
+    lib = _lib.load()
+    _chk(ref_xyz, torch.float32, "ref_xyz")
+    _chk(query_xyz, torch.float32, "query_xyz")
+    nr, nq = ref_xyz.shape[0], query_xyz.shape[0]
+    nn = torch.empty(nq, dtype=torch.int64, device=ref_xyz.device)
+    if nq == 0:
+        return nn
+    ws = _ws(lib.gp_nn1_workspace_bytes(nr, nq), ref_xyz.device)
+    check(lib.gp_nn1_f64(_ptr(ref_xyz), nr, _ptr(query_xyz), nq, _ptr(nn), _ptr(ws), ws.numel(), _stream()), "gp_nn1_f64")
+    return nn
+
+
+# ------------------------------------------------------------------------------------------ row 13
+def classify_argmax(feat, text_norm, logit_scale, d=None):
+    lib = _lib.load()
+    n = feat.shape[0]
+    d = feat.shape[1] if d is None else d
+    C = text_norm.shape[0]
+    pred = torch.empty(n, dtype=torch.int64, device=feat.device)
+    zero = torch.empty(n, dtype=torch.uint8, device=feat.device)
+    check(lib.gp_classify_argmax(_ptr(feat), feat.stride(0), int(d), n, _ptr(text_norm), C, float(logit_scale),
+                                 _ptr(pred), _ptr(zero), _stream()), "gp_classify_argmax")
+    return pred, zero
+
+
+def iou_hist(pred, target, num_classes, ignore_ids, counts):
+    lib = _lib.load()
+    ig = (ctypes.c_int64 * max(len(ignore_ids), 1))(*[int(v) for v in ignore_ids])
+    check(lib.gp_iou_hist_i64(_ptr(pred), _ptr(target), pred.shape[0], int(num_classes), ig, len(ignore_ids),
+                              _ptr(counts), _stream()), "gp_iou_hist_i64")
+    return counts

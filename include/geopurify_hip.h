@@ -1,0 +1,193 @@
+/*
+ * geopurify_hip.h -- C ABI of libgeopurify_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for GeoPurify's per-scene hot path.  The reference has no
+ * FFI of its own: its hot path calls third-party engines from Python.  Each entry point below
+ * replaces one of those call sites (cited as file:line relative to the reference tree); the Python
+ * host layer (geopurify_amd/_lib.py) binds them with ctypes, see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all buffers (outputs and workspaces) are caller-allocated; *_workspace_bytes() gives sizes;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream unless
+ *     it documents a synchronisation;
+ *   - return value: 0 = ok, negative = error (GP_E*), gp_last_error() gives a message;
+ *   - no exceptions, no hidden allocation on the launch path, no torch types.
+ *   - rows are fp32 row-major with an explicit leading dimension (in elements) where noted.
+ */
+#ifndef GEOPURIFY_HIP_H
+#define GEOPURIFY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GP_OK 0
+#define GP_EINVAL (-22)   /* bad argument / shape */
+#define GP_ENOMEM (-12)   /* workspace too small */
+#define GP_EHIP (-5)      /* HIP runtime error */
+#define GP_ERANGE (-34)   /* coordinate extent not representable */
+
+#define GP_KNN_MAX_K 127  /* K+1 <= 128 */
+
+int gp_version(void);
+const char *gp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rows 1-2: Voxelizer.voxelize + FNV-1 dedupe (dataset/voxelizer.py:103-121,                  */
+/*           dataset/voxelization_utils.py:6-18,95-97: np.unique(return_index, return_inverse)) */
+/* c = floor([x 1] @ rigid^T[:, :3]); c -= min(c); key = FNV-1(c) ; voxels in ascending key      */
+/* order.  rigid_host: 16 doubles row-major (M_r @ M_v).  Outputs: coords_aug f64 [N,3] and inds */
+/* i64 [N] hold nv valid rows; inds_reconstruct i64 [N]; *nv_dev receives the voxel count;       */
+/* order i64 [N] (optional, may be NULL): point ids sorted by (key, id); seg_start i64 [N+1]     */
+/* (optional): CSR offsets of each voxel's points in `order`.                                    */
+size_t gp_voxelize_workspace_bytes(int64_t n);
+int gp_voxelize_f64(const double *coords, int64_t n, const double *rigid_host,
+                    double *coords_aug, int64_t *inds, int64_t *inds_reconstruct, int64_t *nv_dev,
+                    int64_t *order, int64_t *seg_start,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* FNV-1 hash of integer-valued fp64 coordinates [n,3] -> uint64 [n] (voxelization_utils.py:6-18) */
+int gp_fnv_hash_f64(const double *coords, int64_t n, uint64_t *hash, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 3: point -> pixel mapping with depth-consistency test                                    */
+/* (models/utils/fusion_util.py:99-147 ScanNet, :45-82 Matterport).                              */
+/* w2c_host: 16 doubles row-major world->camera (the host passes world_view_transform^T, or     */
+/* inv(camera_to_world)); fx,fy,cx,cy: intrinsics at image_dim.  depth f64 [H,W] or NULL.        */
+/* mapping i64 [N,3] rows (v,u,1) or (0,0,0).  weight f64 [N] optional (ScanNet variant).         */
+int gp_project_points_f64(const double *coords, int64_t n, const double *w2c_host,
+                          double fx, double fy, double cx, double cy,
+                          const double *depth, int32_t width, int32_t height,
+                          int32_t cut_bound, double vis_thres,
+                          int64_t *mapping, double *weight, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Internal voxel order + lattice grid (shared by kernel-map build and kNN).                     */
+/* gp_morton_order: perm i32 [nv] = voxel rows sorted by the Morton code of (coords - min);      */
+/* rank i32 [nv] = inverse permutation.  coords i32 [nv,3].                                      */
+size_t gp_morton_order_workspace_bytes(int64_t nv);
+int gp_morton_order(const int32_t *coords, int64_t nv, int32_t *perm, int32_t *rank,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* gp_grid_build: coords must already be in Morton order (as produced by perm).  The grid lives   */
+/* in `grid` (gp_grid_bytes(nv, extent) bytes).  extent_host: 3 ints = max-min+1 per axis,        */
+/* origin_host: 3 ints = min per axis.                                                           */
+size_t gp_grid_bytes(int64_t nv, const int32_t *extent_host);
+int gp_grid_build(const int32_t *coords, int64_t nv, const int32_t *origin_host,
+                  const int32_t *extent_host, void *grid, size_t grid_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 8: torch_scatter.scatter_mean(src, index, dim=0) (models/affinity_module.py:1524-1535).   */
+/* CSR form (deterministic, sums in ascending point id): seg_start i64 [nv+1], order i64 [n].     */
+/* out[v, col0:col0+d] = mean over the voxel's points.  ld_src / ld_out in floats.                */
+int gp_scatter_mean_csr(const float *src, int64_t ld_src, int32_t d, const int64_t *order,
+                        const int64_t *seg_start, int64_t nv, const int32_t *row_map,
+                        float *out, int64_t ld_out, int32_t col0, void *stream);
+/* out[p, 0:d] = src[index[p], 0:d]   (final voxel->point gather, affinity_module.py:1589)        */
+int gp_gather_rows(const float *src, int64_t ld_src, int32_t d, const int64_t *index, int64_t n,
+                   const int32_t *row_map, float *out, int64_t ld_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 9: MinkowskiEngine submanifold convolution (models/affinity_module.py:36-66,1541-1546).   */
+/* gp_kernel_map_build: nbr_map i32 [27,nv]; nbr_map[k][u] = row of voxel coords[u]+o_k or -1,   */
+/* k = (dx+1)+3(dy+1)+9(dz+1).  Needs the grid built from the same Morton-ordered coords.         */
+int gp_kernel_map_build(const void *grid, const int32_t *coords, int64_t nv, int32_t *nbr_map,
+                        void *stream);
+/* Y[u, :] = epilogue( sum_k X[nbr_map[k][u], :] @ W[k] ),  W fp32 [kv, cin, cout] row-major,      */
+/* kv = 27 (nbr_map [27,nv]) or 1 (nbr_map NULL: identity).  epilogue: y = acc*scale + shift      */
+/* (scale/shift fp32 [cout] or NULL), optional residual add (fp32 [nv, ld_res] or NULL), optional  */
+/* ReLU.  cin % 8 == 0 (pad channels with zeros), cout % 128 == 0.                                */
+int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t nv,
+                   const float *w, int32_t kv, int32_t cin, int32_t cout,
+                   const float *scale, const float *shift, const float *residual, int64_t ld_res,
+                   int32_t relu, float *y, int64_t ld_y, void *stream);
+/* in-place row L2 normalisation, F.normalize(p=2, dim=1, eps=1e-12) (affinity_module.py:1547)     */
+int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 10: faiss.IndexFlatL2.search(K+1) on integer voxel coordinates, self dropped              */
+/* (models/affinity_module.py:1551-1557).  Exact; canonical tie rule (d^2, id) ascending where id  */
+/* = ids[row] (NULL: the row number).  nbr i32 [nv,K] holds ROW numbers of the given arrays,      */
+/* emitted in (d^2, id) order.  coords Morton-ordered + grid as above.  K <= GP_KNN_MAX_K.         */
+size_t gp_knn_workspace_bytes(int64_t nv);
+int gp_knn_lattice(const void *grid, const int32_t *coords, const int32_t *ids, int64_t nv,
+                   int32_t k, int32_t *nbr, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 11: cosine affinity + sharpened softmax (models/affinity_module.py:1559-1572).             */
+/* w[i,j] = softmax_j( sharpen * <E_i, E_nbr[i,j]> ),  E fp32 [nv, ld_e], first d columns.         */
+int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k,
+                        int64_t nv, float sharpen, float *w, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 12: one application of the row-stochastic affinity operator, torch.sparse.mm(A, X)        */
+/* (models/affinity_module.py:1575-1587) in ELL form: Y[i,0:d] = sum_j w[i,j] * X[nbr[i,j],0:d].   */
+/* d % 4 == 0, ld_x/ld_y % 4 == 0.  X and Y must not alias.                                       */
+int gp_pool_ell(const float *x, int64_t ld_x, const int32_t *nbr, const float *w, int32_t k,
+                int64_t nv, int32_t d, float *y, int64_t ld_y, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */
+/* gp_lift_dense_accum: sum[pt[i], :] += feat2d[:, x[i], y[i]] ; cnt[pt[i]] += 1 for one view.     */
+int gp_lift_dense_accum(const float *feat2d, int32_t d, int32_t height, int32_t width,
+                        const int64_t *pt, const int64_t *x, const int64_t *y, int64_t n_v,
+                        float *sum, int64_t ld_sum, float *cnt, void *stream);
+/* gp_lift_dense_finish: out = sum / (cnt==0 ? 1e-6 : cnt); seen[p] = cnt > 1e-5 (u8).             */
+int gp_lift_dense_finish(float *sum, int64_t ld_sum, int32_t d, const float *cnt, int64_t n,
+                         uint8_t *seen, void *stream);
+/* gp_lift_masks_view: per visible point pick the segment k* = argmax_q score[q]*sigmoid(m_q(x,y)) */
+/* over queries with score>0, where m_q is the bicubic-antialias resize of pred_masks [Q,h,w] to    */
+/* mask_shape evaluated only at the sampled pixel (separable taps tap_x0/tap_wx [W,4],              */
+/* tap_y0/tap_wy [H,4] precomputed on the host); seg[i] = k* if sigmoid(m_k*) >= 0.5 else -1.       */
+size_t gp_lift_masks_workspace_bytes(int32_t q, int32_t h, int32_t w);
+int gp_lift_masks_view(const float *pred_masks, int32_t q, int32_t h, int32_t w,
+                       const float *scores, const int32_t *tap_x0, const float *tap_wx,
+                       const int32_t *tap_y0, const float *tap_wy, int32_t out_h, int32_t out_w,
+                       const int64_t *x, const int64_t *y, int64_t n_v, int32_t *seg,
+                       float *seg_logit, void *workspace, size_t workspace_bytes, void *stream);
+/* gp_segment_tables: per view, f_seg[q,:] = normalize(mask_embed[q,:]) and                         */
+/* logit_seg[q,c] = logit_scale * <f_seg[q], normalize(text[c])>  (affinity_module.py:627-630;       */
+/* every point feature is a segment embedding).                                     */
+int gp_segment_tables(const float *mask_embed, int32_t q, int32_t d, const float *text_norm,
+                      int32_t c, float logit_scale, float *f_seg, float *logit_seg, void *stream);
+/* point -> (view, segment) CSR, replacing the reference's per-point Python dict                       */
+/* (affinity_module.py:633-639): gp_pv_count adds 1 to cnt[pt[i]] for one view; after all views an    */
+/* exclusive scan gives pv_start; gp_pv_fill appends (view, seg[i]) to every visible point's slot      */
+/* list (views must be filled in ascending order on one stream; cursor i32 [n] zero-initialised).     */
+int gp_pv_count(const int64_t *pt, int64_t n_v, int64_t *cnt, void *stream);
+size_t gp_scan_workspace_bytes(int64_t n);
+int gp_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int gp_pv_fill(const int64_t *pt, const int32_t *seg, int64_t n_v, int32_t view,
+               const int64_t *pv_start, int32_t *cursor, int32_t *pv_view, int32_t *pv_seg,
+               void *stream);
+/* gp_fuse_views_top3: CSR over points (pv_start i64 [n+1]; pv_view i32, pv_seg i32 per slot in      */
+/* ascending view order; seg -1 = zero feature): consensus class = argmax of the mean logits,        */
+/* top-min(M,3) views by agreement, softmax weights, weighted sum of segment features                */
+/* f_seg fp32 [V,Q,d], logit_seg fp32 [V,Q,c].  out fp32 [n, ld_out]; seen u8 [n].                    */
+int gp_fuse_views_top3(const int64_t *pv_start, const int32_t *pv_view, const int32_t *pv_seg,
+                       int64_t n, const float *f_seg, const float *logit_seg, int32_t q, int32_t d,
+                       int32_t c, float *out, int64_t ld_out, uint8_t *seen, void *stream);
+/* gp_nn1_fill_f64: exact 1-NN (fp64 distances on fp32 coordinates, lowest index on ties) from       */
+/* query points to reference points; writes nn[i] = index into ref.  (sklearn KDTree k=1,           */
+/* affinity_module.py:619-625,693-696; run/validation.py:425-430.)                                   */
+size_t gp_nn1_workspace_bytes(int64_t n_ref, int64_t n_query);
+int gp_nn1_f64(const float *ref_xyz, int64_t n_ref, const float *query_xyz, int64_t n_query,
+               int64_t *nn, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row 13 + caller tail (run/validation.py:413-416, util/util.py:160-177).                        */
+/* pred[p] = argmax_c <normalize(F[p]), text_norm[c]> (first max on ties); zero_row[p] = sum|F|==0  */
+int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int64_t n, const float *text_norm,
+                       int32_t c, float logit_scale, int64_t *pred, uint8_t *zero_row, void *stream);
+/* counts i64 [3,C] += (intersection, output, target) histograms with the ignore-id overwrite.      */
+int gp_iou_hist_i64(const int64_t *pred, const int64_t *target, int64_t n, int32_t num_classes,
+                    const int64_t *ignore_ids_host, int32_t num_ignore, int64_t *counts,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOPURIFY_HIP_H */
