@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- scenes/sec of the GeoPurify per-scene hot path on MI355X (BASELINE.json metric).
+
+A "step" = ONE ScanNet-shaped synthetic scene (config S: ~150k points, 25 views, 512-d X-Decoder
+features, K=96, 19 pooling applications as in the reference code) through the whole device path:
+voxelizer + per-view mapping + mask-embedding lift + top-3 fusion + fills + point->voxel mean +
+Student Affinity Network (9 sparse 3-D convs + linear) + exact kNN + affinity softmax + pooling +
+gather + classify + IoU histogram.  Inputs (point cloud, depth maps, poses, synthetic VLM outputs,
+random-init student weights) are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Scenes shard one per GPU with no data-path collective (weak scaling); the only collective is one
+int64 all-reduce of the [3,C] IoU counts after the local loop, as the reference's (dead) metric
+reduce would do (run/validation.py:441-450).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3        # dense fp32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="S", choices=["P", "S", "M", "T"])
+    ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
+    ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+class PoolTimer:
+    """HIP events around every pooling launch, on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.events = []
+        self.enabled = False
+
+    def wrap(self, ops):
+        orig = ops.pool_ell
+        timer = self
+
+        def timed(*a, **k):
+            if not timer.enabled:
+                return orig(*a, **k)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = orig(*a, **k)
+            e1.record(s)
+            timer.events.append((e0, e1))
+            return r
+        ops.pool_ell = timed
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else float("nan")
+
+
+class StageTimer:
+    """Coarse per-stage HIP-event timing (reported in `stages_ms`, not part of the contract)."""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.marks.append((name, e))
+
+    def table(self):
+        out = {}
+        for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def cpu_baseline(scene, vlm_np, sd, rigid, cfg, pool_iters, budget_s):
+    """The oracle ("port") timed on the host cores, on a BOUNDED sample of the same workload: the same
+    scene geometry sub-sampled to fewer points / views so that it finishes in ~budget_s, scaled to
+    scenes/sec by its measured per-stage costs (linear in points x views for the lift, in voxels for
+    the refine stages)."""
+    import dataclasses
+    from geopurify_amd import synthetic as syn
+    from oracle import pipeline as o_pipe
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    frac_pts, n_views = 0.2, max(2, cfg.num_views // 6)
+    small_cfg = dataclasses.replace(cfg, num_points=int(cfg.num_points * frac_pts), num_views=n_views)
+    small = syn.make_scene(small_cfg, 5557)
+    vlm_small = {k: (v[:n_views] if isinstance(v, np.ndarray) and v.ndim >= 3 and v.shape[0] == cfg.num_views else v)
+                 for k, v in vlm_np.items()}
+    timings = {}
+    t0 = time.perf_counter()
+    o_pipe.evaluate_scene_oracle(small, vlm_small, sd, rigid, K=96, num_iters=pool_iters, timings=timings)
+    wall = time.perf_counter() - t0
+    # scale: loader+lift ~ points x views ; fuse ~ points ; refine stages ~ voxels (~points)
+    pv = (cfg.num_points * cfg.num_views) / (small_cfg.num_points * small_cfg.num_views)
+    pn = cfg.num_points / small_cfg.num_points
+    est = 0.0
+    for k, v in timings.items():
+        est += v * (pv if k in ("loader(project+voxelize)", "lift per view") else pn)
+    # kNN brute force in the oracle is quadratic in voxels
+    est += timings.get("knn", 0.0) * (pn * pn - pn)
+    return {"value": round(1.0 / est, 6), "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU/numpy/sklearn, vectorised variant) on {small_cfg.num_points} pts x {n_views} views "
+                      f"of the same scene generator, T={pool_iters}: {wall:.1f}s measured; extrapolated per stage to "
+                      f"{cfg.num_points} pts x {cfg.num_views} views = {est:.1f} s/scene",
+            "stages_s_sample": {k: round(v, 3) for k, v in timings.items()}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from geopurify_amd import ops, pipeline as pl, synthetic as syn
+    cfg = syn.CONFIGS[args.config]
+    # ---- synthetic inputs, resident in HBM before timing ------------------------------------------
+    scenes, vlms, rigids = [], [], []
+    vlm_np0 = None
+    for s in range(args.scenes):
+        seed = 5557 + 1000 * rank + s
+        sc = syn.make_scene(cfg, seed)
+        if cfg.dense_features:
+            feat = syn.make_dense_feature_maps(cfg, cfg.num_views, seed)
+            text = np.random.default_rng(seed).normal(size=(cfg.num_classes, cfg.feat_dim)).astype(np.float32)
+            vlm_np = {"text_embed": text, "logit_scale": np.float32(1 / 0.07), "dense": feat}
+            vlms.append(pl.DenseFeatureVLM(feat, text, 1 / 0.07, dev))
+        else:
+            vlm_np = syn.make_vlm_outputs(cfg, cfg.num_views, seed)
+            vlms.append(pl.SyntheticVLM(vlm_np, dev))
+        if s == 0:
+            vlm_np0 = vlm_np
+        scenes.append(pl.upload_scene(sc, dev))
+        rigids.append(pl.scene_rigid_transform(cfg.voxel_size, seed))
+    sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
+    student = pl.StudentWeights(sd, dev)
+    hp = pl.HotPath(student, cfg.mask_shape, K=96, sharpen=20.0, num_iters=args.pool_iters, device=dev)
+    counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device=dev)
+    pool_timer = PoolTimer()
+    pool_timer.wrap(ops)
+
+    def step(i, stage=None):
+        j = i % args.scenes
+        if stage:
+            stage.mark("start")
+        batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
+        if stage:
+            stage.mark("loader: voxelize+project+lists")
+        if cfg.dense_features:
+            F, text, scale = hp.lift_dense(batch, vlms[j])
+        else:
+            F, text, scale = hp.lift_masks(batch, vlms[j])
+        if stage:
+            stage.mark("lift+fuse+fill")
+        feats = hp.refine(batch, F)
+        if stage:
+            stage.mark("refine: mean+student+knn+affinity+pool+gather")
+        hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale},
+                              batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
+        if stage:
+            stage.mark("classify+iou")
+        return batch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    counts.zero_()
+    pool_timer.enabled = True
+    stage = StageTimer()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(i, stage)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(counts)                       # the one collective: int64 [3,C] IoU counts
+    barrier()
+    dt = time.perf_counter() - t0
+    pool_timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        Nv = hp.stats["Nv"]
+        D = cfg.feat_dim
+        pool_ms = pool_timer.mean_ms()
+        pool_bytes = Nv * (2 * D * 4 + 96 * 8)           # algorithmic bytes per application of A
+        achieved = pool_bytes / (pool_ms * 1e-3) / 1e9
+        stages = stage.table()
+        pairs = int((hp.stats["nbr_map"] >= 0).sum().item())
+        flops = student.flops(pairs, Nv)
+        out = {
+            "metric": "scenes/sec (ScanNet-val shape) + pooled-feature GB/s vs HBM peak",
+            "value": round(world * args.steps / dt, 4), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: ScanNetV2-shaped scene, N={cfg.num_points} pts, Nv={Nv}, "
+                                   f"{len(last.views)}/{cfg.num_views} views kept, D={D}, K=96, "
+                                   f"pool_iters={args.pool_iters}, student 518->512x9->128 random-init",
+                       "sharding": f"1 scene per GPU x {world}, one int64 all-reduce of IoU counts"},
+            "roofline": {"kernel": "pool_ell_kernel (affinity pooling, one application of A)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4)},
+            "stages_ms_per_scene": {k: round(v / args.steps, 3) for k, v in stages.items()},
+            "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                import dataclasses
+                out["cpu_baseline"] = cpu_baseline(scenes[0], vlm_np0, sd, rigids[0], cfg, args.pool_iters, args.cpu_seconds)
+            except Exception as e:  # the baseline is a reported extra; never lose the GPU line
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

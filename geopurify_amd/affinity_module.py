@@ -1,0 +1,146 @@
+"""Host mirror of models/affinity_module.py: AffinityPredictor + SonataXAffinityTrainer.
+
+Same names, constructor arguments and call surface as the reference classes the drivers touch
+(run/validation.py:166-219,408-411), with the numeric work on the HIP path
+(geopurify_amd.pipeline.HotPath).  What is NOT here, on purpose (out of scope):
+the frozen X-Decoder / LSeg / Sonata models.  The 2D VLM is injected as a callable that returns the
+five X-Decoder outputs the lift consumes; `SyntheticVLM` is the offline stand-in.
+"""
+import torch
+import torch.nn as nn
+
+from . import pipeline
+from .pipeline import GEO_DIM, HotPath, SceneBatch, StudentWeights, ViewLists
+
+
+class _SparseConvParams(nn.Module):
+    """Parameter holder with MinkowskiConvolution's state_dict layout: `kernel` [kv,cin,cout] (2-D for kv=1)."""
+
+    def __init__(self, cin, cout, kernel_size):
+        super().__init__()
+        kv = kernel_size ** 3
+        shape = (kv, cin, cout) if kv > 1 else (cin, cout)
+        self.kernel = nn.Parameter(torch.randn(shape) * (2.0 / (kv * cin)) ** 0.5)
+
+
+class _SparseBatchNorm(nn.Module):
+    """MinkowskiBatchNorm wraps a BatchNorm1d as `.bn` (keys `<name>.bn.weight`, ...)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(c)
+
+
+class _ReLU(nn.Module):
+    pass
+
+
+class MinkowskiResBlock(nn.Module):
+    """models/affinity_module.py:33-49."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv1 = _SparseConvParams(channels, channels, 3)
+        self.norm1 = _SparseBatchNorm(channels)
+        self.conv2 = _SparseConvParams(channels, channels, 3)
+        self.norm2 = _SparseBatchNorm(channels)
+
+
+class AffinityPredictor(nn.Module):
+    """models/affinity_module.py:51-85.  Holds parameters in the reference's state_dict layout;
+    the forward pass is executed by the HIP sparse-conv kernels on a (features, nbr_map) pair."""
+
+    def __init__(self, input_dim, embed_dim=128, hidden_dim=256):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.input_layer = nn.Sequential(_SparseConvParams(input_dim, hidden_dim, 3), _SparseBatchNorm(hidden_dim), _ReLU())
+        self.res_blocks = nn.Sequential(*[MinkowskiResBlock(hidden_dim) for _ in range(4)])
+        self.output_layer = _SparseConvParams(hidden_dim, embed_dim, 1)
+        self._dev_weights = None
+
+    def get_param_groups(self):
+        return {"input": list(self.input_layer.parameters()),
+                "middle": list(self.res_blocks.parameters()),
+                "output": list(self.output_layer.parameters())}
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._dev_weights = None
+        return out
+
+    def device_weights(self, device):
+        if self._dev_weights is None or self.training:
+            self._dev_weights = StudentWeights(self.state_dict(), device)
+        return self._dev_weights
+
+    def forward(self, features, nbr_map):
+        """features fp32 [Nv, cin_pad] in Morton order + its 27-offset kernel map -> unnormalised is
+        not exposed: returns the L2-normalised embeddings the caller applies next (:1546-1547)."""
+        return self.device_weights(features.device).forward(features, nbr_map)
+
+
+class SonataXAffinityTrainer(nn.Module):
+    """models/affinity_module.py:129-1607, inference surface.
+
+    cfg needs: all_label, mask_shape, voxel_size (util/config flat namespace).  `xdecoder_cfg` and
+    `scene_config` are accepted for signature compatibility.  `vlm`: object with __call__(view_index)
+    -> dict(pred_masks, pred_logits, mask_embed, text_embed, logit_scale) and attributes
+    text_embed / logit_scale (e.g. pipeline.SyntheticVLM), or a pipeline.DenseFeatureVLM when
+    use_lseg=True (dense-feature lift)."""
+
+    def __init__(self, cfg, xdecoder_cfg=None, scene_config=None, device="cuda", use_lseg=True, vlm=None,
+                 feature_dim=512, embed_dim=128, hidden_dim=512):
+        super().__init__()
+        self.cfg = cfg
+        self.device = device
+        self.use_lseg = use_lseg
+        self.use_ape = bool(getattr(cfg, "use_ape", False)) if not isinstance(cfg, dict) else bool(cfg.get("use_ape", False))
+        if self.use_ape:
+            raise NotImplementedError("lift_ape_features needs the absent xdecoder_test package (SURVEY.md section 2 #1)")
+        self.vlm = vlm
+        self.feature_dim = feature_dim
+        self.affinity_student = AffinityPredictor(input_dim=feature_dim + GEO_DIM, embed_dim=embed_dim,
+                                                  hidden_dim=hidden_dim)
+        self.K = 96                               # :1492
+        self.affinity_sharpen_factor = 20         # :1493
+        self.num_pool_iters = 19                  # :1584-1587 (1 + 18)
+
+    def _hot_path(self):
+        dev = torch.device(self.device if self.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        st = self.affinity_student.device_weights(dev)
+        return HotPath(st, tuple(self.cfg["mask_shape"] if isinstance(self.cfg, dict) else self.cfg.mask_shape),
+                       K=self.K, sharpen=float(self.affinity_sharpen_factor), num_iters=self.num_pool_iters, device=dev)
+
+    @staticmethod
+    def _batch_from_tuple(batch_data, device):
+        """Parse the reference's positional 20-tuple (names at affinity_module.py:1501-1522)."""
+        (scene_coords, scene_coords_3d, scene_inds_reconstruct, scene_label, ori_coords_3ds, _c, _f, _g, _l, _b,
+         _l2, imgs, x_labels, y_labels, mask_2ds, _ir, _um, _mp, _cap, scene_gauss_features) = batch_data
+        dev = torch.device(device)
+        N = scene_coords.shape[0]
+        mask_2ds = mask_2ds.to(dev)
+        V = int(mask_2ds.shape[0] // N)
+        vis = mask_2ds[:, 1].view(V, N).bool()
+        view_of = ori_coords_3ds[:, 0].to(dev).long()
+        x_labels, y_labels = x_labels.to(dev), y_labels.to(dev)
+        views = []
+        for i in range(V):
+            sel = view_of == i
+            views.append(ViewLists(torch.where(vis[i])[0], x_labels[sel].contiguous(), y_labels[sel].contiguous(), i))
+        return SceneBatch(scene_coords.to(dev).float().contiguous(), scene_coords_3d.to(dev).float().contiguous(),
+                          scene_inds_reconstruct.to(dev).long().contiguous(), scene_label.to(dev).long(),
+                          scene_gauss_features[:, :6].to(dev).float().contiguous(), views)
+
+    @torch.no_grad()
+    def evaluate_scene(self, batch_data, vis_prefix="scene0695_00"):
+        """-> {"scene_features" [N,D], "text_features" [C,D], "logit_scale"} (:1604-1607)."""
+        self.affinity_student.eval()
+        if self.vlm is None:
+            raise RuntimeError("no 2D VLM attached: pass vlm=... (the X-Decoder itself is out of scope)")
+        hp = self._hot_path()
+        batch = batch_data if isinstance(batch_data, SceneBatch) else self._batch_from_tuple(batch_data, hp.device)
+        return hp.evaluate_scene(batch, self.vlm)
+
+    def forward(self, batch_data):
+        raise NotImplementedError("training step (Sonata-teacher distillation, affinity_module.py:1138-1237) is a "
+                                  "SURVEY.md 8f 'next' row; this round covers the inference hot path")

@@ -1,4 +1,7 @@
 // Exact 1-NN fill (sklearn KDTree k=1 semantics), classify/argmax, IoU histograms (row 13).
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
 #include "gp_common.h"
 
 namespace {
@@ -46,6 +49,80 @@ __global__ void nn1_reduce_kernel(const double *__restrict__ pd, const int64_t *
         if (d < best) { best = d; bi = pi[(int64_t)s * n_q + q]; }
     }
     nn[q] = bi;
+}
+
+
+// ---- masked variant: references / queries are subsets of one point array, selected by byte masks.
+// Ordered compaction (exclusive scans) keeps ascending point ids, so "lowest index wins ties" holds.
+__global__ void mask_flags_kernel(const uint8_t *__restrict__ rm, const uint8_t *__restrict__ qm, int64_t n,
+                                  int32_t *__restrict__ rf, int32_t *__restrict__ qf) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) { rf[i] = rm[i] ? 1 : 0; qf[i] = qm[i] ? 1 : 0; }
+}
+__global__ void mask_compact_kernel(const float *__restrict__ xyz, const uint8_t *__restrict__ rm,
+                                    const uint8_t *__restrict__ qm, const int32_t *__restrict__ rs,
+                                    const int32_t *__restrict__ qs, int64_t n, float *__restrict__ rxyz,
+                                    int64_t *__restrict__ ridx, int64_t *__restrict__ qidx, int32_t *__restrict__ counts,
+                                    int64_t *__restrict__ nn) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    nn[i] = -1;
+    if (rm[i]) {
+        int p = rs[i];
+        rxyz[p * 3] = xyz[i * 3]; rxyz[p * 3 + 1] = xyz[i * 3 + 1]; rxyz[p * 3 + 2] = xyz[i * 3 + 2];
+        ridx[p] = i;
+    }
+    if (qm[i]) qidx[qs[i]] = i;
+    if (i == n - 1) { counts[0] = rs[i] + (rm[i] ? 1 : 0); counts[1] = qs[i] + (qm[i] ? 1 : 0); }
+}
+// one query per thread, the whole compacted reference set streamed through LDS tiles
+__global__ void __launch_bounds__(256)
+nn1_masked_kernel(const float *__restrict__ xyz, const float *__restrict__ rxyz, const int64_t *__restrict__ ridx,
+                  const int64_t *__restrict__ qidx, const int32_t *__restrict__ counts, int64_t *__restrict__ nn) {
+    __shared__ double sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
+    const int n_ref = counts[0], n_q = counts[1];
+    if ((int64_t)blockIdx.x * 256 >= n_q || n_ref == 0) return;
+    int64_t qi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t q = qi < n_q ? qidx[qi] : -1;
+    double qx = 0, qy = 0, qz = 0;
+    if (q >= 0) { qx = xyz[q * 3]; qy = xyz[q * 3 + 1]; qz = xyz[q * 3 + 2]; }
+    double best = INFINITY;
+    int bi = -1;
+    for (int t0 = 0; t0 < n_ref; t0 += NN_TILE) {
+        int cnt = n_ref - t0 < NN_TILE ? n_ref - t0 : NN_TILE;
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += 256) {
+            sx[j] = rxyz[(int64_t)(t0 + j) * 3]; sy[j] = rxyz[(int64_t)(t0 + j) * 3 + 1]; sz[j] = rxyz[(int64_t)(t0 + j) * 3 + 2];
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            double dx = qx - sx[j], dy = qy - sy[j], dz = qz - sz[j];
+            double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; bi = t0 + j; }
+        }
+    }
+    if (q >= 0) nn[q] = ridx[bi];
+}
+
+// ---- ordered compaction of the visible points of one view: (point id, pixel row, pixel col)
+__global__ void vis_flags_kernel(const int64_t *__restrict__ mapping, int64_t n, int32_t *__restrict__ f) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) f[i] = mapping[i * 3 + 2] != 0 ? 1 : 0;
+}
+__global__ void vis_compact_kernel(const int64_t *__restrict__ mapping, const int32_t *__restrict__ sc, int64_t n,
+                                   int64_t *__restrict__ pt, int64_t *__restrict__ x, int64_t *__restrict__ y,
+                                   int64_t *__restrict__ count) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool v = mapping[i * 3 + 2] != 0;
+    if (v) { int p = sc[i]; pt[p] = i; x[p] = mapping[i * 3]; y[p] = mapping[i * 3 + 1]; }
+    if (i == n - 1) *count = sc[i] + (v ? 1 : 0);
+}
+
+size_t scan32_tmp(int64_t n) {
+    size_t t = 0;
+    (void)rocprim::exclusive_scan(nullptr, t, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), 0);
+    return t;
 }
 
 int nn1_splits(int64_t n_ref, int64_t n_q) {
@@ -130,6 +207,65 @@ extern "C" int gp_nn1_f64(const float *ref_xyz, int64_t n_ref, const float *quer
     dim3 grid((unsigned)((n_query + 255) / 256), (unsigned)s);
     nn1_partial_kernel<<<grid, 256, 0, st>>>(ref_xyz, n_ref, query_xyz, n_query, s, pd, pi);
     nn1_reduce_kernel<<<(int)((n_query + 255) / 256), 256, 0, st>>>(pd, pi, n_query, s, nn);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+
+extern "C" size_t gp_nn1_masked_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    GpCarver cv(nullptr, 0);
+    cv.take<int32_t>(n); cv.take<int32_t>(n); cv.take<int32_t>(n); cv.take<int32_t>(n);
+    cv.take<float>(3 * n); cv.take<int64_t>(n); cv.take<int64_t>(n); cv.take<int32_t>(64);
+    cv.take<char>(scan32_tmp(n));
+    return cv.off;
+}
+
+extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref_mask, const uint8_t *query_mask,
+                                 int64_t *nn, void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(xyz && ref_mask && query_mask && nn && workspace, "gp_nn1_masked_f64: null argument");
+    GP_CHECK_ARG(n > 0 && n < (1ll << 31), "gp_nn1_masked_f64: n=%lld out of range", (long long)n);
+    GpCarver cv(workspace, workspace_bytes);
+    int32_t *rf = cv.take<int32_t>(n), *qf = cv.take<int32_t>(n), *rs = cv.take<int32_t>(n), *qs = cv.take<int32_t>(n);
+    float *rxyz = cv.take<float>(3 * n);
+    int64_t *ridx = cv.take<int64_t>(n), *qidx = cv.take<int64_t>(n);
+    int32_t *counts = cv.take<int32_t>(64);
+    size_t tb = scan32_tmp(n);
+    char *tmp = cv.take<char>(tb);
+    if (!cv.ok()) { gp_set_error("gp_nn1_masked_f64: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
+    hipStream_t st = gp_stream(stream_);
+    int blocks = (int)((n + 255) / 256);
+    mask_flags_kernel<<<blocks, 256, 0, st>>>(ref_mask, query_mask, n, rf, qf);
+    size_t t = tb;
+    GP_CHECK_HIP(rocprim::exclusive_scan(tmp, t, rf, rs, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), st));
+    t = tb;
+    GP_CHECK_HIP(rocprim::exclusive_scan(tmp, t, qf, qs, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), st));
+    mask_compact_kernel<<<blocks, 256, 0, st>>>(xyz, ref_mask, query_mask, rs, qs, n, rxyz, ridx, qidx, counts, nn);
+    nn1_masked_kernel<<<blocks, 256, 0, st>>>(xyz, rxyz, ridx, qidx, counts, nn);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" size_t gp_visible_lists_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    GpCarver cv(nullptr, 0);
+    cv.take<int32_t>(n); cv.take<int32_t>(n); cv.take<char>(scan32_tmp(n));
+    return cv.off;
+}
+
+extern "C" int gp_visible_lists(const int64_t *mapping, int64_t n, int64_t *pt, int64_t *x, int64_t *y,
+                                int64_t *count_dev, void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(mapping && pt && x && y && count_dev && workspace && n > 0, "gp_visible_lists: null/empty argument");
+    GpCarver cv(workspace, workspace_bytes);
+    int32_t *f = cv.take<int32_t>(n), *sc = cv.take<int32_t>(n);
+    size_t tb = scan32_tmp(n);
+    char *tmp = cv.take<char>(tb);
+    if (!cv.ok()) { gp_set_error("gp_visible_lists: workspace too small"); return GP_ENOMEM; }
+    hipStream_t st = gp_stream(stream_);
+    int blocks = (int)((n + 255) / 256);
+    vis_flags_kernel<<<blocks, 256, 0, st>>>(mapping, n, f);
+    GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, f, sc, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), st));
+    vis_compact_kernel<<<blocks, 256, 0, st>>>(mapping, sc, n, pt, x, y, count_dev);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

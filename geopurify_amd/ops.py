@@ -295,6 +295,30 @@ def nn1(ref_xyz, query_xyz):
     return nn
 
 
+def nn1_masked(xyz, ref_mask, query_mask, workspace=None):
+    """nn[i] = nearest point with ref_mask among xyz for every i with query_mask, else -1.  No sync."""
+    lib = _lib.load()
+    _chk(xyz, torch.float32, "xyz")
+    n = xyz.shape[0]
+    nn = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    need = lib.gp_nn1_masked_workspace_bytes(n)
+    if workspace is None or workspace.numel() < need:
+        workspace = _ws(need, xyz.device)
+    check(lib.gp_nn1_masked_f64(_ptr(xyz), n, _ptr(ref_mask), _ptr(query_mask), _ptr(nn), _ptr(workspace),
+                                workspace.numel(), _stream()), "gp_nn1_masked_f64")
+    return nn
+
+
+def visible_lists(mapping, pt, x, y, count_dev, workspace=None):
+    lib = _lib.load()
+    n = mapping.shape[0]
+    need = lib.gp_visible_lists_workspace_bytes(n)
+    if workspace is None or workspace.numel() < need:
+        workspace = _ws(need, mapping.device)
+    check(lib.gp_visible_lists(_ptr(mapping), n, _ptr(pt), _ptr(x), _ptr(y), _ptr(count_dev), _ptr(workspace),
+                               workspace.numel(), _stream()), "gp_visible_lists")
+
+
 # ------------------------------------------------------------------------------------------ row 13
 def classify_argmax(feat, text_norm, logit_scale, d=None):
     lib = _lib.load()

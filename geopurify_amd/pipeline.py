@@ -1,0 +1,374 @@
+"""Device-resident per-scene hot path: loader math -> 2D->3D lift -> student -> kNN affinity -> pooling.
+
+Host orchestration only: every numeric step is a HIP kernel reached through the C-ABI
+(geopurify_amd.ops).  Mirrors, stage by stage, the reference call stack of SURVEY.md 3.1:
+  dataset/data_loader_ablation.py:242-264,348-372  (mapper, visible lists, scene voxelization)
+  models/affinity_module.py:455-714               (lift_xdecoder_features)   / :348-453 (dense lift)
+  models/affinity_module.py:1491-1607             (evaluate_scene)
+  run/validation.py:413-439                       (classify + IoU counts)
+Voxel-level arrays live in an internal Morton order (perm/rank); outputs are per point, so the
+order never leaks.  Host synchronisations per scene: voxel count + extent (one readback) and the
+per-view visible counts (one readback).
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .bicubic import aa_bicubic_taps
+
+GEO_DIM = 6
+CONV_PAD = 32                     # gp_sparse_conv needs cin % 32 == 0
+
+
+def _pad_to(v, m):
+    return (v + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------------------
+class StudentWeights:
+    """Device copy of an AffinityPredictor state_dict (ME layout) with the input
+    kernel zero-padded to a multiple of 32 channels and BatchNorm(eval) folded to scale/shift."""
+
+    def __init__(self, state_dict, device, eps=1e-5):
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        w0 = sd["input_layer.0.kernel"].float()
+        self.cin = w0.shape[1]
+        self.cin_pad = _pad_to(self.cin, CONV_PAD)
+        self.hidden = w0.shape[2]
+        w0p = torch.zeros((27, self.cin_pad, self.hidden), dtype=torch.float32)
+        w0p[:, :self.cin] = w0
+        self.w_in = w0p.to(device).contiguous()
+        self.bn_in = self._fold(sd, "input_layer.1", device, eps)
+        self.blocks = []
+        i = 0
+        while f"res_blocks.{i}.conv1.kernel" in sd:
+            self.blocks.append((
+                sd[f"res_blocks.{i}.conv1.kernel"].float().to(device).contiguous(),
+                self._fold(sd, f"res_blocks.{i}.norm1", device, eps),
+                sd[f"res_blocks.{i}.conv2.kernel"].float().to(device).contiguous(),
+                self._fold(sd, f"res_blocks.{i}.norm2", device, eps)))
+            i += 1
+        self.w_out = sd["output_layer.kernel"].float().to(device).contiguous()
+        self.embed = self.w_out.shape[1]
+
+    @staticmethod
+    def _fold(sd, prefix, device, eps):
+        s = sd[prefix + ".bn.weight"].float() / torch.sqrt(sd[prefix + ".bn.running_var"].float() + eps)
+        b = sd[prefix + ".bn.bias"].float() - sd[prefix + ".bn.running_mean"].float() * s
+        return s.to(device).contiguous(), b.to(device).contiguous()
+
+    def forward(self, x, nbr_map):
+        """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed]."""
+        h = ops.sparse_conv(x, nbr_map, self.w_in, self.bn_in[0], self.bn_in[1], relu=True)
+        for w1, bn1, w2, bn2 in self.blocks:
+            t = ops.sparse_conv(h, nbr_map, w1, bn1[0], bn1[1], relu=True)
+            h = ops.sparse_conv(t, nbr_map, w2, bn2[0], bn2[1], residual=h, relu=True)
+        e = ops.sparse_conv(h, None, self.w_out)
+        return ops.l2norm_rows_(e)
+
+    def flops(self, num_pairs, nv):
+        per_pair = self.cin * self.hidden + 2 * len(self.blocks) * self.hidden * self.hidden
+        return 2.0 * num_pairs * per_pair + 2.0 * nv * self.hidden * self.embed
+
+
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class ViewLists:
+    pt: torch.Tensor              # i64 [n_v] ascending ids of the visible points
+    x: torch.Tensor               # i64 [n_v] pixel row  (x_label)
+    y: torch.Tensor               # i64 [n_v] pixel col  (y_label)
+    src_view: int                 # index of the view before dropping (for the VLM outputs)
+
+
+@dataclass
+class SceneBatch:
+    """Device-side equivalent of the 20-tuple of scene_based_collate_fn
+    (dataset/data_loader_ablation.py:429-495), holding what evaluate_scene reads."""
+    scene_coords: torch.Tensor            # f32 [N,3]
+    scene_coords_3d: torch.Tensor         # f32 [Nv,3] integer-valued voxel coords (hash order)
+    scene_inds_reconstruct: torch.Tensor  # i64 [N]
+    scene_label: torch.Tensor             # i64 [N]
+    scene_gauss_features: torch.Tensor    # f32 [N,6]
+    views: List[ViewLists] = field(default_factory=list)
+    order: Optional[torch.Tensor] = None       # CSR of each voxel's points (from the voxelizer sort)
+    seg_start: Optional[torch.Tensor] = None
+    extent: Optional[list] = None              # host ints: max voxel coord + 1 per axis (min is 0)
+
+    def as_tuple(self):
+        """The reference's positional 20-tuple (unused per-view voxelization slots are empty)."""
+        dev = self.scene_coords.device
+        N = self.scene_coords.shape[0]
+        e = torch.empty(0, device=dev)
+        V = len(self.views)
+        ori = torch.cat([torch.cat([torch.full((len(v.pt), 1), float(i), device=dev),
+                                    self.scene_coords[v.pt]], 1) for i, v in enumerate(self.views)]) if V else e
+        mask = torch.zeros((V, N), dtype=torch.long, device=dev)
+        for i, v in enumerate(self.views):
+            mask[i, v.pt] = 1
+        vid = torch.arange(V, device=dev).repeat_interleave(N)
+        mask_2ds = torch.stack([vid, mask.reshape(-1)], 1)
+        xl = torch.cat([v.x for v in self.views]) if V else e.long()
+        yl = torch.cat([v.y for v in self.views]) if V else e.long()
+        return (self.scene_coords, self.scene_coords_3d, self.scene_inds_reconstruct, self.scene_label, ori,
+                e, e, e, e, e, e, e, xl, yl, mask_2ds, e, e, e, (None,) * V, self.scene_gauss_features)
+
+
+def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000):
+    """Loader math on the device for one synthetic scene (geopurify_amd.synthetic.Scene):
+    scene voxelization (rows 1-2), per-view mapping (row 3), visible lists and the view-drop rule
+    (data_loader_ablation.py:254-255,280-288)."""
+    from .synthetic import mapper_intrinsics
+    cfg = scene.cfg
+    dev = torch.device(device)
+    coords64 = scene.coords_dev if hasattr(scene, "coords_dev") else torch.from_numpy(scene.coords).to(dev)
+    N = coords64.shape[0]
+    vox = ops.voxelize(coords64, rigid)                                   # sync #1 (nv)
+    W, H = cfg.image_dim
+    V = len(scene.views)
+    depth_dev = scene.depth_dev if hasattr(scene, "depth_dev") else [torch.from_numpy(v.depth).to(dev) for v in scene.views]
+    pt = torch.empty((V, N), dtype=torch.int64, device=dev)
+    xs = torch.empty((V, N), dtype=torch.int64, device=dev)
+    ys = torch.empty((V, N), dtype=torch.int64, device=dev)
+    counts = torch.zeros(V + 3, dtype=torch.int64, device=dev)
+    ws = None
+    for i, v in enumerate(scene.views):
+        K = mapper_intrinsics(cfg, v.K)
+        if cfg.dataset == "scannet":
+            w2c = np.asarray(v.pose).T.astype(np.float64)                 # fusion_util.py:114 (W2C^T float32 -> .T)
+        else:
+            w2c = np.linalg.inv(np.asarray(v.pose))                       # fusion_util.py:60 (inverse of the fp32 c2w)
+        mapping = ops.project_points(coords64, w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], depth_dev[i], W, H,
+                                     cfg.cut_bound, cfg.vis_thres)
+        if ws is None:
+            ws = torch.empty(ops._lib.load().gp_visible_lists_workspace_bytes(N), dtype=torch.uint8, device=dev)
+        ops.visible_lists(mapping, pt[i], xs[i], ys[i], counts[i:i + 1], ws)
+    counts[V:V + 3] = vox["coords_aug"].amax(0).to(torch.int64) + 1
+    host = counts.cpu().tolist()                                          # sync #2 (n_v per view + extent)
+    views = []
+    for i in range(V):
+        n_v = host[i]
+        if n_v == 0 or n_v < cfg.min_visible or n_v > val_keep:
+            continue
+        views.append(ViewLists(pt[i, :n_v], xs[i, :n_v], ys[i, :n_v], i))
+    gauss = scene.gauss_dev if hasattr(scene, "gauss_dev") else torch.from_numpy(
+        np.concatenate([scene.colors, scene.normals], 1).astype(np.float32)).to(dev)
+    labels = scene.labels_dev if hasattr(scene, "labels_dev") else torch.from_numpy(scene.labels).to(dev)
+    return SceneBatch(coords64.float(), vox["coords_aug"].float(), vox["inds_reconstruct"], labels, gauss, views,
+                      vox["order"], vox["seg_start"], host[V:V + 3])
+
+
+def upload_scene(scene, device="cuda"):
+    """Make the raw inputs resident in HBM (outside any timed region)."""
+    dev = torch.device(device)
+    scene.coords_dev = torch.from_numpy(scene.coords).to(dev)
+    scene.depth_dev = [torch.from_numpy(v.depth).to(dev) for v in scene.views]
+    scene.gauss_dev = torch.from_numpy(np.concatenate([scene.colors, scene.normals], 1).astype(np.float32)).to(dev)
+    scene.labels_dev = torch.from_numpy(scene.labels).to(dev)
+    return scene
+
+
+# --------------------------------------------------------------------------------------------------
+class SyntheticVLM:
+    """Stand-in for the frozen X-Decoder (out of scope, weights unavailable offline): returns the five
+    outputs the lift consumes (SURVEY.md 8a'), pre-generated per view and resident on the device."""
+
+    def __init__(self, outputs, device="cuda"):
+        dev = torch.device(device)
+        self.pred_masks = torch.as_tensor(outputs["pred_masks"]).to(dev)
+        self.pred_logits = torch.as_tensor(outputs["pred_logits"]).to(dev)
+        self.mask_embed = torch.as_tensor(outputs["mask_embed"]).to(dev)
+        self.text_embed = torch.as_tensor(outputs["text_embed"]).to(dev)
+        self.logit_scale = float(outputs["logit_scale"])
+
+    def __call__(self, view_index):
+        return {"pred_masks": self.pred_masks[view_index], "pred_logits": self.pred_logits[view_index],
+                "mask_embed": self.mask_embed[view_index], "text_embed": self.text_embed,
+                "logit_scale": self.logit_scale}
+
+
+class DenseFeatureVLM:
+    """P config: dense per-pixel feature maps [V,D,H,W] (LSeg-style lift, affinity_module.py:416-449)."""
+
+    def __init__(self, feat_maps, text_embed, logit_scale, device="cuda"):
+        dev = torch.device(device)
+        self.feat = torch.as_tensor(feat_maps).to(dev)
+        self.text_embed = torch.as_tensor(text_embed).to(dev)
+        self.logit_scale = float(logit_scale)
+
+
+# --------------------------------------------------------------------------------------------------
+class HotPath:
+    """evaluate_scene on the device.  K, sharpen and num_iters are the reference's hard-coded
+    constants (affinity_module.py:1492-1493,1584-1587) exposed as options."""
+
+    def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda"):
+        self.student = student
+        self.mask_shape = tuple(mask_shape)
+        self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
+        self.device = torch.device(device)
+        self._taps = {}
+        self.stats = {}
+
+    def _tap_tables(self, h, w):
+        key = (h, w)
+        if key not in self._taps:
+            H, W = self.mask_shape
+            tx0, twx = aa_bicubic_taps(w, W)
+            ty0, twy = aa_bicubic_taps(h, H)
+            d = self.device
+            self._taps[key] = tuple(torch.from_numpy(a).to(d) for a in (tx0, twx, ty0, twy))
+        return self._taps[key]
+
+    # ---- rows 6-7 -------------------------------------------------------------------------------
+    def lift_masks(self, batch: SceneBatch, vlm: SyntheticVLM):
+        dev = self.device
+        N = batch.scene_coords.shape[0]
+        V = len(batch.views)
+        text_norm = torch.nn.functional.normalize(vlm.text_embed, dim=-1).contiguous()
+        Q, D = vlm.mask_embed.shape[1:]
+        C = text_norm.shape[0]
+        f_seg = torch.empty((max(V, 1), Q, D), dtype=torch.float32, device=dev)
+        l_seg = torch.empty((max(V, 1), Q, C), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        segs = []
+        ws_m = ws_n = None
+        for i, v in enumerate(batch.views):
+            out = vlm(v.src_view)
+            pm = out["pred_masks"]
+            scores = torch.softmax(out["pred_logits"], dim=-1)[..., :-1].max(-1).values.contiguous()
+            if ws_m is None:
+                lib = ops._lib.load()
+                ws_m = torch.empty(lib.gp_lift_masks_workspace_bytes(*pm.shape), dtype=torch.uint8, device=dev)
+                ws_n = torch.empty(lib.gp_nn1_masked_workspace_bytes(N), dtype=torch.uint8, device=dev)
+            seg = ops.lift_masks_view(pm, scores, self._tap_tables(pm.shape[1], pm.shape[2]), self.mask_shape,
+                                      v.x, v.y, workspace=ws_m)
+            # in-view fill of uncovered points from the nearest covered point of the same view (:604-625)
+            xyz = batch.scene_coords[v.pt].contiguous()
+            covered = (seg >= 0).to(torch.uint8)
+            nn = ops.nn1_masked(xyz, covered, 1 - covered, workspace=ws_n)
+            seg = torch.where(nn >= 0, seg[nn.clamp(min=0)], seg)
+            ops.segment_tables(out["mask_embed"].contiguous(), text_norm, out["logit_scale"], f_seg[i], l_seg[i])
+            ops.pv_count(v.pt, cnt)
+            segs.append(seg)
+        start = ops.exclusive_scan_i64(cnt)
+        total = sum(len(v.pt) for v in batch.views)
+        cursor = torch.zeros(N, dtype=torch.int32, device=dev)
+        pvv = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        pvs = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        for i, v in enumerate(batch.views):
+            ops.pv_fill(v.pt, segs[i], i, start, cursor, pvv, pvs)
+        F = torch.empty((N, D), dtype=torch.float32, device=dev)
+        seen = ops.fuse_views_top3(start, pvv, pvs, N, f_seg, l_seg, F)
+        # scene-level fill of never-seen points (:687-696)
+        nn = ops.nn1_masked(batch.scene_coords, seen, 1 - seen)
+        src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
+        F = ops.gather_rows(F, D, src)
+        return F, vlm.text_embed, vlm.logit_scale
+
+    # ---- row 5 ----------------------------------------------------------------------------------
+    def lift_dense(self, batch: SceneBatch, vlm: DenseFeatureVLM):
+        dev = self.device
+        N = batch.scene_coords.shape[0]
+        D = vlm.feat.shape[1]
+        s = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(N, dtype=torch.float32, device=dev)
+        for v in batch.views:
+            ops.lift_dense_accum(vlm.feat[v.src_view], v.pt, v.x, v.y, s, cnt)
+        seen = ops.lift_dense_finish(s, D, cnt)
+        nn = ops.nn1_masked(batch.scene_coords, seen, 1 - seen)
+        src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
+        return ops.gather_rows(s, D, src), vlm.text_embed, vlm.logit_scale
+
+    # ---- rows 8-12 ------------------------------------------------------------------------------
+    def refine(self, batch: SceneBatch, F):
+        """evaluate_scene after the lift (affinity_module.py:1524-1589). F fp32 [N,D] -> [N,D]."""
+        dev = self.device
+        N, D = F.shape
+        st = self.student
+        assert st.cin == D + GEO_DIM, f"student expects {st.cin} input channels, lift gives {D}+{GEO_DIM}"
+        coords = batch.scene_coords_3d.floor().to(torch.int32).contiguous()      # batched_coordinates floors (:1543)
+        Nv = coords.shape[0]
+        perm, rank = ops.morton_order(coords)
+        cs = coords[perm.long()].contiguous()
+        if batch.order is None:                                               # generic tuple input: CSR from the index
+            order = torch.sort(batch.scene_inds_reconstruct, stable=True).indices
+            segc = torch.zeros(Nv + 1, dtype=torch.int64, device=dev)
+            segc[1:] = torch.bincount(batch.scene_inds_reconstruct, minlength=Nv).cumsum(0)
+            batch.order, batch.seg_start = order, segc
+        X = torch.zeros((Nv, st.cin_pad), dtype=torch.float32, device=dev)
+        ops.scatter_mean_csr(F, D, batch.order, batch.seg_start, Nv, X, col0=0, row_map=rank)
+        ops.scatter_mean_csr(batch.scene_gauss_features, GEO_DIM, batch.order, batch.seg_start, Nv, X, col0=D,
+                             row_map=rank)
+        if batch.extent is not None:
+            grid = ops.grid_build(cs, [0, 0, 0], batch.extent)
+        else:
+            grid = ops.grid_build(cs)
+        nbr_map = ops.kernel_map_build(grid, cs)
+        E = st.forward(X, nbr_map)
+        nbr = ops.knn_lattice(grid, cs, perm, self.K)
+        w = ops.affinity_softmax(E, nbr, self.sharpen)
+        bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
+        cur = X
+        for t in range(self.num_iters):
+            ops.pool_ell(cur, nbr, w, D, bufs[t % 2])
+            cur = bufs[t % 2]
+        out = ops.gather_rows(cur, D, batch.scene_inds_reconstruct, row_map=rank)
+        self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8)}
+        return out
+
+    def evaluate_scene(self, batch: SceneBatch, vlm):
+        if isinstance(vlm, DenseFeatureVLM):
+            F, text, scale = self.lift_dense(batch, vlm)
+        else:
+            F, text, scale = self.lift_masks(batch, vlm)
+        return {"scene_features": self.refine(batch, F), "text_features": text, "logit_scale": scale}
+
+    # ---- row 13 + caller tail --------------------------------------------------------------------
+    def classify_and_count(self, result, labels, num_classes, ignore_ids, counts):
+        text_norm = torch.nn.functional.normalize(result["text_features"], dim=-1).contiguous()
+        pred, zero = ops.classify_argmax(result["scene_features"], text_norm, result["logit_scale"])
+        ops.iou_hist(pred, labels, num_classes, ignore_ids, counts)
+        return pred, zero
+
+
+# --------------------------------------------------------------------------------------------------
+def random_student_state_dict(input_dim, hidden=512, embed=128, num_blocks=4, seed=0):
+    """Random-init weights of the AffinityPredictor architecture in the ME state_dict layout
+    (He-normal kernels; BN statistics near identity).  No checkpoint is available offline."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def kern(ci, co, kv=27):
+        std = (2.0 / (kv * ci)) ** 0.5
+        return torch.randn((kv, ci, co) if kv > 1 else (ci, co), generator=g) * std
+
+    def bn(prefix, c):
+        sd[prefix + ".bn.weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[prefix + ".bn.bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[prefix + ".bn.running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[prefix + ".bn.running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
+        sd[prefix + ".bn.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    sd["input_layer.0.kernel"] = kern(input_dim, hidden)
+    bn("input_layer.1", hidden)
+    for i in range(num_blocks):
+        sd[f"res_blocks.{i}.conv1.kernel"] = kern(hidden, hidden)
+        bn(f"res_blocks.{i}.norm1", hidden)
+        sd[f"res_blocks.{i}.conv2.kernel"] = kern(hidden, hidden)
+        bn(f"res_blocks.{i}.norm2", hidden)
+    sd["output_layer.kernel"] = kern(hidden, embed, kv=1)
+    return sd
+
+
+def scene_rigid_transform(voxel_size, seed):
+    """Host mirror of Voxelizer.get_transformation_matrix (dataset/voxelizer.py:32-58) with the
+    always-on augmentation of Point3DLoader (dataset/point_loader.py:54-60,100-107): consumes
+    np.random in the reference's order.  Returns M_r @ M_v."""
+    from .voxelizer import Voxelizer, default_voxelizer
+    np.random.seed(seed)
+    vox = default_voxelizer(voxel_size)
+    M_v, M_r = vox.get_transformation_matrix()
+    return M_r @ M_v

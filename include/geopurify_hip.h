@@ -176,6 +176,18 @@ int gp_fuse_views_top3(const int64_t *pv_start, const int32_t *pv_view, const in
 size_t gp_nn1_workspace_bytes(int64_t n_ref, int64_t n_query);
 int gp_nn1_f64(const float *ref_xyz, int64_t n_ref, const float *query_xyz, int64_t n_query,
                int64_t *nn, void *workspace, size_t workspace_bytes, void *stream);
+/* masked form (no host synchronisation): references = points with ref_mask != 0, queries = points  */
+/* with query_mask != 0, both subsets of xyz fp32 [n,3]; nn i64 [n] = index into xyz for queries,    */
+/* -1 elsewhere.  If there is no reference point nn stays -1 everywhere.                            */
+size_t gp_nn1_masked_workspace_bytes(int64_t n);
+int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref_mask, const uint8_t *query_mask,
+                      int64_t *nn, void *workspace, size_t workspace_bytes, void *stream);
+/* Loader glue (dataset/data_loader_ablation.py:257-264,348-351): ordered lists of the visible      */
+/* points of one view from its mapping i64 [n,3]: pt (ascending ids), x = pixel row, y = pixel col;  */
+/* *count_dev receives n_v.  Outputs must hold n entries.                                           */
+size_t gp_visible_lists_workspace_bytes(int64_t n);
+int gp_visible_lists(const int64_t *mapping, int64_t n, int64_t *pt, int64_t *x, int64_t *y,
+                     int64_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row 13 + caller tail (run/validation.py:413-416, util/util.py:160-177).                        */

@@ -1,0 +1,89 @@
+"""CPU tests of the host-side mirrors (no GPU compute): config loader, state_dict layout, voxelizer
+matrices / RNG order, bicubic tap tables, synthetic scenes, scene sharding."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from geopurify_amd import config as gp_config
+
+
+def test_config_flatten_and_overrides(tmp_path):
+    y = tmp_path / "c.yaml"
+    y.write_text("DATA:\n  voxel_size: 0.02\n  mask_shape: [484, 648]\n  category_split:\n    base_category: [0, 1]\n"
+                 "  save_path:\nTEST:\n  test_classes: 19\n  label: ['a', 'b']\n")
+    c = gp_config.load_cfg_from_cfg_file(str(y))
+    assert c.voxel_size == 0.02 and c.test_classes == 19 and c.category_split.base_category == [0, 1]
+    c2 = gp_config.merge_cfg_from_list(c, ["voxel_size", "0.05", "save_path", "out/x", "label", "('x','y')"])
+    assert c2.voxel_size == 0.05 and c2.save_path == "out/x" and c2.label == ["x", "y"] and c.voxel_size == 0.02
+    with pytest.raises(ValueError):
+        gp_config.merge_cfg_from_list(c, ["test_classes", "abc"])
+    with pytest.raises(AssertionError):
+        gp_config.merge_cfg_from_list(c, ["nope", "1"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/config"), reason="reference yamls only exist in the build container")
+def test_config_matches_reference_flattening(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "config_flat.json")))
+    for fn, ref in g.items():
+        if fn.startswith("__"):
+            continue
+        c = gp_config.load_cfg_from_cfg_file(os.path.join("/root/reference/config", fn))
+        assert json.loads(json.dumps(dict(c), default=lambda o: dict(o))) == ref
+
+
+def test_student_state_dict_layout():
+    from geopurify_amd.affinity_module import AffinityPredictor
+    m = AffinityPredictor(518, embed_dim=128, hidden_dim=512)
+    sd = m.state_dict()
+    assert tuple(sd["input_layer.0.kernel"].shape) == (27, 518, 512)
+    assert tuple(sd["res_blocks.3.conv2.kernel"].shape) == (27, 512, 512)
+    assert tuple(sd["output_layer.kernel"].shape) == (512, 128)
+    for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+        assert f"input_layer.1.bn.{k}" in sd and f"res_blocks.0.norm2.bn.{k}" in sd
+    g = m.get_param_groups()
+    assert len(g["input"]) == 3 and len(g["middle"]) == 4 * 6 and len(g["output"]) == 1
+    assert sum(p.numel() for p in m.parameters()) == 27 * 518 * 512 + 8 * 27 * 512 * 512 + 512 * 128 + 9 * 2 * 512
+
+
+def test_voxelizer_matrices_follow_reference_rng(golden_dir):
+    from geopurify_amd.voxelizer import default_voxelizer
+    g = np.load(os.path.join(golden_dir, "voxelize.npz"))
+    for case in (0, 1):
+        p = f"c{case}_"
+        np.random.seed(int(g[p + "seed"]))
+        M_v, M_r = default_voxelizer(float(g[p + "voxel_size"])).get_transformation_matrix()
+        assert np.array_equal(M_v, g[p + "M_v"]) and np.array_equal(M_r, g[p + "M_r"])
+
+
+def test_bicubic_taps_match_torch():
+    import torch.nn.functional as F
+    from geopurify_amd.bicubic import aa_bicubic_taps
+    for a, b in [(42, 162), (32, 121)]:
+        x0, w = aa_bicubic_taps(a, b)
+        eye = torch.eye(a).reshape(1, a, 1, a)
+        ref = F.interpolate(eye, size=(1, b), mode="bicubic", align_corners=False, antialias=True)[0, :, 0, :].numpy()
+        W = np.zeros((a, b), np.float32)
+        for i in range(b):
+            for j in range(4):
+                if w[i, j] != 0:
+                    W[x0[i] + j, i] = w[i, j]
+        assert np.abs(W - ref).max() < 1e-6
+    with pytest.raises(ValueError):
+        aa_bicubic_taps(100, 40)
+
+
+def test_synthetic_scene_shapes():
+    from geopurify_amd import synthetic as syn
+    cfg = syn.CONFIGS["T"]
+    s = syn.make_scene(cfg, 1)
+    assert s.coords.shape == (cfg.num_points, 3) and s.coords.dtype == np.float64
+    assert len(s.views) == cfg.num_views and s.views[0].depth.shape == (cfg.image_dim[1], cfg.image_dim[0])
+    s2 = syn.make_scene(cfg, 1)
+    assert np.array_equal(s.coords, s2.coords) and np.array_equal(s.views[1].depth, s2.views[1].depth)
+    v = syn.make_vlm_outputs(cfg, 2, 1)
+    H, W = cfg.mask_shape
+    assert v["pred_masks"].shape == (2, cfg.num_queries, ((H + 31) // 32) * 8, ((W + 31) // 32) * 8)
+    assert v["pred_logits"].shape == (2, cfg.num_queries, cfg.num_classes + 1)
