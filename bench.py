@@ -43,6 +43,19 @@ def parse():
     return ap.parse_args()
 
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Cores this process may actually use (cgroup / affinity share of the GPU box, capped at 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 class PoolTimer:
     """HIP events around every pooling launch, on the stream the kernels are launched on."""
 
@@ -96,7 +109,7 @@ def cpu_baseline(scene, vlm_np, sd, rigid, cfg, pool_iters, budget_s):
     import dataclasses
     from geopurify_amd import synthetic as syn
     from oracle import pipeline as o_pipe
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     torch.set_num_threads(threads)
     frac_pts, n_views = 0.2, max(2, cfg.num_views // 6)
     small_cfg = dataclasses.replace(cfg, num_points=int(cfg.num_points * frac_pts), num_views=n_views)
@@ -105,7 +118,8 @@ def cpu_baseline(scene, vlm_np, sd, rigid, cfg, pool_iters, budget_s):
                  for k, v in vlm_np.items()}
     timings = {}
     t0 = time.perf_counter()
-    o_pipe.evaluate_scene_oracle(small, vlm_small, sd, rigid, K=96, num_iters=pool_iters, timings=timings)
+    o_pipe.evaluate_scene_oracle(small, vlm_small, sd, rigid, K=96, num_iters=pool_iters, timings=timings,
+                                 knn_impl="kdtree")
     wall = time.perf_counter() - t0
     # scale: loader+lift ~ points x views ; fuse ~ points ; refine stages ~ voxels (~points)
     pv = (cfg.num_points * cfg.num_views) / (small_cfg.num_points * small_cfg.num_views)
@@ -113,10 +127,8 @@ def cpu_baseline(scene, vlm_np, sd, rigid, cfg, pool_iters, budget_s):
     est = 0.0
     for k, v in timings.items():
         est += v * (pv if k in ("loader(project+voxelize)", "lift per view") else pn)
-    # kNN brute force in the oracle is quadratic in voxels
-    est += timings.get("knn", 0.0) * (pn * pn - pn)
     return {"value": round(1.0 / est, 6), "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch-CPU/numpy/sklearn, vectorised variant) on {small_cfg.num_points} pts x {n_views} views "
+            "sample": f"oracle (torch-CPU/numpy/sklearn, vectorised variant, kNN by scipy cKDTree) on {small_cfg.num_points} pts x {n_views} views "
                       f"of the same scene generator, T={pool_iters}: {wall:.1f}s measured; extrapolated per stage to "
                       f"{cfg.num_points} pts x {cfg.num_views} views = {est:.1f} s/scene",
             "stages_s_sample": {k: round(v, 3) for k, v in timings.items()}}
@@ -141,7 +153,9 @@ def main():
     # ---- synthetic inputs, resident in HBM before timing ------------------------------------------
     scenes, vlms, rigids = [], [], []
     vlm_np0 = None
+    torch.set_num_threads(host_threads())
     for s in range(args.scenes):
+        log(f"rank {rank}: generating synthetic scene {s + 1}/{args.scenes} ({cfg.name})")
         seed = 5557 + 1000 * rank + s
         sc = syn.make_scene(cfg, seed)
         if cfg.dense_features:
@@ -192,9 +206,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    log("inputs resident; warm-up")
     for i in range(args.warmup):
         step(i)
     barrier()
+    log("timing")
     counts.zero_()
     pool_timer.enabled = True
     stage = StageTimer()
@@ -239,7 +255,9 @@ def main():
             "stages_ms_per_scene": {k: round(v / args.steps, 3) for k, v in stages.items()},
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
         }
+        log(f"gpu: {out['value']} scenes/s, {out['ms_per_step']} ms/scene; pooling {pool_ms:.3f} ms/launch")
         if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline (bounded sample of the oracle on the host cores)")
             try:
                 import dataclasses
                 out["cpu_baseline"] = cpu_baseline(scenes[0], vlm_np0, sd, rigids[0], cfg, args.pool_iters, args.cpu_seconds)

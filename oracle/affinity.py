@@ -41,6 +41,15 @@ def knn_lattice(voxel_coords, K, chunk=1024):
     return out
 
 
+def knn_kdtree(voxel_coords, K):
+    """Fast CPU kNN for the timing baseline only (scipy cKDTree, all cores): exact distances, but ties
+    are broken in tree order, not by (d2, id) -- never used as a parity reference."""
+    from scipy.spatial import cKDTree
+    c = np.asarray(voxel_coords, dtype=np.float64)
+    _, idx = cKDTree(c).query(c, k=K + 1, workers=-1)
+    return torch.from_numpy(idx[:, 1:].astype(np.int64))
+
+
 def affinity_weights(E, nbr, sharpen=20.0):
     """affinity_module.py:1559-1572: a_ij = <E_i, E_nbr(i,j)>, w = softmax_j(sharpen * a_ij)."""
     Nv, K = nbr.shape

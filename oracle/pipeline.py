@@ -47,7 +47,7 @@ def loader_math(scene, rigid, val_keep=10_000_000):
 
 
 def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=19, vectorised=True,
-                          dense_feat=None, timings=None, num_blocks=None):
+                          dense_feat=None, timings=None, num_blocks=None, knn_impl="exact"):
     """Returns dict(scene_features [N,D], text_features, logit_scale, + intermediates)."""
     cfg = scene.cfg
     t0 = time.perf_counter()
@@ -90,7 +90,7 @@ def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=1
         num_blocks = sum(1 for k in sd if k.endswith(".conv1.kernel"))
     E = student.student_forward(X, coords_i, sd, num_blocks=num_blocks)
     tick("student")
-    nbr = affinity.knn_lattice(coords_i, K)
+    nbr = affinity.knn_lattice(coords_i, K) if knn_impl == "exact" else affinity.knn_kdtree(coords_i, K)
     tick("knn")
     w = affinity.affinity_weights(E, nbr, sharpen)
     tick("affinity")
