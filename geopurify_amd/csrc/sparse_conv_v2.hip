@@ -1,0 +1,313 @@
+// Row 9, fast path: submanifold sparse convolution as a per-offset gather-GEMM on the f16 matrix
+// cores with fp32-class accuracy, followed by a deterministic per-voxel sum.
+//
+//   pairs     For every kernel offset k the (input row, output row) pairs are compacted once per
+//             scene (flags -> scan -> scatter over the [27,Nv] kernel map); pair_pos[k][u] is the
+//             global pair index of (k,u) or -1.
+//   phase 1   P[pair, :] = X[in(pair), :] @ W[k]      (256 pairs x 256 channels per workgroup,
+//             accumulators in registers, Cin reduced in 32-channel steps through a double-buffered
+//             LDS ring).  fp32 operands are split on the fly into two f16 halves x = hi + lo
+//             (|x - hi - lo| <= 2^-22 |x|); the product keeps hi*hi + hi*lo + lo*hi, three
+//             v_mfma_f32_16x16x32_f16 per tile with fp32 accumulation -- every f16 product is exact in
+//             fp32, the dropped lo*lo term is 2^-22 relative.  Weights are pre-split, pre-scaled by a
+//             power of two and stored [k][cout][cin] so that the B fragment is a straight 16-byte read.
+//   phase 2   Y[u, :] = epilogue( sum_k P[pair_pos[k][u], :] )  in ascending k (bitwise reproducible),
+//             BatchNorm(eval) scale/shift, residual, ReLU fused.
+//
+// Weight re-use is per offset (all pairs of k stream through W[k]) instead of per output tile, which
+// cuts the weight traffic from L2 by ~8x against the output-stationary v1 kernel.
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include <hip/hip_fp16.h>
+
+#include "gp_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 256, TN = 256, TK = 32;
+constexpr int NT2 = 512;
+constexpr int APITCH = 32;   // halfs per LDS row: 64-byte rows = four 16-byte slots
+// XOR swizzle of the 16-byte slot inside a row so that the ds_read_b128 lane groups of a 16-row
+// fragment read hit 16 distinct slot positions of the 256-byte bank row (checked for all four groups)
+__device__ __forceinline__ int sw_slot(int row, int slot) {
+    const int h = (0x78 >> (((row >> 2) & 3) * 2)) & 3;      // h = {0,2,3,1}[(row>>2)&3] ... packed 2 bits each
+    return slot ^ h;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t total, int32_t *__restrict__ f) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < total) f[i] = nm[i] >= 0 ? 1 : 0;
+}
+__global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *__restrict__ sc, int64_t nv, int kv,
+                                 int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_pos,
+                                 int32_t *__restrict__ off /*[kv+1]*/) {
+    int64_t total = (int64_t)kv * nv;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int in = nm[i];
+    int s = sc[i];
+    pair_pos[i] = in >= 0 ? s : -1;
+    if (in >= 0) pair_in[s] = in;
+    if (i % nv == 0) off[i / nv] = s;
+    if (i == total - 1) off[kv] = s + (in >= 0 ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct V2Smem {
+    _Float16 a_hi[2][TM][APITCH];
+    _Float16 a_lo[2][TM][APITCH];
+    _Float16 b_hi[2][TN][APITCH];
+    _Float16 b_lo[2][TN][APITCH];
+};
+
+__device__ __forceinline__ void split8(const float4 &u, const float4 &v, f16x8 &hi, f16x8 &lo) {
+    float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 h = (_Float16)x[i];
+        hi[i] = h;
+        lo[i] = (_Float16)(x[i] - (float)h);
+    }
+}
+
+// grid.x = (#m-tiles upper bound) * n_tiles ; tile -> offset k by a search in tile_off (device)
+__global__ void __launch_bounds__(NT2)
+conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
+                   const int32_t *__restrict__ off, int kv, const _Float16 *__restrict__ w_hi,
+                   const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, int n_tiles) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- which (offset, m-tile, n-tile)?
+    int nt = blockIdx.x % n_tiles;
+    int mt = blockIdx.x / n_tiles;
+    int k = 0, base = 0, cnt = 0;
+    {
+        int acc_t = 0;
+        bool found = false;
+        for (int kk = 0; kk < kv; ++kk) {
+            int c = off[kk + 1] - off[kk];
+            int t = (c + TM - 1) / TM;
+            if (!found && mt < acc_t + t) { k = kk; base = off[kk] + (mt - acc_t) * TM; cnt = min(TM, off[kk + 1] - base); found = true; }
+            acc_t += t;
+        }
+        if (!found) return;
+    }
+    const int n0 = nt * TN;
+    // staging roles: A row = tid/2 (pair), half = tid%2 (16 channels); B col = tid/2, half = tid%2
+    const int s_row = tid >> 1, s_half = tid & 1;
+    const bool a_ok = s_row < cnt;
+    const int in_row = a_ok ? pair_in[base + s_row] : 0;
+    const float *xa = x + (int64_t)in_row * ld_x + s_half * 16;
+    const _Float16 *wbh = w_hi + ((int64_t)k * cout + n0 + s_row) * cin + s_half * 16;
+    const _Float16 *wbl = w_lo + ((int64_t)k * cout + n0 + s_row) * cin + s_half * 16;
+
+    float4 ra[4];
+    f16x8 rbh[2], rbl[2];
+    auto load_step = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = a_ok ? *reinterpret_cast<const float4 *>(xa + c0 + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rbh[i] = *reinterpret_cast<const f16x8 *>(wbh + c0 + i * 8);
+            rbl[i] = *reinterpret_cast<const f16x8 *>(wbl + c0 + i * 8);
+        }
+    };
+    auto store_step = [&](int buf) {
+        f16x8 h0, l0, h1, l1;
+        split8(ra[0], ra[1], h0, l0);
+        split8(ra[2], ra[3], h1, l1);
+        const int q0 = sw_slot(s_row, s_half * 2) * 8, q1 = sw_slot(s_row, s_half * 2 + 1) * 8;
+        *reinterpret_cast<f16x8 *>(&sm.a_hi[buf][s_row][q0]) = h0;
+        *reinterpret_cast<f16x8 *>(&sm.a_hi[buf][s_row][q1]) = h1;
+        *reinterpret_cast<f16x8 *>(&sm.a_lo[buf][s_row][q0]) = l0;
+        *reinterpret_cast<f16x8 *>(&sm.a_lo[buf][s_row][q1]) = l1;
+        *reinterpret_cast<f16x8 *>(&sm.b_hi[buf][s_row][q0]) = rbh[0];
+        *reinterpret_cast<f16x8 *>(&sm.b_hi[buf][s_row][q1]) = rbh[1];
+        *reinterpret_cast<f16x8 *>(&sm.b_lo[buf][s_row][q0]) = rbl[0];
+        *reinterpret_cast<f16x8 *>(&sm.b_lo[buf][s_row][q1]) = rbl[1];
+    };
+
+    // wave tile: rows wm*64 .. +64 (4 row tiles), cols wn*128 .. +128 (8 col tiles)
+    const int wm = wv >> 1, wn = wv & 1;
+    const int fl = lane & 15, fq = lane >> 4;
+    const int fsw = sw_slot(fl, fq) * 8;                       // row bits 2..3 come from fl in every 16-row tile
+    // skip row tiles that are entirely padding
+    const int rows_here = cnt - wm * 64;
+    const int nrt = rows_here <= 0 ? 0 : (rows_here >= 64 ? 4 : (rows_here + 15) >> 4);
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int steps = cin / TK;
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) load_step((s + 1) * TK);
+        f16x8 ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8 *>(&sm.a_hi[buf][wm * 64 + i * 16 + fl][fsw]);
+            al[i] = *reinterpret_cast<const f16x8 *>(&sm.a_lo[buf][wm * 64 + i * 16 + fl][fsw]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f16x8 bh = *reinterpret_cast<const f16x8 *>(&sm.b_hi[buf][wn * 128 + j * 16 + fl][fsw]);
+            f16x8 bl = *reinterpret_cast<const f16x8 *>(&sm.b_lo[buf][wn * 128 + j * 16 + fl][fsw]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < nrt) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < steps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- store the partial rows (fp32).  C layout: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nrt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = wm * 64 + i * 16 + fq * 4 + r;
+                if (row < cnt) {
+                    float *dst = P + (int64_t)(base + row) * cout + n0 + wn * 128 + fl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dst[j * 16] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+// phase 2: one wave per output voxel; lanes hold 2 x float4 of the 512 (or cout) channels
+__global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *__restrict__ pair_pos, int64_t nv, int kv,
+                                   int cout, const float *__restrict__ scale, const float *__restrict__ shift,
+                                   const float *__restrict__ residual, int64_t ld_res, int relu,
+                                   float *__restrict__ y, int64_t ld_y) {
+    int64_t u = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (u >= nv) return;
+    int lane = gp_lane();
+    int mypos = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    for (int c = lane * 4; c < cout; c += 256) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < kv; ++k) {
+            int pos = __shfl(mypos, k, 64);
+            if (pos >= 0) {
+                float4 t = *reinterpret_cast<const float4 *>(P + (int64_t)pos * cout + c);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+        }
+        float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
+        if (residual) {
+            float4 r = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
+    }
+}
+
+// weight prepare: w fp32 [kv][cin][cout] -> hi/lo f16 [kv][cout][cin], scaled by `s`
+__global__ void weight_split_kernel(const float *__restrict__ w, int kv, int cin, int cout, float s,
+                                    _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+    int64_t total = (int64_t)kv * cin * cout;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k = i / ((int64_t)cin * cout);
+        int64_t rem = i - k * (int64_t)cin * cout;
+        int n = (int)(rem / cin), c = (int)(rem % cin);               // output index order [k][n][c]
+        float v = w[(k * cin + c) * cout + n] * s;
+        _Float16 h = (_Float16)v;
+        hi[i] = h;
+        lo[i] = (_Float16)(v - (float)h);
+    }
+}
+
+size_t scan_tmp32(int64_t n) {
+    size_t t = 0;
+    (void)rocprim::exclusive_scan(nullptr, t, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), 0);
+    return t;
+}
+
+}  // namespace
+
+extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {
+    if (nv <= 0 || kv <= 0) return 0;
+    GpCarver cv(nullptr, 0);
+    cv.take<int32_t>((size_t)kv * nv);
+    cv.take<int32_t>((size_t)kv * nv);
+    cv.take<char>(scan_tmp32((int64_t)kv * nv));
+    return cv.off;
+}
+
+extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t *pair_in, int32_t *pair_pos,
+                                   int32_t *pair_off, void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(nbr_map && pair_in && pair_pos && pair_off && workspace && nv > 0 && kv > 0, "gp_conv_pairs_build: null/empty argument");
+    GP_CHECK_ARG((int64_t)kv * nv < (1ll << 31), "gp_conv_pairs_build: kernel map too large");
+    int64_t total = (int64_t)kv * nv;
+    GpCarver cv(workspace, workspace_bytes);
+    int32_t *f = cv.take<int32_t>(total), *sc = cv.take<int32_t>(total);
+    size_t tb = scan_tmp32(total);
+    char *tmp = cv.take<char>(tb);
+    if (!cv.ok()) { gp_set_error("gp_conv_pairs_build: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
+    hipStream_t s = gp_stream(stream_);
+    int blocks = (int)((total + 255) / 256);
+    pair_flags_kernel<<<blocks, 256, 0, s>>>(nbr_map, total, f);
+    GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, f, sc, (int32_t)0, (size_t)total, rocprim::plus<int32_t>(), s));
+    pair_emit_kernel<<<blocks, 256, 0, s>>>(nbr_map, sc, nv, kv, pair_in, pair_pos, pair_off);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2,
+                                     void *w_hi, void *w_lo, void *stream_) {
+    GP_CHECK_ARG(w && w_hi && w_lo && kv > 0 && cin > 0 && cout > 0, "gp_conv_weights_split: null/empty argument");
+    weight_split_kernel<<<2048, 256, 0, gp_stream(stream_)>>>(w, kv, cin, cout, scale_pow2, static_cast<_Float16 *>(w_hi),
+                                                              static_cast<_Float16 *>(w_lo));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const int32_t *pair_in, const int32_t *pair_pos,
+                                    const int32_t *pair_off, int64_t num_pairs, int64_t nv, int32_t kv,
+                                    const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
+                                    const float *scale, const float *shift, const float *residual, int64_t ld_res,
+                                    int32_t relu, float *y, int64_t ld_y, void *stream_) {
+    GP_CHECK_ARG(x && pair_in && pair_pos && pair_off && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
+    GP_CHECK_ARG(nv > 0 && num_pairs > 0 && (kv == 27 || kv == 1), "gp_sparse_conv_f16x3: bad sizes");
+    GP_CHECK_ARG(cin % TK == 0, "gp_sparse_conv_f16x3: cin=%d must be a multiple of %d", cin, TK);
+    GP_CHECK_ARG(ld_x % 4 == 0 && (uintptr_t)x % 16 == 0, "gp_sparse_conv_f16x3: x rows must be 16-byte aligned");
+    static bool attr_set = false;
+    if (!attr_set) {
+        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_phase1_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(V2Smem)));
+        attr_set = true;
+    }
+    GP_CHECK_ARG(cout % TN == 0, "gp_sparse_conv_f16x3: cout=%d must be a multiple of %d on this path", cout, TN);
+    hipStream_t s = gp_stream(stream_);
+    int n_tiles = cout / TN;
+    int64_t m_tiles_ub = num_pairs / TM + kv;
+    conv_phase1_kernel<<<(unsigned)(m_tiles_ub * n_tiles), NT2, sizeof(V2Smem), s>>>(
+        x, ld_x, pair_in, pair_off, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout,
+        partial, n_tiles);
+    conv_phase2_kernel<<<(unsigned)((nv * 64 + 255) / 256), 256, 0, s>>>(partial, pair_pos, nv, kv, cout, scale, shift, residual,
+                                                                        ld_res, relu, y, ld_y);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}

@@ -172,6 +172,56 @@ def sparse_conv(x, nbr_map, w, scale=None, shift=None, residual=None, relu=False
     return out
 
 
+class ConvPairs:
+    """Compacted kernel map of one scene (shared by every 3x3x3 layer)."""
+
+    def __init__(self, pair_in, pair_pos, pair_off, num_pairs, nv):
+        self.pair_in, self.pair_pos, self.pair_off, self.num_pairs, self.nv = pair_in, pair_pos, pair_off, num_pairs, nv
+        self.partial = None
+
+
+def conv_pairs_build(nbr_map):
+    """nbr_map i32 [27,nv] -> ConvPairs.  One host sync (number of pairs, to size the partial buffer)."""
+    lib = _lib.load()
+    kv, nv = nbr_map.shape
+    dev = nbr_map.device
+    ws = _ws(lib.gp_conv_pairs_workspace_bytes(nv, kv), dev)
+    pair_in = torch.empty(kv * nv, dtype=torch.int32, device=dev)
+    pair_pos = torch.empty((kv, nv), dtype=torch.int32, device=dev)
+    pair_off = torch.empty(kv + 1, dtype=torch.int32, device=dev)
+    check(lib.gp_conv_pairs_build(_ptr(nbr_map), nv, kv, _ptr(pair_in), _ptr(pair_pos), _ptr(pair_off), _ptr(ws),
+                                  ws.numel(), _stream()), "gp_conv_pairs_build")
+    num_pairs = int(pair_off[kv].item())
+    return ConvPairs(pair_in, pair_pos, pair_off, num_pairs, nv)
+
+
+def conv_weights_split(w, scale_pow2):
+    """w fp32 [kv,cin,cout] -> (w_hi, w_lo) f16 [kv,cout,cin] of scale_pow2*w."""
+    lib = _lib.load()
+    kv, cin, cout = w.shape
+    hi = torch.empty((kv, cout, cin), dtype=torch.float16, device=w.device)
+    lo = torch.empty((kv, cout, cin), dtype=torch.float16, device=w.device)
+    check(lib.gp_conv_weights_split(_ptr(w), kv, cin, cout, float(scale_pow2), _ptr(hi), _ptr(lo), _stream()),
+          "gp_conv_weights_split")
+    return hi, lo
+
+
+def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=None, relu=False, out=None):
+    lib = _lib.load()
+    kv, cout, cin = w_hi.shape
+    nv = pairs.nv
+    if pairs.partial is None or pairs.partial.shape[1] < cout:
+        pairs.partial = torch.empty((pairs.num_pairs, cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((nv, cout), dtype=torch.float32, device=x.device)
+    check(lib.gp_sparse_conv_f16x3(_ptr(x), x.stride(0), _ptr(pairs.pair_in), _ptr(pairs.pair_pos), _ptr(pairs.pair_off),
+                                   pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout, _ptr(pairs.partial),
+                                   _ptr(scale), _ptr(shift), _ptr(residual),
+                                   residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
+                                   out.stride(0), _stream()), "gp_sparse_conv_f16x3")
+    return out
+
+
 def l2norm_rows_(x, d=None):
     lib = _lib.load()
     d = x.shape[1] if d is None else d

@@ -30,47 +30,71 @@ def _pad_to(v, m):
 # --------------------------------------------------------------------------------------------------
 class StudentWeights:
     """Device copy of an AffinityPredictor state_dict (ME layout) with the input
-    kernel zero-padded to a multiple of 32 channels and BatchNorm(eval) folded to scale/shift."""
+    kernel zero-padded to a multiple of 32 channels and BatchNorm(eval) folded to scale/shift.
 
-    def __init__(self, state_dict, device, eps=1e-5):
+    mode "f16x3" (default): 3x3x3 layers run on the f16 matrix cores with fp32-class accuracy
+    (gp_sparse_conv_f16x3: operands split hi+lo, weights pre-scaled by a power of two whose inverse
+    is folded into the BN scale).  mode "f32": every layer on the exact-fp32 MFMA kernel."""
+
+    def __init__(self, state_dict, device, eps=1e-5, mode="f16x3"):
         sd = {k: v.detach() for k, v in state_dict.items()}
+        self.mode = mode
         w0 = sd["input_layer.0.kernel"].float()
         self.cin = w0.shape[1]
         self.cin_pad = _pad_to(self.cin, CONV_PAD)
         self.hidden = w0.shape[2]
         w0p = torch.zeros((27, self.cin_pad, self.hidden), dtype=torch.float32)
         w0p[:, :self.cin] = w0
-        self.w_in = w0p.to(device).contiguous()
-        self.bn_in = self._fold(sd, "input_layer.1", device, eps)
-        self.blocks = []
-        i = 0
-        while f"res_blocks.{i}.conv1.kernel" in sd:
-            self.blocks.append((
-                sd[f"res_blocks.{i}.conv1.kernel"].float().to(device).contiguous(),
-                self._fold(sd, f"res_blocks.{i}.norm1", device, eps),
-                sd[f"res_blocks.{i}.conv2.kernel"].float().to(device).contiguous(),
-                self._fold(sd, f"res_blocks.{i}.norm2", device, eps)))
-            i += 1
+        self.layers = []          # (weights, (scale, shift)) per 3x3x3 conv, in execution order
+        self._add_layer(w0p, self._fold(sd, "input_layer.1", eps), device)
+        self.num_blocks = 0
+        while f"res_blocks.{self.num_blocks}.conv1.kernel" in sd:
+            i = self.num_blocks
+            self._add_layer(sd[f"res_blocks.{i}.conv1.kernel"].float(), self._fold(sd, f"res_blocks.{i}.norm1", eps), device)
+            self._add_layer(sd[f"res_blocks.{i}.conv2.kernel"].float(), self._fold(sd, f"res_blocks.{i}.norm2", eps), device)
+            self.num_blocks += 1
         self.w_out = sd["output_layer.kernel"].float().to(device).contiguous()
         self.embed = self.w_out.shape[1]
 
     @staticmethod
-    def _fold(sd, prefix, device, eps):
+    def _fold(sd, prefix, eps):
         s = sd[prefix + ".bn.weight"].float() / torch.sqrt(sd[prefix + ".bn.running_var"].float() + eps)
         b = sd[prefix + ".bn.bias"].float() - sd[prefix + ".bn.running_mean"].float() * s
-        return s.to(device).contiguous(), b.to(device).contiguous()
+        return s, b
 
-    def forward(self, x, nbr_map):
+    def _add_layer(self, w, bn, device):
+        w = w.to(device).contiguous()
+        scale, shift = bn[0].to(device).contiguous(), bn[1].to(device).contiguous()
+        use_fast = self.mode == "f16x3" and w.shape[2] % 256 == 0
+        if use_fast:
+            amax = float(w.abs().max().item())
+            p2 = 2.0 ** int(np.floor(np.log2(2.0 / amax))) if amax > 0 else 1.0
+            hi, lo = ops.conv_weights_split(w, p2)
+            self.layers.append(("f16x3", (hi, lo), (scale / p2).contiguous(), shift))
+        else:
+            self.layers.append(("f32", w, scale, shift))
+
+    def _conv(self, li, x, ctx, residual=None):
+        kind, w, scale, shift = self.layers[li]
+        if kind == "f16x3":
+            return ops.sparse_conv_f16x3(x, ctx["pairs"], w[0], w[1], scale, shift, residual=residual, relu=True)
+        return ops.sparse_conv(x, ctx["nbr_map"], w, scale, shift, residual=residual, relu=True)
+
+    def forward(self, x, nbr_map, pairs=None):
         """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed]."""
-        h = ops.sparse_conv(x, nbr_map, self.w_in, self.bn_in[0], self.bn_in[1], relu=True)
-        for w1, bn1, w2, bn2 in self.blocks:
-            t = ops.sparse_conv(h, nbr_map, w1, bn1[0], bn1[1], relu=True)
-            h = ops.sparse_conv(t, nbr_map, w2, bn2[0], bn2[1], residual=h, relu=True)
+        ctx = {"nbr_map": nbr_map, "pairs": pairs}
+        if pairs is None and any(l[0] == "f16x3" for l in self.layers):
+            ctx["pairs"] = ops.conv_pairs_build(nbr_map)
+        h = self._conv(0, x, ctx)
+        for b in range(self.num_blocks):
+            t = self._conv(1 + 2 * b, h, ctx)
+            h = self._conv(2 + 2 * b, t, ctx, residual=h)
         e = ops.sparse_conv(h, None, self.w_out)
+        self.last_pairs = ctx["pairs"]
         return ops.l2norm_rows_(e)
 
     def flops(self, num_pairs, nv):
-        per_pair = self.cin * self.hidden + 2 * len(self.blocks) * self.hidden * self.hidden
+        per_pair = self.cin * self.hidden + 2 * self.num_blocks * self.hidden * self.hidden
         return 2.0 * num_pairs * per_pair + 2.0 * nv * self.hidden * self.embed
 
 

@@ -433,3 +433,35 @@ def test_error_paths(ops):
         ops.pool_ell(x, nbr, w, 512, x)                              # aliasing is rejected
     with pytest.raises(GeoPurifyHipError):
         ops.sparse_conv(x, None, torch.zeros((100, 128), device="cuda"))   # cin not a multiple of 32
+
+
+# ------------------------------------------------------------------------------------------ row 9 fast path
+def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
+    """f16-split (hi+lo, 3 MFMAs) convolution: fp32-class accuracy against the fp64 oracle."""
+    rng = np.random.default_rng(11)
+    c = surface_voxels(rng, 2500)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    nm = ops.kernel_map_build(grid, cs)
+    pairs = ops.conv_pairs_build(nm)
+    nmc = nm.cpu().numpy()
+    assert pairs.num_pairs == int((nmc >= 0).sum())
+    pos = pairs.pair_pos.cpu().numpy()
+    assert np.array_equal(pos >= 0, nmc >= 0)
+    assert np.array_equal(pairs.pair_in.cpu().numpy()[pos[pos >= 0]], nmc[nmc >= 0])
+    off = pairs.pair_off.cpu().numpy()
+    assert np.array_equal(np.diff(off), (nmc >= 0).sum(1))
+    Nv = len(c)
+    X = torch.randn(Nv, 96) * 3.0
+    X[:, :8] *= 1e-3                                                   # small-magnitude channels too
+    W = torch.randn(27, 96, 256) * 0.05
+    sc, sh = torch.rand(256) + 0.5, torch.randn(256)
+    res = torch.randn(Nv, 256)
+    p2 = 2.0 ** int(np.floor(np.log2(2.0 / float(W.abs().max()))))
+    hi, lo = ops.conv_weights_split(dev(W), p2)
+    y = ops.sparse_conv_f16x3(dev(X), pairs, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True)
+    ref = o_student.sparse_conv3(X.double(), nmc.astype(np.int64), W.double())
+    ref = torch.relu(ref * sc.double() + sh.double() + res.double())
+    err = (y.cpu().double() - ref).abs().max().item()
+    y32 = ops.sparse_conv(dev(X), nm, dev(W), dev(sc), dev(sh), residual=dev(res), relu=True)
+    err32 = (y32.cpu().double() - ref).abs().max().item()
+    assert err < 5e-5 and err < 4 * err32 + 1e-6, (err, err32)        # same class as the exact-fp32 MFMA kernel
