@@ -18,6 +18,7 @@ _P = c_void_p  # every device pointer travels as void*
 SIGNATURES = {
     "gp_version": (c_int32, []),
     "gp_last_error": (c_char_p, []),
+    "gp_debug_set": (c_int32, [c_int32, c_int32]),
     "gp_voxelize_workspace_bytes": (c_size_t, [c_int64]),
     "gp_voxelize_f64": (c_int32, [_P, c_int64, POINTER(c_double), _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gp_fnv_hash_f64": (c_int32, [_P, c_int64, _P, _P]),
@@ -42,6 +43,10 @@ SIGNATURES = {
     "gp_knn_lattice": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "gp_affinity_softmax": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int64, c_float, _P, _P]),
     "gp_pool_ell": (c_int32, [_P, c_int64, _P, _P, c_int32, c_int64, c_int32, _P, c_int64, _P]),
+    "gp_pool_tiles_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "gp_pool_tiles_count": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "gp_pool_tiles_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
+    "gp_pool_tiles_apply": (c_int32, [_P, c_int64, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_lift_dense_finish": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "gp_lift_masks_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -258,6 +258,39 @@ def pool_ell(x, nbr, w, d, out):
     return out
 
 
+class PoolTiles:
+    """Affinity operator re-blocked into tiles of r rows (built once per scene, applied many times)."""
+
+    def __init__(self, tile_off, u_row, u_w, r, nv, total):
+        self.tile_off, self.u_row, self.u_w, self.r, self.nv, self.total = tile_off, u_row, u_w, r, nv, total
+
+
+def pool_tiles_build(nbr, w, r=16):
+    """One host sync (total union entries, to size the tile arrays)."""
+    lib = _lib.load()
+    nv, k = nbr.shape
+    dev = nbr.device
+    nt = (nv + r - 1) // r
+    ws = _ws(lib.gp_pool_tiles_workspace_bytes(nv, r), dev)
+    off = torch.empty(nt + 1, dtype=torch.int64, device=dev)
+    check(lib.gp_pool_tiles_count(_ptr(nbr), nv, int(k), int(r), _ptr(off), _ptr(ws), ws.numel(), _stream()),
+          "gp_pool_tiles_count")
+    total = int(off[nt].item())
+    u_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    u_w = torch.empty((max(total, 1), r), dtype=torch.float32, device=dev)
+    check(lib.gp_pool_tiles_fill(_ptr(nbr), _ptr(w), nv, int(k), int(r), _ptr(off), _ptr(u_row), _ptr(u_w), _stream()),
+          "gp_pool_tiles_fill")
+    return PoolTiles(off, u_row, u_w, r, nv, total)
+
+
+def pool_tiles_apply(x, tiles, d, out):
+    lib = _lib.load()
+    check(lib.gp_pool_tiles_apply(_ptr(x), x.stride(0), _ptr(tiles.tile_off), _ptr(tiles.u_row), _ptr(tiles.u_w),
+                                  int(tiles.r), tiles.nv, int(d), _ptr(out), out.stride(0), _stream()),
+          "gp_pool_tiles_apply")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ rows 5-7
 def lift_dense_accum(feat2d, pt, x, y, sum_, cnt):
     lib = _lib.load()

@@ -228,8 +228,10 @@ class HotPath:
     """evaluate_scene on the device.  K, sharpen and num_iters are the reference's hard-coded
     constants (affinity_module.py:1492-1493,1584-1587) exposed as options."""
 
-    def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda"):
+    def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda",
+                 pool_mode="tiles", pool_tile_rows=8):
         self.student = student
+        self.pool_mode, self.pool_tile_rows = pool_mode, pool_tile_rows
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
         self.device = torch.device(device)
@@ -336,8 +338,14 @@ class HotPath:
         w = ops.affinity_softmax(E, nbr, self.sharpen)
         bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
         cur = X
+        R = self.pool_tile_rows
+        use_tiles = self.pool_mode == "tiles" and self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
+        tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
         for t in range(self.num_iters):
-            ops.pool_ell(cur, nbr, w, D, bufs[t % 2])
+            if use_tiles:
+                ops.pool_tiles_apply(cur, tiles, D, bufs[t % 2])
+            else:
+                ops.pool_ell(cur, nbr, w, D, bufs[t % 2])
             cur = bufs[t % 2]
         out = ops.gather_rows(cur, D, batch.scene_inds_reconstruct, row_map=rank)
         self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8)}

@@ -1,0 +1,96 @@
+"""Scene sharding across GPUs (one process per GPU) and the single metric all-reduce.
+
+The reference shards evaluation by hand: `--split_idx/--split_total` pick a contiguous slice of the
+scene list (run/validation.py:269-286) and run/val.sh runs the slices one after the other, never
+merging their metrics; its per-scene dist.all_reduce calls are dead code (run/validation.py:441-450).
+Here: scenes are independent, so each rank evaluates its own slice with no data-path collective and
+ONE int64 all-reduce of the [3,C] (intersection, output, target) counts follows the local loop
+(RCCL over xGMI on the GPU box, gloo in the CPU tests).  int64 keeps the counts exact (the reference
+accumulates them in fp32).
+"""
+import numpy as np
+import torch
+
+
+def get_batch_scenes(scene_ids, batch_idx, total_batches=4):
+    """Contiguous split rule of run/validation.py:269-280: the first (n mod t) slices get one extra scene."""
+    n = len(scene_ids)
+    size, rem = divmod(n, total_batches)
+    start = batch_idx * size + min(batch_idx, rem)
+    return scene_ids[start:start + size + (1 if batch_idx < rem else 0)]
+
+
+def assign_scenes_lpt(costs, world_size):
+    """Greedy longest-processing-time assignment (scene sizes span 28k..302k points):
+    scenes sorted by cost descending, each to the currently lightest rank.  Deterministic.
+    Returns a list of index lists, one per rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += costs[i]
+    return out
+
+
+def reduce_counts(counts, group=None):
+    """The one collective: SUM all-reduce of the int64 [3,C] counts (no-op without a process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
+def evaluate_sharded(num_scenes, scene_counts_fn, num_classes, device, rank=0, world_size=1, costs=None,
+                     policy="contiguous"):
+    """Run scene_counts_fn(scene_index, counts) for this rank's scenes, then all-reduce.
+    scene_counts_fn adds the scene's (I, O, T) histograms into `counts` (int64 [3,C] on `device`)."""
+    ids = list(range(num_scenes))
+    if policy == "lpt" and costs is not None:
+        mine = assign_scenes_lpt(costs, world_size)[rank]
+    else:
+        mine = get_batch_scenes(ids, rank, world_size)
+    counts = torch.zeros((3, num_classes), dtype=torch.int64, device=device)
+    for i in mine:
+        scene_counts_fn(i, counts)
+    return reduce_counts(counts), mine
+
+
+def summarize(counts, category_split=None):
+    """mIoU / mAcc / allAcc for Base / Novel / All exactly as run/validation.py:490-523
+    (I/(U+1e-10) averaged over the index lists of category_split)."""
+    c = counts.detach().cpu().numpy().astype(np.float64)
+    inter, out, tgt = c[0], c[1], c[2]
+    union = out + tgt - inter
+
+    def block(idx):
+        i, u, t = inter[idx], union[idx], tgt[idx]
+        iou, acc = i / (u + 1e-10), i / (t + 1e-10)
+        return {"mIoU": float(np.mean(iou)), "mAcc": float(np.mean(acc)), "allAcc": float(i.sum() / (t.sum() + 1e-10)),
+                "iou_class": iou, "intersection": i, "union": u, "target": t}
+
+    res = {"All": block(np.arange(len(inter)))}
+    if category_split is not None:
+        res["Base"] = block(np.asarray(category_split["base_category"], dtype=np.int64))
+        res["Novel"] = block(np.asarray(category_split["novel_category"], dtype=np.int64))
+    return res
+
+
+def log_lines(summary):
+    """The reference's log strings (run/validation.py:524-553), one list entry per logger.info call."""
+    lines = []
+    for name in ("Base", "Novel", "All"):
+        if name in summary:
+            s = summary[name]
+            lines.append("Raw stats {}: intersection {}, union {}, target {}".format(name, s["intersection"], s["union"],
+                                                                                    s["target"]))
+    for name in ("Base", "Novel", "All"):
+        if name in summary:
+            s = summary[name]
+            lines.append("Val 2d result: mIoU_{0}/mAcc_{0}/allAcc_{0} {1:.4f}/{2:.4f}/{3:.4f}.".format(
+                name, s["mIoU"], s["mAcc"], s["allAcc"]))
+    for name in ("Base", "Novel", "All"):
+        if name in summary:
+            lines.append("iou_class_{} '{}'".format(name, summary[name]["iou_class"]))
+    return lines

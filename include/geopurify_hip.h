@@ -34,6 +34,7 @@ extern "C" {
 #define GP_KNN_MAX_K 127  /* K+1 <= 128 */
 
 int gp_version(void);
+int gp_debug_set(int32_t key, int32_t value);   /* kernel tuning knobs for experiments (pool_tiles.hip) */
 const char *gp_last_error(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -146,6 +147,19 @@ int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, const int32_t *
 /* d % 4 == 0, ld_x/ld_y % 4 == 0.  X and Y must not alias.                                       */
 int gp_pool_ell(const float *x, int64_t ld_x, const int32_t *nbr, const float *w, int32_t k,
                 int64_t nv, int32_t d, float *y, int64_t ld_y, void *stream);
+
+/* Fast path of the same operator, re-blocked once per scene for the 19 applications: tiles of r     */
+/* Morton-adjacent rows (r in {4,8,16}); per tile the union of its rows' neighbours and a dense        */
+/* [union, r] weight block.  count: tile_off i64 [ntiles+1] (exclusive scan; last = total entries,     */
+/* read it back to size u_row i32 [total] and u_w f32 [total, r]); fill; apply = one application.       */
+size_t gp_pool_tiles_workspace_bytes(int64_t nv, int32_t r);
+int gp_pool_tiles_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t r, int64_t *tile_off,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int gp_pool_tiles_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t r,
+                       const int64_t *tile_off, int32_t *u_row, float *u_w, void *stream);
+int gp_pool_tiles_apply(const float *x, int64_t ld_x, const int64_t *tile_off, const int32_t *u_row,
+                        const float *u_w, int32_t r, int64_t nv, int32_t d, float *y, int64_t ld_y,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Interleaved timing of the pooling kernel variants on one S-shaped voxel set (tuning aid)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from geopurify_amd import _lib, ops, pipeline as pl, synthetic as syn  # noqa: E402
+
+cfg = syn.CONFIGS["S"]
+import dataclasses
+cfg = dataclasses.replace(cfg, num_views=1)
+sc = syn.make_scene(cfg, 5557)
+rigid = pl.scene_rigid_transform(cfg.voxel_size, 5557)
+vox = ops.voxelize(torch.from_numpy(sc.coords).cuda(), rigid)
+coords = vox["coords_aug"].to(torch.int32).contiguous()
+perm, rank = ops.morton_order(coords)
+cs = coords[perm.long()].contiguous()
+grid = ops.grid_build(cs)
+K, D = 96, 512
+nbr = ops.knn_lattice(grid, cs, perm, K)
+Nv = cs.shape[0]
+E = torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1)
+w = ops.affinity_softmax(E, nbr, 20.0)
+X = torch.randn(Nv, 544, device="cuda")
+Y = torch.empty(Nv, D, device="cuda")
+lib = _lib.load()
+bytes_alg = Nv * (2 * D * 4 + K * 8)
+
+
+def timeit(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+variants = [("ell", None)]
+tiles = {}
+for R in (4, 8, 16):
+    tiles[R] = ops.pool_tiles_build(nbr, w, R)
+    print(f"R={R}: union entries/row = {tiles[R].total / Nv:.2f}", flush=True)
+    for nf4 in (1, 2):
+        for un in (4, 8):
+            if (R, nf4, un) in ((16, 2, 8), (4, 1, 4), (4, 1, 8)):
+                continue
+            variants.append((f"tiles R={R} nf4={nf4} unroll={un}", (R, nf4, un)))
+res = {}
+for rnd in range(3):
+    for name, v in variants:
+        if v is None:
+            t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
+        else:
+            R, nf4, un = v
+            lib.gp_debug_set(1, nf4); lib.gp_debug_set(2, un)
+            t = timeit(lambda: ops.pool_tiles_apply(X, tiles[R], D, Y))
+        res.setdefault(name, []).append(t)
+for name, ts in res.items():
+    t = min(ts)
+    print(f"{name:32s} min {t:7.3f} ms  med {np.median(ts):7.3f} ms  -> {bytes_alg / t / 1e6:7.1f} GB/s algorithmic ({bytes_alg / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)

@@ -465,3 +465,41 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     y32 = ops.sparse_conv(dev(X), nm, dev(W), dev(sc), dev(sh), residual=dev(res), relu=True)
     err32 = (y32.cpu().double() - ref).abs().max().item()
     assert err < 5e-5 and err < 4 * err32 + 1e-6, (err, err32)        # same class as the exact-fp32 MFMA kernel
+
+
+# ------------------------------------------------------------------------------------------ row 12 fast path
+@pytest.mark.parametrize("R", [4, 8, 16])
+def test_pool_tiles_matches_ell_and_oracle(ops, R):
+    rng = np.random.default_rng(12)
+    c = surface_voxels(rng, 2500)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, K, D = len(c), 96, 512
+    nbr = ops.knn_lattice(grid, cs, perm, K)                            # internal (Morton) rows
+    E = F.normalize(torch.randn(Nv, 128), dim=1)
+    w = ops.affinity_softmax(dev(E), nbr, 20.0)
+    tiles = ops.pool_tiles_build(nbr, w, R)
+    # structure: every (row, neighbour, weight) appears exactly once in its tile's dense block
+    off, urow, uw = tiles.tile_off.cpu().numpy(), tiles.u_row.cpu().numpy(), tiles.u_w.cpu().numpy()
+    nbc, wc = nbr.cpu().numpy(), w.cpu().numpy()
+    for t in (0, len(off) // 2, len(off) - 2):
+        rows = range(t * R, min((t + 1) * R, Nv))
+        u = urow[off[t]:off[t + 1]]
+        assert len(np.unique(u)) == len(u) and set(u) == set(nbc[list(rows)].reshape(-1))
+        dense = np.zeros((Nv if False else len(u), R), np.float32)
+        pos = {v: i for i, v in enumerate(u)}
+        for r_i, row in enumerate(rows):
+            for j in range(K):
+                dense[pos[nbc[row, j]], r_i] = wc[row, j]
+        assert np.array_equal(uw[off[t]:off[t + 1]], dense)
+    X = torch.randn(Nv, D + 32)
+    Xd = dev(X)
+    a = [torch.empty((Nv, D), device="cuda") for _ in range(2)]
+    b = [torch.empty((Nv, D), device="cuda") for _ in range(2)]
+    ca, cb = Xd, Xd
+    T = 5
+    for t in range(T):
+        ops.pool_tiles_apply(ca, tiles, D, a[t % 2]); ca = a[t % 2]
+        ops.pool_ell(cb, nbr, w, D, b[t % 2]); cb = b[t % 2]
+    assert (ca - cb).abs().max() < 1e-5                                # same operator, different fp32 order
+    ref = o_aff.pool_gather(X[:, :D], nbr.cpu().long(), w.cpu(), T)
+    assert (ca.cpu().double() - ref).abs().max() < 1e-5
