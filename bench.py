@@ -62,22 +62,25 @@ class PoolTimer:
     def __init__(self):
         self.events = []
         self.enabled = False
+        self.kernel = "pool_ell"
 
     def wrap(self, ops):
-        orig = ops.pool_ell
         timer = self
+        for name in ("pool_ell", "pool_tiles_apply"):
+            orig = getattr(ops, name)
 
-        def timed(*a, **k):
-            if not timer.enabled:
-                return orig(*a, **k)
-            s = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            r = orig(*a, **k)
-            e1.record(s)
-            timer.events.append((e0, e1))
-            return r
-        ops.pool_ell = timed
+            def timed(*a, _orig=orig, _name=name, **k):
+                if not timer.enabled:
+                    return _orig(*a, **k)
+                s = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                r = _orig(*a, **k)
+                e1.record(s)
+                timer.events.append((e0, e1))
+                timer.kernel = _name
+                return r
+            setattr(ops, name, timed)
 
     def mean_ms(self):
         return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else float("nan")
@@ -248,7 +251,8 @@ def main():
                                    f"{len(last.views)}/{cfg.num_views} views kept, D={D}, K=96, "
                                    f"pool_iters={args.pool_iters}, student 518->512x9->128 random-init",
                        "sharding": f"1 scene per GPU x {world}, one int64 all-reduce of IoU counts"},
-            "roofline": {"kernel": "pool_ell_kernel (affinity pooling, one application of A)", "bound": "hbm",
+            "roofline": {"kernel": ("pool_tiles_kernel" if pool_timer.kernel == "pool_tiles_apply" else "pool_ell_kernel")
+                         + " (affinity pooling, one application of A)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4)},

@@ -222,14 +222,9 @@ size_t scan64_tmp(int64_t n) {
 
 }  // namespace
 
-static int g_pool_nf4 = 0, g_pool_unroll = 4;
-// tuning knobs for experiments (key 1: float4 per lane 0=auto/1/2; key 2: unroll 4/8)
-extern "C" int gp_debug_set(int32_t key, int32_t value) {
-    if (key == 1) g_pool_nf4 = value;
-    else if (key == 2) g_pool_unroll = value;
-    else return GP_EINVAL;
-    return GP_OK;
-}
+extern int g_gp_knobs[8];
+#define g_pool_nf4 g_gp_knobs[1]
+#define g_pool_unroll g_gp_knobs[2]
 
 extern "C" size_t gp_pool_tiles_workspace_bytes(int64_t nv, int32_t r) {
     if (nv <= 0 || r <= 0) return 0;

@@ -79,7 +79,7 @@ __device__ __forceinline__ void split8(const float4 &u, const float4 &v, f16x8 &
 __global__ void __launch_bounds__(NT2)
 conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
                    const int32_t *__restrict__ off, int kv, const _Float16 *__restrict__ w_hi,
-                   const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, int n_tiles) {
+                   const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, int n_tiles, int ablate) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -154,7 +154,7 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < steps) load_step((s + 1) * TK);
+        if (s + 1 < steps && !(ablate & 1)) load_step((s + 1) * TK);
         f16x8 ah[4], al[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -167,16 +167,17 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
             f16x8 bl = *reinterpret_cast<const f16x8 *>(&sm.b_lo[buf][wn * 128 + j * 16 + fl][fsw]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i < nrt) {
+                if (i < nrt && !(ablate & 2)) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
                 }
             }
         }
-        if (s + 1 < steps) store_step(buf ^ 1);
+        if (s + 1 < steps && !(ablate & 4)) store_step(buf ^ 1);
         __syncthreads();
     }
+    if (ablate & 8) return;
     // ---- store the partial rows (fp32).  C layout: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -247,6 +248,9 @@ size_t scan_tmp32(int64_t n) {
 
 }  // namespace
 
+extern int g_gp_knobs[8];
+#define g_conv_ablate g_gp_knobs[3]
+
 extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {
     if (nv <= 0 || kv <= 0) return 0;
     GpCarver cv(nullptr, 0);
@@ -305,7 +309,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const int32_t 
     int64_t m_tiles_ub = num_pairs / TM + kv;
     conv_phase1_kernel<<<(unsigned)(m_tiles_ub * n_tiles), NT2, sizeof(V2Smem), s>>>(
         x, ld_x, pair_in, pair_off, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout,
-        partial, n_tiles);
+        partial, n_tiles, g_conv_ablate);
     conv_phase2_kernel<<<(unsigned)((nv * 64 + 255) / 256), 256, 0, s>>>(partial, pair_pos, nv, kv, cout, scale, shift, residual,
                                                                         ld_res, relu, y, ld_y);
     GP_CHECK_LAUNCH();
