@@ -39,22 +39,49 @@ __device__ __forceinline__ int sw_slot(int row, int slot) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t total, int32_t *__restrict__ f) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < total) f[i] = nm[i] >= 0 ? 1 : 0;
+// Pairs are ordered by (chunk of CH Morton-consecutive output rows, offset k, output row): a chunk's
+// 27 offset segments gather from the same few thousand input rows, so the A operand stays in the
+// XCD's L2 while the chunk is processed (k-major order re-read every input row ~7x from beyond L2).
+__device__ __forceinline__ void pair_decode(int64_t i, int64_t nv, int kv, int ch, int &c, int &k, int64_t &u) {
+    int64_t per = (int64_t)kv * ch;
+    c = (int)(i / per);
+    int64_t rem = i - (int64_t)c * per;
+    int64_t rows_c = nv - (int64_t)c * ch < ch ? nv - (int64_t)c * ch : ch;
+    k = (int)(rem / rows_c);
+    u = (int64_t)c * ch + (rem - (int64_t)k * rows_c);
 }
-__global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *__restrict__ sc, int64_t nv, int kv,
-                                 int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_pos,
-                                 int32_t *__restrict__ off /*[kv+1]*/) {
+__global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t nv, int kv, int ch, int32_t *__restrict__ f) {
     int64_t total = (int64_t)kv * nv;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= total) return;
-    int in = nm[i];
+    int c, k; int64_t u;
+    pair_decode(i, nv, kv, ch, c, k, u);
+    f[i] = nm[(int64_t)k * nv + u] >= 0 ? 1 : 0;
+}
+__global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *__restrict__ sc, int64_t nv, int kv, int ch,
+                                 int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_pos,
+                                 int32_t *__restrict__ seg_off /*[nseg+1]*/) {
+    int64_t total = (int64_t)kv * nv;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int c, k; int64_t u;
+    pair_decode(i, nv, kv, ch, c, k, u);
+    int in = nm[(int64_t)k * nv + u];
     int s = sc[i];
-    pair_pos[i] = in >= 0 ? s : -1;
+    pair_pos[(int64_t)k * nv + u] = in >= 0 ? s : -1;
     if (in >= 0) pair_in[s] = in;
-    if (i % nv == 0) off[i / nv] = s;
-    if (i == total - 1) off[kv] = s + (in >= 0 ? 1 : 0);
+    if (u == (int64_t)c * ch) seg_off[c * kv + k] = s;           // first row of the (chunk, offset) segment
+    if (i == total - 1) seg_off[(c + 1) * kv] = s + (in >= 0 ? 1 : 0);
+}
+// tile_start[s] = number of TM-row tiles before segment s (serial scan over a few thousand segments)
+__global__ void tile_start_kernel(const int32_t *__restrict__ seg_off, int nseg, int32_t *__restrict__ tile_start) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int acc = 0;
+    for (int s = 0; s < nseg; ++s) {
+        tile_start[s] = acc;
+        acc += (seg_off[s + 1] - seg_off[s] + TM - 1) / TM;
+    }
+    tile_start[nseg] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -75,29 +102,56 @@ __device__ __forceinline__ void split8(const float4 &u, const float4 &v, f16x8 &
     }
 }
 
+
+// one Cin step of a wave's 64x128 tile with a compile-time number of live 16-row tiles (the last
+// m-tile of an offset is partial): no per-MFMA control flow, term-major order so that consecutive
+// MFMAs hit different accumulators.
+template <int NRT>
+__device__ __forceinline__ void mma_step_f16x3(const V2Smem &sm, int buf, int wm, int wn, int fl, int fsw,
+                                               f32x4 (&acc)[4][8]) {
+    f16x8 ah[NRT > 0 ? NRT : 1], al[NRT > 0 ? NRT : 1];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8 *>(&sm.a_hi[buf][wm * 64 + i * 16 + fl][fsw]);
+        al[i] = *reinterpret_cast<const f16x8 *>(&sm.a_lo[buf][wm * 64 + i * 16 + fl][fsw]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f16x8 bh = *reinterpret_cast<const f16x8 *>(&sm.b_hi[buf][wn * 128 + j * 16 + fl][fsw]);
+        f16x8 bl = *reinterpret_cast<const f16x8 *>(&sm.b_lo[buf][wn * 128 + j * 16 + fl][fsw]);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+    }
+}
 // grid.x = (#m-tiles upper bound) * n_tiles ; tile -> offset k by a search in tile_off (device)
 __global__ void __launch_bounds__(NT2)
 conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
-                   const int32_t *__restrict__ off, int kv, const _Float16 *__restrict__ w_hi,
-                   const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, int n_tiles, int ablate) {
+                   const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, int nseg, int kv,
+                   const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
+                   float *__restrict__ P, int n_tiles, int ablate) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ---- which (offset, m-tile, n-tile)?
-    int nt = blockIdx.x % n_tiles;
-    int mt = blockIdx.x / n_tiles;
-    int k = 0, base = 0, cnt = 0;
-    {
-        int acc_t = 0;
-        bool found = false;
-        for (int kk = 0; kk < kv; ++kk) {
-            int c = off[kk + 1] - off[kk];
-            int t = (c + TM - 1) / TM;
-            if (!found && mt < acc_t + t) { k = kk; base = off[kk] + (mt - acc_t) * TM; cnt = min(TM, off[kk + 1] - base); found = true; }
-            acc_t += t;
-        }
-        if (!found) return;
+    // XCD-contiguous tile order: blocks b, b+8, ... share an XCD; each XCD walks a contiguous range of
+    // (m-tile, n-tile) pairs, both channel tiles of an m-tile back to back (shared A rows hit its L2)
+    const int64_t nb = gridDim.x, per_xcd = nb >> 3;
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int nt = (int)(lb % n_tiles);
+    const int mt = (int)(lb / n_tiles);
+    if (mt >= tile_start[nseg]) return;
+    int lo_s = 0, hi_s = nseg;                                  // segment with tile_start[s] <= mt < tile_start[s+1]
+    while (hi_s - lo_s > 1) {
+        int mid = (lo_s + hi_s) >> 1;
+        if (tile_start[mid] <= mt) lo_s = mid; else hi_s = mid;
     }
+    const int k = lo_s % kv;
+    const int base = off[lo_s] + (mt - tile_start[lo_s]) * TM;
+    const int cnt = min(TM, off[lo_s + 1] - base);
     const int n0 = nt * TN;
     // staging roles: A row = tid/2 (pair), half = tid%2 (16 channels); B col = tid/2, half = tid%2
     const int s_row = tid >> 1, s_half = tid & 1;
@@ -140,7 +194,7 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     const int fsw = sw_slot(fl, fq) * 8;                       // row bits 2..3 come from fl in every 16-row tile
     // skip row tiles that are entirely padding
     const int rows_here = cnt - wm * 64;
-    const int nrt = rows_here <= 0 ? 0 : (rows_here >= 64 ? 4 : (rows_here + 15) >> 4);
+    const int nrt = __builtin_amdgcn_readfirstlane(rows_here <= 0 ? 0 : (rows_here >= 64 ? 4 : (rows_here + 15) >> 4));
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -155,25 +209,7 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < steps && !(ablate & 1)) load_step((s + 1) * TK);
-        f16x8 ah[4], al[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *reinterpret_cast<const f16x8 *>(&sm.a_hi[buf][wm * 64 + i * 16 + fl][fsw]);
-            al[i] = *reinterpret_cast<const f16x8 *>(&sm.a_lo[buf][wm * 64 + i * 16 + fl][fsw]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            f16x8 bh = *reinterpret_cast<const f16x8 *>(&sm.b_hi[buf][wn * 128 + j * 16 + fl][fsw]);
-            f16x8 bl = *reinterpret_cast<const f16x8 *>(&sm.b_lo[buf][wn * 128 + j * 16 + fl][fsw]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < nrt && !(ablate & 2)) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
-                }
-            }
-        }
+        if (!(ablate & 2)) mma_step_f16x3<4>(sm, buf, wm, wn, fl, fsw, acc);   // padded rows are computed and discarded
         if (s + 1 < steps && !(ablate & 4)) store_step(buf ^ 1);
         __syncthreads();
     }
@@ -195,11 +231,123 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// phase 1, LDS-DMA variant: activations arrive pre-split (hi/lo f16 rows written by the previous
+// layer's epilogue), so both operands are staged global -> LDS by global_load_lds_dwordx4 with no
+// VGPR round trip, no conversion and no ds_write in the loop.  The LDS image is lane-linear per
+// instruction (16 rows x 64 B); the XOR swizzle is applied on the SOURCE address (slot q = p ^ h(row))
+// and again on the fragment reads.  Epilogue goes through LDS so that rows are stored in 512-byte runs.
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(NT2)
+conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
+                       const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
+                       const int32_t *__restrict__ tile_start, int nseg, int kv,
+                       const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
+                       float *__restrict__ P, int n_tiles, int ablate) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XCD-contiguous tile order: blocks b, b+8, ... share an XCD; each XCD walks a contiguous range of
+    // (m-tile, n-tile) pairs, both channel tiles of an m-tile back to back (shared A rows hit its L2)
+    const int64_t nb = gridDim.x, per_xcd = nb >> 3;
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int nt = (int)(lb % n_tiles);
+    const int mt = (int)(lb / n_tiles);
+    if (mt >= tile_start[nseg]) return;
+    int lo_s = 0, hi_s = nseg;                                  // segment with tile_start[s] <= mt < tile_start[s+1]
+    while (hi_s - lo_s > 1) {
+        int mid = (lo_s + hi_s) >> 1;
+        if (tile_start[mid] <= mt) lo_s = mid; else hi_s = mid;
+    }
+    const int k = lo_s % kv;
+    const int base = off[lo_s] + (mt - tile_start[lo_s]) * TM;
+    const int cnt = min(TM, off[lo_s + 1] - base);
+    const int n0 = nt * TN;
+    // DMA roles: wave wv stages rows [wv*32, wv*32+32) of each array, two instructions of 16 rows
+    const int lrow = lane >> 2, lp = lane & 3;
+    const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;         // logical 8-half slot this lane fetches
+    const _Float16 *ga_hi[2], *ga_lo[2], *gb_hi[2], *gb_lo[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int row = wv * 32 + t * 16 + lrow;
+        int in_row = row < cnt ? pair_in[base + row] : 0;
+        ga_hi[t] = x_hi + (int64_t)in_row * ld_xh + q;
+        ga_lo[t] = x_lo + (int64_t)in_row * ld_xh + q;
+        int64_t wrow = ((int64_t)k * cout + n0 + row) * cin + q;
+        gb_hi[t] = w_hi + wrow;
+        gb_lo[t] = w_lo + wrow;
+    }
+    auto issue = [&](int c0, int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r0 = wv * 32 + t * 16;
+            glds16(ga_hi[t] + c0, &sm.a_hi[buf][r0][0]);
+            glds16(ga_lo[t] + c0, &sm.a_lo[buf][r0][0]);
+            glds16(gb_hi[t] + c0, &sm.b_hi[buf][r0][0]);
+            glds16(gb_lo[t] + c0, &sm.b_lo[buf][r0][0]);
+        }
+    };
+
+    const int wm = wv >> 1, wn = wv & 1;
+    const int fl = lane & 15, fq = lane >> 4;
+    const int fsw = sw_slot(fl, fq) * 8;
+    const int rows_here = cnt - wm * 64;
+    const int nrt = __builtin_amdgcn_readfirstlane(rows_here <= 0 ? 0 : (rows_here >= 64 ? 4 : (rows_here + 15) >> 4));
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int steps = cin / TK;
+    issue(0, 0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
+        if (!(ablate & 2)) mma_step_f16x3<4>(sm, buf, wm, wn, fl, fsw, acc);   // padded rows are computed and discarded
+        __syncthreads();
+    }
+    if (ablate & 8) return;
+    // ---- epilogue through LDS: each wave transposes 16-row slices of its 64x128 tile and stores
+    //      whole 512-byte row segments (16 B per lane)
+    constexpr int EP = 132;                                  // floats per staged row (16-byte aligned, bank-skewed)
+    float *st = reinterpret_cast<float *>(smem_raw) + wv * (16 * EP);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nrt) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * EP + j * 16 + fl] = acc[i][j][r];
+            gp_wave_sync();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                int idx = t * 64 + lane;
+                int row = idx >> 5, c4 = idx & 31;
+                int grow = wm * 64 + i * 16 + row;
+                if (grow < cnt) {
+                    float4 v = *reinterpret_cast<const float4 *>(st + row * EP + c4 * 4);
+                    *reinterpret_cast<float4 *>(P + (int64_t)(base + grow) * cout + n0 + wn * 128 + c4 * 4) = v;
+                }
+            }
+            gp_wave_sync();
+        }
+    }
+}
+
 // phase 2: one wave per output voxel; lanes hold 2 x float4 of the 512 (or cout) channels
 __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *__restrict__ pair_pos, int64_t nv, int kv,
                                    int cout, const float *__restrict__ scale, const float *__restrict__ shift,
                                    const float *__restrict__ residual, int64_t ld_res, int relu,
-                                   float *__restrict__ y, int64_t ld_y) {
+                                   float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ y_hi,
+                                   _Float16 *__restrict__ y_lo, int64_t ld_yh) {
     int64_t u = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     if (u >= nv) return;
     int lane = gp_lane();
@@ -222,6 +370,33 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
         }
         if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
         *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
+        if (y_hi) {                                           // pre-split operand of the next layer
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            float v[4] = {a.x, a.y, a.z, a.w};
+            f16x4 h, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h[i] = (_Float16)v[i]; l[i] = (_Float16)(v[i] - (float)h[i]); }
+            *reinterpret_cast<f16x4 *>(y_hi + u * ld_yh + c) = h;
+            *reinterpret_cast<f16x4 *>(y_lo + u * ld_yh + c) = l;
+        }
+    }
+}
+
+// fp32 rows -> hi/lo f16 rows (input of the first layer)
+__global__ void split_rows_kernel(const float *__restrict__ x, int64_t ld_x, int d, int64_t n, _Float16 *__restrict__ hi,
+                                  _Float16 *__restrict__ lo, int64_t ld_h) {
+    int64_t total = n * (d / 4);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / (d / 4);
+        int c = (int)(i - r * (d / 4)) * 4;
+        float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        float v[4] = {a.x, a.y, a.z, a.w};
+        f16x4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h[k] = (_Float16)v[k]; l[k] = (_Float16)(v[k] - (float)h[k]); }
+        *reinterpret_cast<f16x4 *>(hi + r * ld_h + c) = h;
+        *reinterpret_cast<f16x4 *>(lo + r * ld_h + c) = l;
     }
 }
 
@@ -260,10 +435,12 @@ extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {
     return cv.off;
 }
 
-extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t *pair_in, int32_t *pair_pos,
-                                   int32_t *pair_off, void *workspace, size_t workspace_bytes, void *stream_) {
-    GP_CHECK_ARG(nbr_map && pair_in && pair_pos && pair_off && workspace && nv > 0 && kv > 0, "gp_conv_pairs_build: null/empty argument");
+extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t chunk_rows, int32_t *pair_in,
+                                   int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start, void *workspace,
+                                   size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(nbr_map && pair_in && pair_pos && seg_off && tile_start && workspace && nv > 0 && kv > 0, "gp_conv_pairs_build: null/empty argument");
     GP_CHECK_ARG((int64_t)kv * nv < (1ll << 31), "gp_conv_pairs_build: kernel map too large");
+    GP_CHECK_ARG(chunk_rows >= TM, "gp_conv_pairs_build: chunk_rows=%d must be >= %d", chunk_rows, TM);
     int64_t total = (int64_t)kv * nv;
     GpCarver cv(workspace, workspace_bytes);
     int32_t *f = cv.take<int32_t>(total), *sc = cv.take<int32_t>(total);
@@ -272,9 +449,11 @@ extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t k
     if (!cv.ok()) { gp_set_error("gp_conv_pairs_build: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     int blocks = (int)((total + 255) / 256);
-    pair_flags_kernel<<<blocks, 256, 0, s>>>(nbr_map, total, f);
+    int nseg = (int)((nv + chunk_rows - 1) / chunk_rows) * kv;
+    pair_flags_kernel<<<blocks, 256, 0, s>>>(nbr_map, nv, kv, chunk_rows, f);
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, f, sc, (int32_t)0, (size_t)total, rocprim::plus<int32_t>(), s));
-    pair_emit_kernel<<<blocks, 256, 0, s>>>(nbr_map, sc, nv, kv, pair_in, pair_pos, pair_off);
+    pair_emit_kernel<<<blocks, 256, 0, s>>>(nbr_map, sc, nv, kv, chunk_rows, pair_in, pair_pos, seg_off);
+    tile_start_kernel<<<1, 64, 0, s>>>(seg_off, nseg, tile_start);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -288,30 +467,54 @@ extern "C" int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, in
     return GP_OK;
 }
 
-extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const int32_t *pair_in, const int32_t *pair_pos,
-                                    const int32_t *pair_off, int64_t num_pairs, int64_t nv, int32_t kv,
+extern "C" int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
+                            void *stream_) {
+    GP_CHECK_ARG(x && hi && lo && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0, "gp_split_f16: bad argument");
+    split_rows_kernel<<<2048, 256, 0, gp_stream(stream_)>>>(x, ld_x, d, n, static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), ld_h);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
+                                    const int32_t *pair_in, const int32_t *pair_pos,
+                                    const int32_t *pair_off, const int32_t *tile_start, int32_t nseg,
+                                    int64_t num_pairs, int64_t nv, int32_t kv,
                                     const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                                     const float *scale, const float *shift, const float *residual, int64_t ld_res,
-                                    int32_t relu, float *y, int64_t ld_y, void *stream_) {
-    GP_CHECK_ARG(x && pair_in && pair_pos && pair_off && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
+                                    int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
+                                    void *stream_) {
+    GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && nseg > 0 && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
+    GP_CHECK_ARG(!x_hi || (ld_xh % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0), "gp_sparse_conv_f16x3: pre-split rows must be 16-byte aligned");
+    GP_CHECK_ARG(!y_hi || (y_lo && ld_yh % 4 == 0), "gp_sparse_conv_f16x3: y_hi/y_lo come as a pair");
     GP_CHECK_ARG(nv > 0 && num_pairs > 0 && (kv == 27 || kv == 1), "gp_sparse_conv_f16x3: bad sizes");
     GP_CHECK_ARG(cin % TK == 0, "gp_sparse_conv_f16x3: cin=%d must be a multiple of %d", cin, TK);
-    GP_CHECK_ARG(ld_x % 4 == 0 && (uintptr_t)x % 16 == 0, "gp_sparse_conv_f16x3: x rows must be 16-byte aligned");
+    GP_CHECK_ARG(x_hi || (ld_x % 4 == 0 && (uintptr_t)x % 16 == 0), "gp_sparse_conv_f16x3: x rows must be 16-byte aligned");
     static bool attr_set = false;
     if (!attr_set) {
         GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_phase1_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(V2Smem)));
+        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_phase1_dma_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(V2Smem)));
         attr_set = true;
     }
     GP_CHECK_ARG(cout % TN == 0, "gp_sparse_conv_f16x3: cout=%d must be a multiple of %d on this path", cout, TN);
     hipStream_t s = gp_stream(stream_);
     int n_tiles = cout / TN;
-    int64_t m_tiles_ub = num_pairs / TM + kv;
-    conv_phase1_kernel<<<(unsigned)(m_tiles_ub * n_tiles), NT2, sizeof(V2Smem), s>>>(
-        x, ld_x, pair_in, pair_off, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout,
-        partial, n_tiles, g_conv_ablate);
+    int64_t m_tiles_ub = num_pairs / TM + nseg;
+    int64_t nblocks = ((m_tiles_ub * n_tiles + 7) / 8) * 8;
+    if (x_hi && !(g_conv_ablate & 16))
+        conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
+            static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, nseg, kv,
+            static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate);
+    else {
+        GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
+        conv_phase1_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
+            x, ld_x, pair_in, pair_off, tile_start, nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout,
+            partial, n_tiles, g_conv_ablate);
+    }
     conv_phase2_kernel<<<(unsigned)((nv * 64 + 255) / 256), 256, 0, s>>>(partial, pair_pos, nv, kv, cout, scale, shift, residual,
-                                                                        ld_res, relu, y, ld_y);
+                                                                        ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
+                                                                        static_cast<_Float16 *>(y_lo), ld_yh);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

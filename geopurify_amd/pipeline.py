@@ -74,21 +74,32 @@ class StudentWeights:
         else:
             self.layers.append(("f32", w, scale, shift))
 
-    def _conv(self, li, x, ctx, residual=None):
+    def _conv(self, li, x, ctx, residual=None, x_split=None, want_split=False):
         kind, w, scale, shift = self.layers[li]
         if kind == "f16x3":
-            return ops.sparse_conv_f16x3(x, ctx["pairs"], w[0], w[1], scale, shift, residual=residual, relu=True)
-        return ops.sparse_conv(x, ctx["nbr_map"], w, scale, shift, residual=residual, relu=True)
+            out_split = None
+            if want_split:
+                nv, cout = ctx["pairs"].nv, w[0].shape[1]
+                out_split = tuple(torch.empty((nv, cout), dtype=torch.float16, device=w[0].device) for _ in range(2))
+            y = ops.sparse_conv_f16x3(x, ctx["pairs"], w[0], w[1], scale, shift, residual=residual, relu=True,
+                                      x_split=x_split, out_split=out_split)
+            return y, out_split
+        return ops.sparse_conv(x, ctx["nbr_map"], w, scale, shift, residual=residual, relu=True), None
 
     def forward(self, x, nbr_map, pairs=None):
-        """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed]."""
+        """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed].
+        On the f16x3 path every layer also emits its output pre-split (hi/lo f16) so that the next
+        layer stages both operands by LDS-DMA."""
         ctx = {"nbr_map": nbr_map, "pairs": pairs}
+        fast = all(l[0] == "f16x3" for l in self.layers)
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
             ctx["pairs"] = ops.conv_pairs_build(nbr_map)
-        h = self._conv(0, x, ctx)
+        xs = ops.split_f16(x, self.cin_pad) if fast else None
+        h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast)
         for b in range(self.num_blocks):
-            t = self._conv(1 + 2 * b, h, ctx)
-            h = self._conv(2 + 2 * b, t, ctx, residual=h)
+            t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast)
+            last = b == self.num_blocks - 1
+            h, hs = self._conv(2 + 2 * b, t, ctx, residual=h, x_split=ts, want_split=fast and not last)
         e = ops.sparse_conv(h, None, self.w_out)
         self.last_pairs = ctx["pairs"]
         return ops.l2norm_rows_(e)

@@ -107,22 +107,32 @@ int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t
 /* Fast path of the same convolution on the f16 matrix cores with fp32-class accuracy (operands     */
 /* split x = hi + lo in f16, products hi*hi + hi*lo + lo*hi accumulated in fp32; relative error of   */
 /* a product <= 2^-21).  gp_conv_pairs_build compacts the kernel map once per scene: pair_in i32     */
-/* [num_pairs] (input row per pair, ordered by (k, output row)), pair_pos i32 [kv,nv] (pair index or   */
-/* -1), pair_off i32 [kv+1] (first pair of each offset; pair_off[kv] = num_pairs).                    */
+/* [num_pairs] (input row per pair, ordered by (chunk of chunk_rows output rows, k, output row)),      */
+/* pair_pos i32 [kv,nv] (pair index or -1), seg_off i32 [nseg+1] (first pair of each (chunk,k) segment, */
+/* nseg = ceil(nv/chunk_rows)*kv; seg_off[nseg] = num_pairs), tile_start i32 [nseg+1] (256-pair tiles    */
+/* before each segment).                                                                              */
 /* gp_conv_weights_split: w fp32 [kv,cin,cout] -> w_hi/w_lo f16 [kv,cout,cin] of scale_pow2 * w.       */
 /* gp_sparse_conv_f16x3: partial fp32 [num_pairs,cout] workspace; epilogue as gp_sparse_conv (the     */
 /* caller folds 1/scale_pow2 into `scale`).  cin % 32 == 0, cout % 256 == 0, |x| < 65504.              */
 size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv);
-int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t *pair_in,
-                        int32_t *pair_pos, int32_t *pair_off, void *workspace, size_t workspace_bytes,
-                        void *stream);
+int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t chunk_rows,
+                        int32_t *pair_in, int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start,
+                        void *workspace, size_t workspace_bytes, void *stream);
 int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2,
                           void *w_hi, void *w_lo, void *stream);
-int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const int32_t *pair_in, const int32_t *pair_pos,
-                         const int32_t *pair_off, int64_t num_pairs, int64_t nv, int32_t kv,
+/* Optional pre-split operands: x_hi/x_lo f16 [nv, ld_xh] (from gp_split_f16 or a previous layer's   */
+/* y_hi/y_lo) select the LDS-DMA staging path (x may then be NULL); y_hi/y_lo f16 [nv, ld_yh] (or      */
+/* NULL) receive the split output for the next layer.                                                */
+int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
+                 void *stream);
+int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
+                         const int32_t *pair_in, const int32_t *pair_pos,
+                         const int32_t *seg_off, const int32_t *tile_start, int32_t nseg,
+                         int64_t num_pairs, int64_t nv, int32_t kv,
                          const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                          const float *scale, const float *shift, const float *residual, int64_t ld_res,
-                         int32_t relu, float *y, int64_t ld_y, void *stream);
+                         int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
+                         void *stream);
 /* in-place row L2 normalisation, F.normalize(p=2, dim=1, eps=1e-12) (affinity_module.py:1547)     */
 int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
 

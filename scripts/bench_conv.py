@@ -19,7 +19,9 @@ perm, rank = ops.morton_order(coords)
 cs = coords[perm.long()].contiguous()
 grid = ops.grid_build(cs)
 nm = ops.kernel_map_build(grid, cs)
-pairs = ops.conv_pairs_build(nm)
+import sys as _s
+CHUNK = int(os.environ.get('GP_CHUNK', '1073741824'))
+pairs = ops.conv_pairs_build(nm, CHUNK)
 Nv = cs.shape[0]
 print("Nv", Nv, "pairs", pairs.num_pairs, flush=True)
 X = torch.randn(Nv, 512, device="cuda")
@@ -49,5 +51,16 @@ for name, v in (("full", 0), ("no global loads after step 0", 1), ("no MFMA", 2)
     print(f"{name:36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
 if ab is not None:
     ab(ctypes.c_int(0))
+xs = ops.split_f16(X)
+ys = tuple(torch.empty((Nv, 512), dtype=torch.float16, device="cuda") for _ in range(2))
+t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs, out_split=ys))
+print(f"{'LDS-DMA path (pre-split in/out)':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
+t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs))
+print(f"{'LDS-DMA path (no split output)':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
+for name, v in (("DMA: no MFMA", 2), ("DMA: no MFMA, no epilogue", 10), ("DMA: no epilogue", 8)):
+    lib.gp_debug_set(3, v)
+    t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs))
+    print(f"{name:36s} {t:7.3f} ms", flush=True)
+lib.gp_debug_set(3, 0)
 t = timeit(lambda: ops.sparse_conv(X, nm, W, sc_, sh, relu=True), 2)
 print(f"{'v1 fp32 MFMA kernel':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s)")

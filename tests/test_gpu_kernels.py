@@ -442,14 +442,18 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     c = surface_voxels(rng, 2500)
     ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
     nm = ops.kernel_map_build(grid, cs)
-    pairs = ops.conv_pairs_build(nm)
+    pairs = ops.conv_pairs_build(nm, 2048)
     nmc = nm.cpu().numpy()
     assert pairs.num_pairs == int((nmc >= 0).sum())
     pos = pairs.pair_pos.cpu().numpy()
     assert np.array_equal(pos >= 0, nmc >= 0)
     assert np.array_equal(pairs.pair_in.cpu().numpy()[pos[pos >= 0]], nmc[nmc >= 0])
-    off = pairs.pair_off.cpu().numpy()
-    assert np.array_equal(np.diff(off), (nmc >= 0).sum(1))
+    off = pairs.pair_off.cpu().numpy()                                  # (chunk, k) segments, chunk-major
+    CH = 2048
+    seg_counts = np.concatenate([(nmc[:, c0:c0 + CH] >= 0).sum(1) for c0 in range(0, len(c), CH)])
+    assert np.array_equal(np.diff(off), seg_counts) and off[-1] == pairs.num_pairs
+    ts = pairs.tile_start.cpu().numpy()
+    assert np.array_equal(np.diff(ts), (seg_counts + 255) // 256)
     Nv = len(c)
     X = torch.randn(Nv, 96) * 3.0
     X[:, :8] *= 1e-3                                                   # small-magnitude channels too
@@ -465,6 +469,14 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     y32 = ops.sparse_conv(dev(X), nm, dev(W), dev(sc), dev(sh), residual=dev(res), relu=True)
     err32 = (y32.cpu().double() - ref).abs().max().item()
     assert err < 5e-5 and err < 4 * err32 + 1e-6, (err, err32)        # same class as the exact-fp32 MFMA kernel
+    # LDS-DMA path: pre-split operand in, split output out; identical arithmetic => identical result
+    xs = ops.split_f16(dev(X))
+    assert torch.equal(xs[0].float() + xs[1].float(), dev(X)) or (xs[0].float() + xs[1].float() - dev(X)).abs().max() < 1e-6
+    ys = tuple(torch.empty((Nv, 256), dtype=torch.float16, device="cuda") for _ in range(2))
+    y2 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs,
+                               out_split=ys)
+    assert torch.equal(y2, y)
+    assert (ys[0].float() + ys[1].float() - y2).abs().max() <= 2e-6 * max(1.0, float(y2.abs().max()))
 
 
 # ------------------------------------------------------------------------------------------ row 12 fast path
