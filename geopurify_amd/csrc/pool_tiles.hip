@@ -276,7 +276,7 @@ extern "C" int gp_pool_tiles_apply(const float *x, int64_t ld_x, const int64_t *
     int64_t nt = (nv + r - 1) / r;
     hipStream_t s = gp_stream(stream_);
     // R=16 keeps 256 columns per wave (64 accumulator registers); R<=8 keeps 512 (tunable: gp_debug_set)
-    int nf4 = g_pool_nf4 ? g_pool_nf4 : ((r == 16) ? 1 : 2);
+    int nf4 = g_pool_nf4 ? g_pool_nf4 : ((r == 4) ? 2 : 1);   // measured best: 256 columns per wave for r=8,16
     GP_CHECK_ARG(d % (nf4 * 256) == 0, "gp_pool_tiles_apply: d=%d must be a multiple of %d (use gp_pool_ell otherwise)", d, nf4 * 256);
     int slabs = d / (nf4 * 256);
     int64_t waves = nt * slabs;

@@ -350,10 +350,17 @@ class HotPath:
         bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
         cur = X
         R = self.pool_tile_rows
-        use_tiles = self.pool_mode == "tiles" and self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
+        use_tiles = self.pool_mode in ("tiles", "blocks") and self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
         tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
+        blocks = None
+        if use_tiles and self.pool_mode == "blocks" and R == 8 and D == 512:
+            blocks = ops.pool_blocks_build(tiles)
+            if not blocks.ok:
+                blocks = None
         for t in range(self.num_iters):
-            if use_tiles:
+            if blocks is not None:
+                ops.pool_blocks_apply(cur, blocks, D, bufs[t % 2])
+            elif use_tiles:
                 ops.pool_tiles_apply(cur, tiles, D, bufs[t % 2])
             else:
                 ops.pool_ell(cur, nbr, w, D, bufs[t % 2])

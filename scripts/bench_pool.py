@@ -51,11 +51,16 @@ for R in (4, 8, 16):
             if (R, nf4, un) in ((16, 2, 8), (4, 1, 4), (4, 1, 8)):
                 continue
             variants.append((f"tiles R={R} nf4={nf4} unroll={un}", (R, nf4, un)))
+blocks = ops.pool_blocks_build(tiles[8])
+print("blocks ok", blocks.ok, "block union rows/row", (int(blocks.bu_off[-1]) / Nv) if blocks.ok else None, flush=True)
+variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4] + [("blocks (64 rows share LDS x)", "blocks")]
 res = {}
 for rnd in range(3):
     for name, v in variants:
         if v is None:
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
+        elif v == "blocks":
+            t = timeit(lambda: ops.pool_blocks_apply(X, blocks, D, Y))
         else:
             R, nf4, un = v
             lib.gp_debug_set(1, nf4); lib.gp_debug_set(2, un)
