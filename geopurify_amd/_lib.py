@@ -71,6 +71,7 @@ SIGNATURES = {
     "gp_visible_lists_workspace_bytes": (c_size_t, [c_int64]),
     "gp_visible_lists": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gp_classify_argmax": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_float, _P, _P, _P]),
+    "gp_rows_argmax": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "gp_iou_hist_i64": (c_int32, [_P, _P, c_int64, c_int32, POINTER(c_int64), c_int32, _P, _P]),
 }
 

@@ -4,6 +4,8 @@
 
 #include "gp_common.h"
 
+extern int g_gp_knobs[8];
+
 namespace {
 
 constexpr int NN_TILE = 1024;
@@ -104,6 +106,157 @@ nn1_masked_kernel(const float *__restrict__ xyz, const float *__restrict__ rxyz,
     if (q >= 0) nn[q] = ridx[bi];
 }
 
+
+// ---- grid-accelerated exact 1-NN (large point sets).  A uniform grid over the bounding box of ALL
+// points (so every query lies inside its cell); references are bucketed by cell (counting sort).  A query
+// scans the cubic shells of cells around its own cell; after shell r every unscanned point is at least
+// r*h away, so the search stops once best_d <= r*h (with a 1e-9 relative slack for the cell rounding).
+// Winner = lexicographic minimum of (d2 in fp64, original index): identical to the brute-force kernel.
+constexpr int NGMAX = 128;                                 // buffers are sized for this many cells per axis
+
+struct NnGrid { double lo[3]; double inv_h; double h; int ng; };
+
+__global__ void nn_bbox_kernel(const float *__restrict__ xyz, int64_t n, float *__restrict__ bb /*[6] min,max*/) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { float v = xyz[i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+        if (gp_lane() == 0) {
+            // float atomic min/max through the ordered-int trick (values are finite)
+            int *pl = reinterpret_cast<int *>(bb + a), *ph = reinterpret_cast<int *>(bb + 3 + a);
+            int il = __float_as_int(lo[a]), ih = __float_as_int(hi[a]);
+            if (il >= 0) atomicMin(pl, il); else atomicMax(reinterpret_cast<unsigned *>(pl), (unsigned)il);
+            if (ih >= 0) atomicMax(ph, ih); else atomicMin(reinterpret_cast<unsigned *>(ph), (unsigned)ih);
+        }
+    }
+}
+__global__ void nn_bbox_init_kernel(float *bb) {
+    if (threadIdx.x < 3) bb[threadIdx.x] = INFINITY;
+    else if (threadIdx.x < 6) bb[threadIdx.x] = -INFINITY;
+}
+__device__ __forceinline__ void nn_grid_of(const float *bb, NnGrid &g, int NG) {
+    g.ng = NG;
+    double ext = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g.lo[a] = bb[a]; double e = (double)bb[3 + a] - (double)bb[a]; ext = e > ext ? e : ext; }
+    g.h = ext > 0 ? ext * (1.0 + 1e-6) / NG : 1.0;
+    g.inv_h = 1.0 / g.h;
+}
+__device__ __forceinline__ int nn_cell(const NnGrid &g, double v, int a) {
+    int c = (int)floor((v - g.lo[a]) * g.inv_h);
+    return c < 0 ? 0 : (c >= g.ng ? g.ng - 1 : c);
+}
+__global__ void nn_cell_count_kernel(const float *__restrict__ rxyz, const int32_t *__restrict__ counts, const float *__restrict__ bb,
+                                     int32_t *__restrict__ cell_cnt, int32_t *__restrict__ rcell, int NG) {
+    int n_ref = counts[0];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ref) return;
+    NnGrid g; nn_grid_of(bb, g, NG);
+    int c = (nn_cell(g, rxyz[i * 3 + 2], 2) * NG + nn_cell(g, rxyz[i * 3 + 1], 1)) * NG + nn_cell(g, rxyz[i * 3], 0);
+    rcell[i] = c;
+    atomicAdd(&cell_cnt[c], 1);
+}
+__global__ void nn_cell_fill_kernel(const float *__restrict__ rxyz, const int64_t *__restrict__ ridx, const int32_t *__restrict__ counts,
+                                    const int32_t *__restrict__ rcell, const int32_t *__restrict__ cell_start,
+                                    int32_t *__restrict__ cursor, float *__restrict__ sxyz, int64_t *__restrict__ sidx) {
+    int n_ref = counts[0];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ref) return;
+    int c = rcell[i];
+    int p = cell_start[c] + atomicAdd(&cursor[c], 1);
+    sxyz[p * 3] = rxyz[i * 3]; sxyz[p * 3 + 1] = rxyz[i * 3 + 1]; sxyz[p * 3 + 2] = rxyz[i * 3 + 2];
+    sidx[p] = ridx[i];
+}
+__global__ void __launch_bounds__(256)
+nn_grid_query_kernel(const float *__restrict__ xyz, const float *__restrict__ sxyz, const int64_t *__restrict__ sidx,
+                     const int32_t *__restrict__ cell_start, const int64_t *__restrict__ qidx, const int32_t *__restrict__ counts,
+                     const float *__restrict__ bb, int64_t *__restrict__ nn, int NG, int r_max, int pending_only) {
+    const int n_ref = counts[0], n_q = counts[1];
+    int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= n_q || n_ref == 0) return;
+    NnGrid g; nn_grid_of(bb, g, NG);
+    const int64_t q = qidx[qi];
+    if (pending_only && nn[q] != -2) return;
+    const double qx = xyz[q * 3], qy = xyz[q * 3 + 1], qz = xyz[q * 3 + 2];
+    const int cx = nn_cell(g, qx, 0), cy = nn_cell(g, qy, 1), cz = nn_cell(g, qz, 2);
+    double best = INFINITY;
+    int64_t bi = INT64_MAX;
+    bool done = false;
+    for (int r = 0; r < NG && r <= r_max; ++r) {
+        const int z0 = cz - r, z1 = cz + r, y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
+        for (int z = max(z0, 0); z <= min(z1, NG - 1); ++z)
+            for (int y = max(y0, 0); y <= min(y1, NG - 1); ++y) {
+                const bool face = (z == z0 || z == z1 || y == y0 || y == y1);
+                const int xs = face ? 1 : (x1 - x0 > 0 ? x1 - x0 : 1);           // interior rows: only the two x faces
+                for (int x = x0; x <= x1; x += xs) {
+                    if (x < 0 || x >= NG) continue;
+                    const int c = (z * NG + y) * NG + x;
+                    for (int j = cell_start[c]; j < cell_start[c + 1]; ++j) {
+                        double dx = qx - sxyz[j * 3], dy = qy - sxyz[j * 3 + 1], dz = qz - sxyz[j * 3 + 2];
+                        double d2 = (dx * dx + dy * dy) + dz * dz;
+                        int64_t id = sidx[j];
+                        if (d2 < best || (d2 == best && id < bi)) { best = d2; bi = id; }
+                    }
+                }
+            }
+        const double bound = r * g.h * (1.0 - 1e-9);
+        if (best <= bound * bound) { done = true; break; }
+        if (x0 <= 0 && y0 <= 0 && z0 <= 0 && x1 >= NG - 1 && y1 >= NG - 1 && z1 >= NG - 1) { done = true; break; }   // whole grid scanned
+    }
+    nn[q] = done ? bi : -2;                                   // -2: not settled within r_max shells (next pass)
+}
+
+// far queries (not settled within 2 fine shells): one WAVE per query on the coarse grid; the 64 lanes
+// split the (z,y) cell rows of each shell and scan their points, then a wave reduction of (d2, id)
+__global__ void __launch_bounds__(256)
+nn_grid_query_wave_kernel(const float *__restrict__ xyz, const float *__restrict__ sxyz, const int64_t *__restrict__ sidx,
+                          const int32_t *__restrict__ cell_start, const int64_t *__restrict__ qidx,
+                          const int32_t *__restrict__ counts, const float *__restrict__ bb, int64_t *__restrict__ nn, int NG) {
+    const int n_ref = counts[0], n_q = counts[1];
+    const int qi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (qi >= n_q || n_ref == 0) return;
+    const int64_t q = qidx[qi];
+    if (nn[q] != -2) return;                                   // wave-uniform
+    NnGrid g; nn_grid_of(bb, g, NG);
+    const double qx = xyz[q * 3], qy = xyz[q * 3 + 1], qz = xyz[q * 3 + 2];
+    const int cx = nn_cell(g, qx, 0), cy = nn_cell(g, qy, 1), cz = nn_cell(g, qz, 2);
+    double best = INFINITY;
+    long long bi = INT64_MAX;
+    for (int r = 0; r < NG; ++r) {
+        const int z0 = cz - r, y0 = cy - r, x0 = cx - r, x1 = cx + r, side = 2 * r + 1;
+        for (int p = lane; p < side * side; p += 64) {
+            const int z = z0 + p / side, y = y0 + p % side;
+            if (z < 0 || z >= NG || y < 0 || y >= NG) continue;
+            const bool face = (z == z0 || z == cz + r || y == y0 || y == cy + r);
+            const int xs = face ? 1 : (side > 1 ? side - 1 : 1);
+            for (int x = x0; x <= x1; x += xs) {
+                if (x < 0 || x >= NG) continue;
+                const int c = (z * NG + y) * NG + x;
+                for (int j = cell_start[c]; j < cell_start[c + 1]; ++j) {
+                    double dx = qx - sxyz[j * 3], dy = qy - sxyz[j * 3 + 1], dz = qz - sxyz[j * 3 + 2];
+                    double d2 = (dx * dx + dy * dy) + dz * dz;
+                    long long id = sidx[j];
+                    if (d2 < best || (d2 == best && id < bi)) { best = d2; bi = id; }
+                }
+            }
+        }
+        // wave-wide lexicographic minimum (all lanes end up with the same value)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double ob = __shfl_xor(best, o, 64);
+            long long oi = __shfl_xor(bi, o, 64);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const double bound = r * g.h * (1.0 - 1e-9);
+        if (best <= bound * bound) break;
+        if (x0 <= 0 && y0 <= 0 && z0 <= 0 && x1 >= NG - 1 && cy + r >= NG - 1 && cz + r >= NG - 1) break;
+    }
+    if (lane == 0) nn[q] = bi;
+}
+
 // ---- ordered compaction of the visible points of one view: (point id, pixel row, pixel col)
 __global__ void vis_flags_kernel(const int64_t *__restrict__ mapping, int64_t n, int32_t *__restrict__ f) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -163,6 +316,37 @@ __global__ void classify_kernel(const float *__restrict__ feat, int64_t ld, int 
     }
 }
 
+// arg-max over the first C columns of precomputed logits rows (first maximum wins); optional zero-row
+// flag of the feature rows (sum |f| == 0).  Used with the MFMA GEMM logits for large class counts.
+__global__ void rows_argmax_kernel(const float *__restrict__ logits, int64_t ld, int C, int64_t n,
+                                   const float *__restrict__ feat, int64_t ld_f, int d, int64_t *__restrict__ pred,
+                                   uint8_t *__restrict__ zero_row) {
+    int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (p >= n) return;
+    int lane = gp_lane();
+    float bv = -INFINITY;
+    int bc = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        float v = logits[p * ld + c];
+        if (v > bv) { bv = v; bc = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o, 64);
+        int oc = __shfl_xor(bc, o, 64);
+        if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+    }
+    float sa = 0.f;
+    if (zero_row && feat) {
+        for (int c = lane; c < d; c += 64) sa += fabsf(feat[p * ld_f + c]);
+        sa = gp_wave_sum(sa);
+    }
+    if (lane == 0) {
+        pred[p] = bc == 0x7fffffff ? 0 : bc;
+        if (zero_row && feat) zero_row[p] = (sa == 0.f) ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void iou_hist_kernel(const int64_t *__restrict__ pred, const int64_t *__restrict__ target, int64_t n, int C,
                                 const int64_t ig0, const int64_t ig1, const int64_t ig2, const int64_t ig3, int nig,
@@ -217,7 +401,11 @@ extern "C" size_t gp_nn1_masked_workspace_bytes(int64_t n) {
     GpCarver cv(nullptr, 0);
     cv.take<int32_t>(n); cv.take<int32_t>(n); cv.take<int32_t>(n); cv.take<int32_t>(n);
     cv.take<float>(3 * n); cv.take<int64_t>(n); cv.take<int64_t>(n); cv.take<int32_t>(64);
-    cv.take<char>(scan32_tmp(n));
+    cv.take<char>(scan32_tmp(n > (int64_t)NGMAX * NGMAX * NGMAX + 1 ? n : (int64_t)NGMAX * NGMAX * NGMAX + 1));
+    // grid path
+    cv.take<float>(8); cv.take<int32_t>(n); cv.take<int32_t>((size_t)NGMAX * NGMAX * NGMAX + 1); cv.take<int32_t>((size_t)NGMAX * NGMAX * NGMAX + 1);
+    cv.take<int32_t>((size_t)NGMAX * NGMAX * NGMAX + 1); cv.take<float>(3 * n); cv.take<int64_t>(n);
+    cv.take<float>(3 * n); cv.take<int64_t>(n); cv.take<int32_t>(3 * (32 * 32 * 32 + 1));
     return cv.off;
 }
 
@@ -230,8 +418,20 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     float *rxyz = cv.take<float>(3 * n);
     int64_t *ridx = cv.take<int64_t>(n), *qidx = cv.take<int64_t>(n);
     int32_t *counts = cv.take<int32_t>(64);
-    size_t tb = scan32_tmp(n);
+    const int64_t ncell_max = (int64_t)NGMAX * NGMAX * NGMAX;
+    int NG = g_gp_knobs[6] > 0 ? g_gp_knobs[6] : 128;
+    if (NG > NGMAX) NG = NGMAX;
+    const int64_t ncell = (int64_t)NG * NG * NG;
+    size_t tb = scan32_tmp(n > ncell_max + 1 ? n : ncell_max + 1);
     char *tmp = cv.take<char>(tb);
+    float *bb = cv.take<float>(8);
+    int32_t *rcell = cv.take<int32_t>(n);
+    int32_t *cell_cnt = cv.take<int32_t>(ncell_max + 1), *cell_start = cv.take<int32_t>(ncell_max + 1), *cursor = cv.take<int32_t>(ncell_max + 1);
+    float *sxyz = cv.take<float>(3 * n);
+    int64_t *sidx = cv.take<int64_t>(n);
+    float *sxyz2 = cv.take<float>(3 * n);
+    int64_t *sidx2 = cv.take<int64_t>(n);
+    int32_t *cells2 = cv.take<int32_t>(3 * (32 * 32 * 32 + 1));
     if (!cv.ok()) { gp_set_error("gp_nn1_masked_f64: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
     hipStream_t st = gp_stream(stream_);
     int blocks = (int)((n + 255) / 256);
@@ -241,7 +441,31 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     t = tb;
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, t, qf, qs, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), st));
     mask_compact_kernel<<<blocks, 256, 0, st>>>(xyz, ref_mask, query_mask, rs, qs, n, rxyz, ridx, qidx, counts, nn);
-    nn1_masked_kernel<<<blocks, 256, 0, st>>>(xyz, rxyz, ridx, qidx, counts, nn);
+    if (n >= 32768 && !g_gp_knobs[5]) {
+        // grid path: bbox of all points; references bucketed by cell on a fine grid (near queries settle within
+        // 2 shells) and on a coarse 32^3 grid (far queries: empty space is crossed in few, large steps)
+        nn_bbox_init_kernel<<<1, 64, 0, st>>>(bb);
+        nn_bbox_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(xyz, n, bb);
+        auto bucket = [&](int ng, int32_t *cnt, int32_t *start, int32_t *cur, float *sx, int64_t *si) -> int {
+            int64_t nc = (int64_t)ng * ng * ng;
+            GP_CHECK_HIP(hipMemsetAsync(cnt, 0, (nc + 1) * sizeof(int32_t), st));
+            GP_CHECK_HIP(hipMemsetAsync(cur, 0, (nc + 1) * sizeof(int32_t), st));
+            nn_cell_count_kernel<<<blocks, 256, 0, st>>>(rxyz, counts, bb, cnt, rcell, ng);
+            size_t tt = tb;
+            GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tt, cnt, start, (int32_t)0, (size_t)(nc + 1), rocprim::plus<int32_t>(), st));
+            nn_cell_fill_kernel<<<blocks, 256, 0, st>>>(rxyz, ridx, counts, rcell, start, cur, sx, si);
+            return GP_OK;
+        };
+        int rc = bucket(NG, cell_cnt, cell_start, cursor, sxyz, sidx);
+        if (rc) return rc;
+        const int NG2 = 32, nc2 = NG2 * NG2 * NG2 + 1;
+        rc = bucket(NG2, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
+        if (rc) return rc;
+        nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
+        nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, NG2);
+    } else {
+        nn1_masked_kernel<<<blocks, 256, 0, st>>>(xyz, rxyz, ridx, qidx, counts, nn);
+    }
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -275,6 +499,14 @@ extern "C" int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int6
     GP_CHECK_ARG(feat && text_norm && pred && n > 0 && d > 0 && c > 0, "gp_classify_argmax: null/empty argument");
     classify_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
                                                                                pred, zero_row);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_rows_argmax(const float *logits, int64_t ld, int32_t c, int64_t n, const float *feat, int64_t ld_f,
+                              int32_t d, int64_t *pred, uint8_t *zero_row, void *stream_) {
+    GP_CHECK_ARG(logits && pred && n > 0 && c > 0, "gp_rows_argmax: null/empty argument");
+    rows_argmax_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(logits, ld, c, n, feat, ld_f, d, pred, zero_row);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

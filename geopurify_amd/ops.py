@@ -480,6 +480,24 @@ def classify_argmax(feat, text_norm, logit_scale, d=None):
     return pred, zero
 
 
+def classify_argmax_gemm(feat, text_norm, d=None):
+    """Same decision as classify_argmax (arg-max_c <f/|f|, t_c> = arg-max_c <f, t_c>) with the logits from
+    the exact-fp32 MFMA GEMM kernel -- for large class counts (Matterport-160 / ScanNet200)."""
+    lib = _lib.load()
+    n = feat.shape[0]
+    d = feat.shape[1] if d is None else d
+    C = text_norm.shape[0]
+    cpad = (C + 127) // 128 * 128
+    w = torch.zeros((d, cpad), dtype=torch.float32, device=feat.device)
+    w[:, :C] = text_norm.t()
+    logits = sparse_conv(feat, None, w)
+    pred = torch.empty(n, dtype=torch.int64, device=feat.device)
+    zero = torch.empty(n, dtype=torch.uint8, device=feat.device)
+    check(lib.gp_rows_argmax(_ptr(logits), logits.stride(0), C, n, _ptr(feat), feat.stride(0), int(d), _ptr(pred),
+                             _ptr(zero), _stream()), "gp_rows_argmax")
+    return pred, zero
+
+
 def iou_hist(pred, target, num_classes, ignore_ids, counts):
     lib = _lib.load()
     ig = (ctypes.c_int64 * max(len(ignore_ids), 1))(*[int(v) for v in ignore_ids])

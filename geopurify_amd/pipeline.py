@@ -379,7 +379,11 @@ class HotPath:
     # ---- row 13 + caller tail --------------------------------------------------------------------
     def classify_and_count(self, result, labels, num_classes, ignore_ids, counts):
         text_norm = torch.nn.functional.normalize(result["text_features"], dim=-1).contiguous()
-        pred, zero = ops.classify_argmax(result["scene_features"], text_norm, result["logit_scale"])
+        feats = result["scene_features"]
+        if text_norm.shape[0] > 32 and feats.shape[1] % 32 == 0:
+            pred, zero = ops.classify_argmax_gemm(feats, text_norm)
+        else:
+            pred, zero = ops.classify_argmax(feats, text_norm, result["logit_scale"])
         ops.iou_hist(pred, labels, num_classes, ignore_ids, counts)
         return pred, zero
 

@@ -252,6 +252,10 @@ int gp_visible_lists(const int64_t *mapping, int64_t n, int64_t *pt, int64_t *x,
 /* pred[p] = argmax_c <normalize(F[p]), text_norm[c]> (first max on ties); zero_row[p] = sum|F|==0  */
 int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int64_t n, const float *text_norm,
                        int32_t c, float logit_scale, int64_t *pred, uint8_t *zero_row, void *stream);
+/* arg-max over the first c columns of logits rows fp32 [n, ld] (e.g. gp_sparse_conv with kv=1 as the   */
+/* exact-fp32 MFMA GEMM F @ T^T); zero_row from feat (optional).                                      */
+int gp_rows_argmax(const float *logits, int64_t ld, int32_t c, int64_t n, const float *feat, int64_t ld_f,
+                   int32_t d, int64_t *pred, uint8_t *zero_row, void *stream);
 /* counts i64 [3,C] += (intersection, output, target) histograms with the ignore-id overwrite.      */
 int gp_iou_hist_i64(const int64_t *pred, const int64_t *target, int64_t n, int32_t num_classes,
                     const int64_t *ignore_ids_host, int32_t num_ignore, int64_t *counts,

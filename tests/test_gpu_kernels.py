@@ -403,6 +403,15 @@ def test_classify_and_iou(ops):
     safe = (top2[:, 0] - top2[:, 1]) > 1e-4
     assert torch.equal(pred.cpu()[safe], ref_pred[safe]) and safe.float().mean() > 0.99
     assert torch.equal(zero.cpu().bool(), Fp.abs().sum(1) == 0)
+    # large class count: logits by the exact-fp32 MFMA GEMM, same decisions
+    text160 = torch.randn(160, D)
+    tn160 = F.normalize(text160, dim=-1)
+    p160, z160 = ops.classify_argmax_gemm(dev(Fp), dev(tn160))
+    r160, lg160 = o_metric.classify(Fp, text160, 14.285)
+    t2 = lg160.topk(2, dim=1).values
+    safe160 = (t2[:, 0] - t2[:, 1]) > 1e-4
+    assert torch.equal(p160.cpu()[safe160], r160[safe160]) and safe160.float().mean() > 0.99
+    assert torch.equal(z160.cpu().bool(), Fp.abs().sum(1) == 0)
     tgt = torch.from_numpy(rng.integers(0, 21, N))
     counts = torch.zeros((3, C), dtype=torch.int64, device="cuda")
     ops.iou_hist(dev(ref_pred), dev(tgt), C, [19, 20], counts)
@@ -554,3 +563,29 @@ def test_pool_blocks_matches_tiles_and_oracle(ops):
     assert (ca - cb).abs().max() < 1e-5
     ref = o_aff.pool_gather(X[:, :D], nbr.cpu().long(), w.cpu(), T)
     assert (ca.cpu().double() - ref).abs().max() < 1e-5
+
+
+def test_nn1_masked_grid_path_equals_bruteforce(ops):
+    """>= 32768 points take the grid-accelerated search; must equal the brute force (incl. far queries)."""
+    from geopurify_amd import _lib
+    rng = np.random.default_rng(14)
+    n = 60000
+    xyz = rng.uniform(0, 4, size=(n, 3)).astype(np.float32)
+    xyz[:, 2] *= 0.02                                                  # a thin slab: surface-like
+    xyz[:200] += np.array([30.0, 0, 0], np.float32)                    # a far-away cluster of queries
+    xyz[200:260] = xyz[300:360]                                        # exact duplicates (ties -> lowest index)
+    ref = rng.random(n) < 0.7
+    ref[:200] = False
+    qry = ~ref
+    xd = dev(xyz)
+    rm, qm = dev(ref.astype(np.uint8)), dev(qry.astype(np.uint8))
+    lib = _lib.load()
+    nn_grid = ops.nn1_masked(xd, rm, qm).cpu().numpy()
+    lib.gp_debug_set(5, 1)                                             # force the brute-force kernel
+    nn_bf = ops.nn1_masked(xd, rm, qm).cpu().numpy()
+    lib.gp_debug_set(5, 0)
+    assert np.array_equal(nn_grid, nn_bf)
+    assert (nn_grid[ref] == -1).all() and (nn_grid[qry] >= 0).all() and ref[nn_grid[qry]].all()
+    sub = np.where(qry)[0][:400]
+    exp = np.where(ref)[0][o_lift.nn1_indices_bruteforce(xyz[ref], xyz[sub])]
+    assert np.array_equal(nn_grid[sub], exp)
