@@ -1,0 +1,149 @@
+"""Host mirror of dataset/feature_loader.py (+ the parts of dataset/point_loader.py it needs):
+OpenScene-style loader of pre-fused per-point features.
+
+Same constructor and __getitem__ contract as the reference FusedFeatureLoader
+(dataset/feature_loader.py:11-218) and the same collate functions (:221-255); the voxelization runs on
+the HIP voxelizer (geopurify_amd.voxelizer.Voxelizer, augmentation always on as in Point3DLoader).
+On-disk formats: scene `.pth` = (coords, colors in [-1,1], labels) (dataset/scripts/preprocess/
+preprocess_3d_scannet.py:19-25); features `{scene}_{k}.pt` = {"feat": [n_seen,D], "mask_full": [N] bool}
+or the three-key form with an extra "mask".  Out of scope: the SharedArray
+/dev/shm cache (memcache_init) and the train-time colour/elastic augmentations (aug=True).
+"""
+import copy
+from glob import glob
+from os.path import join
+
+import numpy as np
+import torch
+
+from .voxelizer import default_voxelizer
+
+
+class FusedFeatureLoader(torch.utils.data.Dataset):
+    def __init__(self, datapath_prefix, datapath_prefix_feat, voxel_size=0.05, split="train", aug=False,
+                 memcache_init=False, identifier=7791, loop=1, eval_all=False, input_color=False):
+        super().__init__()
+        if aug:
+            raise NotImplementedError("train-time augmentations (dataset/augmentation.py) are out of scope")
+        if memcache_init:
+            raise NotImplementedError("the SharedArray /dev/shm cache is out of scope")
+        self.split = split
+        self.identifier = identifier
+        self.data_paths = sorted(glob(join(datapath_prefix, split or "", "*.pth")))
+        if len(self.data_paths) == 0:
+            raise Exception("0 file is loaded in the point loader.")
+        self.input_color = input_color
+        self.voxel_size = voxel_size
+        self.aug = aug
+        self.loop = loop
+        self.eval_all = eval_all
+        self.dataset_name = datapath_prefix.split("/")[-1]
+        self.use_shm = False
+        self.voxelizer = default_voxelizer(voxel_size)
+        self.datapath_feat = datapath_prefix_feat
+        # scenes without fused features are dropped (feature_loader.py:41-61)
+        if "nuscenes" in self.dataset_name:
+            self.list_occur = None
+        else:
+            occ = [len(glob(join(self.datapath_feat, self._scene_name(p) + "_*.pt"))) for p in self.data_paths]
+            keep = [i for i, n in enumerate(occ) if n != 0]
+            self.data_paths = [self.data_paths[i] for i in keep]
+            self.list_occur = [occ[i] for i in keep]
+        if len(self.data_paths) == 0:
+            raise Exception("0 file is loaded in the feature loader.")
+
+    def _scene_name(self, path):
+        return path[:-15].split("/")[-1] if "scannet" in self.dataset_name else path[:-4].split("/")[-1]
+
+    def __len__(self):
+        return len(self.data_paths) * self.loop
+
+    @staticmethod
+    def _rows_of_masked(mask_chunk, vox_ind):
+        """Row in `feat` (one row per True of mask_chunk, in order) of every voxel-representative point
+        that is inside the chunk (feature_loader.py:147-160)."""
+        rep_in_chunk = vox_ind[mask_chunk[vox_ind]]
+        rank = torch.cumsum(mask_chunk.to(torch.int64), dim=0) - 1
+        return rank[rep_in_chunk]
+
+    def __getitem__(self, index_long):
+        index = index_long % len(self.data_paths)
+        locs_in, feats_in, labels_in = torch.load(self.data_paths[index], weights_only=False)
+        labels_in[labels_in == -100] = 255
+        labels_in = labels_in.astype(np.uint8)
+        feats_in = np.zeros_like(locs_in) if (np.isscalar(feats_in) and feats_in == 0) else (feats_in + 1.0) * 127.5
+        scene_name = self.data_paths[index][:-15].split("/")[-1] if self.dataset_name == "scannet_3d" \
+            else self.data_paths[index][:-4].split("/")[-1]
+        if "nuscenes" not in self.dataset_name:
+            n_occur = self.list_occur[index]
+            if n_occur < 1:
+                raise NotImplementedError
+            nn_occur = np.random.randint(n_occur) if n_occur > 1 else 0
+            processed = torch.load(join(self.datapath_feat, scene_name + "_%d.pt" % nn_occur), weights_only=False)
+        else:
+            processed = torch.load(join(self.datapath_feat, scene_name + ".pt"), weights_only=False)
+
+        two_key = len(processed.keys()) == 2
+        if two_key:
+            feat_3d, mask_chunk = processed["feat"], processed["mask_full"]
+            if isinstance(mask_chunk, np.ndarray):
+                mask_chunk = torch.from_numpy(mask_chunk)
+            mask = copy.deepcopy(mask_chunk)
+            if self.split != "train":                         # evaluation: scatter to all points, keep every point
+                full = torch.zeros((locs_in.shape[0], feat_3d.shape[1]), dtype=feat_3d.dtype)
+                full[mask] = feat_3d
+                feat_3d, mask_chunk = full, torch.ones_like(mask_chunk)
+        else:
+            feat_3d, mask_visible, mask_chunk = processed["feat"], processed["mask"], processed["mask_full"]
+            mask = torch.zeros(feat_3d.shape[0], dtype=torch.bool)
+            mask[mask_visible] = True
+        if feat_3d.dim() > 2:
+            feat_3d = feat_3d[..., 0]
+
+        if self.split == "train":
+            if not two_key:
+                feat_3d = feat_3d[mask]
+                mask_chunk[mask_chunk.clone()] = mask
+            locs, feats, labels, inds_reconstruct, vox_ind = self.voxelizer.voxelize(locs_in, feats_in, labels_in,
+                                                                                     return_ind=True)
+            vox_ind = torch.from_numpy(vox_ind)
+            mask = mask_chunk[vox_ind]
+            feat_3d = feat_3d[self._rows_of_masked(mask_chunk, vox_ind)]
+        else:
+            mc = mask_chunk.numpy().astype(bool)
+            locs, feats, labels, inds_reconstruct, vox_ind = self.voxelizer.voxelize(locs_in[mc], feats_in[mc],
+                                                                                     labels_in[mc], return_ind=True)
+            vox_ind = torch.from_numpy(vox_ind)
+            feat_3d = feat_3d[vox_ind]
+            mask = mask[vox_ind]
+
+        if self.eval_all:
+            labels = labels_in
+        coords = torch.from_numpy(locs).int()
+        coords = torch.cat((torch.ones(coords.shape[0], 1, dtype=torch.int), coords), dim=1)
+        feats = torch.from_numpy(feats).float() / 127.5 - 1.0 if self.input_color else torch.ones(coords.shape[0], 3)
+        labels = torch.from_numpy(labels).long()
+        if self.eval_all:
+            return coords, feats, labels, feat_3d, mask, torch.from_numpy(inds_reconstruct).long()
+        return coords, feats, labels, feat_3d, mask
+
+
+def collation_fn(batch):
+    """feature_loader.py:221-234 (note: column 0 is MULTIPLIED by the batch index, as in the reference)."""
+    coords, feats, labels, feat_3d, mask_chunk = list(zip(*batch))
+    for i in range(len(coords)):
+        coords[i][:, 0] *= i
+    return torch.cat(coords), torch.cat(feats), torch.cat(labels), torch.cat(feat_3d), torch.cat(mask_chunk)
+
+
+def collation_fn_eval_all(batch):
+    """feature_loader.py:237-255."""
+    coords, feats, labels, feat_3d, mask, inds_recons = list(zip(*batch))
+    inds_recons = list(inds_recons)
+    acc = 0
+    for i in range(len(coords)):
+        coords[i][:, 0] *= i
+        inds_recons[i] = acc + inds_recons[i]
+        acc += coords[i].shape[0]
+    return (torch.cat(coords), torch.cat(feats), torch.cat(labels), torch.cat(feat_3d), torch.cat(mask),
+            torch.cat(inds_recons))

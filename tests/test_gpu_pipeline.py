@@ -111,3 +111,91 @@ def test_dense_lift_config(env):
     hp = pl.HotPath(pl.StudentWeights(sd, "cuda"), cfg.mask_shape, K=16, num_iters=2, device="cuda")
     res = hp.evaluate_scene(batch, pl.DenseFeatureVLM(feat, text, 14.0, "cuda"))
     assert (res["scene_features"].cpu() - ref["scene_features"]).abs().max() < 1e-4
+
+
+def test_validation_driver_two_scenes(tmp_path):
+    """the evaluation driver end to end on two tiny synthetic scenes; counts vs the oracle per scene"""
+    import os
+    from geopurify_amd import validation, pipeline as pl, synthetic as syn
+    from geopurify_amd.affinity_module import SonataXAffinityTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = validation.get_parser(["--config", os.path.join(root, "config", "geopurify_synthetic_scannet.yaml"),
+                                  "save_path", str(tmp_path / "o"), "synthetic_config", "T", "num_scenes", "2",
+                                  "mask_shape", "[120, 160]", "pool_iters", "3"])
+    cfg = syn.CONFIGS["T"]
+    model = SonataXAffinityTrainer(args, None, None, device="cuda", use_lseg=False, feature_dim=cfg.feat_dim,
+                                   embed_dim=128, hidden_dim=128)
+    model.K, model.num_pool_iters = 24, 3
+    sd = model.affinity_student.state_dict()
+    hp = model._hot_path()
+    state, total = {}, np.zeros((3, 19), np.int64)
+    scenes = []
+    for sid in (0, 1):
+        seed = 5557 + sid
+        scene = syn.make_scene(cfg, seed)
+        vlm_np = syn.make_vlm_outputs(cfg, cfg.num_views, seed)
+        rigid = pl.scene_rigid_transform(cfg.voxel_size, seed)
+        ref = o_pipe.evaluate_scene_oracle(scene, vlm_np, sd, rigid, K=24, num_iters=3)
+        _, (ri, ru, rt) = o_pipe.classify_and_count(ref, scene.labels, 19, [19, 20])
+        total += np.stack([ri, ru + ri - rt, rt])
+
+        def provider(scene=scene, vlm_np=vlm_np, rigid=rigid):
+            state["vlm"] = pl.SyntheticVLM(vlm_np, "cuda")
+            return pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+        scenes.append((f"scannet_synthetic_{sid:04d}", provider))
+
+    def evaluate(batch, sid):
+        model.vlm = state["vlm"]
+        return model.evaluate_scene(batch, vis_prefix=sid)
+
+    (base, novel), counts = validation.validate(scenes, evaluate, args, hp)
+    c = counts.cpu().numpy()
+    assert np.array_equal(c[2], total[2])                              # target histogram exact
+    assert np.abs(c[0] - total[0]).sum() <= 0.01 * total[0].sum() + 5  # predictions agree up to arg-max near-ties
+    assert 0.0 <= base <= 1.0 and 0.0 <= novel <= 1.0
+
+
+def test_fused_feature_loader_on_disk_formats(tmp_path):
+    """dataset.feature_loader surface: .pth scene + fused-feature .pt (2-key and 3-key forms), eval and train
+    splits, checked against the oracle voxelizer run with the same seed."""
+    import os
+    from geopurify_amd.feature_loader import FusedFeatureLoader, collation_fn_eval_all
+    from oracle import voxelize as o_vox
+    rng = np.random.default_rng(21)
+    for split in ("val", "train"):
+        d3 = tmp_path / f"root_{split}" / "scannet_3d"      # dataset_name must be exactly "scannet_3d" (feature_loader.py:92)
+        os.makedirs(d3 / split)
+        os.makedirs(tmp_path / f"feat_{split}")
+        N, D = 5000, 16
+        locs = rng.uniform(0, 2.5, size=(N, 3)).astype(np.float32)
+        locs[:, 2] *= 0.05
+        cols = rng.uniform(-1, 1, size=(N, 3)).astype(np.float32)
+        labs = rng.integers(0, 20, size=N).astype(np.float64)
+        labs[:50] = -100
+        torch.save((locs, cols, labs), d3 / split / "scene0001_00_vh_clean_2.pth")
+        mask_full = torch.from_numpy(rng.random(N) < 0.6)
+        feat = torch.randn(int(mask_full.sum()), D)
+        torch.save({"feat": feat, "mask_full": mask_full}, tmp_path / f"feat_{split}" / "scene0001_00_0.pt")
+        ds = FusedFeatureLoader(str(d3), str(tmp_path / f"feat_{split}"), voxel_size=0.05, split=split, eval_all=True,
+                                input_color=True)
+        np.random.seed(3)
+        coords, feats, labels, feat_3d, mask, inv = ds[0]
+        # oracle with the same RNG stream
+        np.random.seed(3)
+        M_v, M_r = o_vox.get_transformation_matrix(0.05, True)
+        c, inds, oinv, _ = o_vox.voxelize_with_matrices(locs.astype(np.float64), M_v, M_r, True)
+        assert torch.equal(coords[:, 1:], torch.from_numpy(c).int()) and (coords[:, 0] == 1).all()
+        assert torch.equal(inv, torch.from_numpy(oinv))
+        assert torch.allclose(feats, torch.from_numpy(((cols + 1.0) * 127.5)[inds]).float() / 127.5 - 1.0)
+        full = torch.zeros(N, D)
+        full[mask_full] = feat
+        if split == "val":
+            assert torch.equal(feat_3d, full[torch.from_numpy(inds)]) and torch.equal(mask, mask_full[torch.from_numpy(inds)])
+        else:
+            rep = torch.from_numpy(inds)
+            assert torch.equal(mask, mask_full[rep]) and torch.equal(feat_3d, full[rep[mask_full[rep]]])
+        assert labels.shape[0] == N and int((labels == 255).sum()) == 50       # eval_all returns the per-point labels
+        b = collation_fn_eval_all([(coords.clone(), feats, labels, feat_3d, mask, inv.clone()),
+                                   (coords.clone(), feats, labels, feat_3d, mask, inv.clone())])
+        assert (b[0][:coords.shape[0], 0] == 0).all() and (b[0][coords.shape[0]:, 0] == 1).all()
+        assert int(b[5][N:].min()) == coords.shape[0]

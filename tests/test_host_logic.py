@@ -87,3 +87,18 @@ def test_synthetic_scene_shapes():
     H, W = cfg.mask_shape
     assert v["pred_masks"].shape == (2, cfg.num_queries, ((H + 31) // 32) * 8, ((W + 31) // 32) * 8)
     assert v["pred_logits"].shape == (2, cfg.num_queries, cfg.num_classes + 1)
+
+
+def test_validation_driver_cli_and_dataset_name(tmp_path):
+    from geopurify_amd import validation
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = validation.get_parser(["--config", os.path.join(root, "config", "geopurify_synthetic_scannet.yaml"),
+                                 "--split_idx", "1", "--split_total", "4", "save_path", str(tmp_path / "o"),
+                                 "num_scenes", "5", "voxel_size", "0.05"])
+    assert cfg.split_idx == 1 and cfg.split_total == 4 and cfg.num_scenes == 5 and cfg.voxel_size == 0.05
+    assert cfg.test_classes == 19 and len(cfg.all_label) == 19 and cfg.category_split.ignore_category == [19, 20]
+    assert os.path.isdir(tmp_path / "o" / "result" / "best")
+    assert validation.get_dataset_name("data/ScanNet_3d") == "scannet"
+    assert validation.get_dataset_name("/x/matterport_3d_160") == "matterport"
+    with pytest.raises(ValueError):
+        validation.get_dataset_name("data/nuscenes")
