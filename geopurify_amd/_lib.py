@@ -39,7 +39,7 @@ SIGNATURES = {
     "gp_split_f16": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P]),
     "gp_sparse_conv_f16x3": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_int32, c_int64, c_int64, c_int32, _P, _P,
                                        c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P,
-                                       c_int64, _P]),
+                                       c_int64, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), _P]),
     "gp_l2norm_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P]),
     "gp_knn_workspace_bytes": (c_size_t, [c_int64]),
     "gp_knn_lattice": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(NT2)
 conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
                    const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, int nseg, int kv,
                    const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
-                   float *__restrict__ P, int n_tiles, int ablate) {
+                   float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -142,7 +142,9 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     const int64_t nb = gridDim.x, per_xcd = nb >> 3;
     const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int nt = (int)(lb % n_tiles);
-    const int mt = (int)(lb / n_tiles);
+    const int mt_local = (int)(lb / n_tiles);
+    if (mt_local >= tile_count) return;
+    const int mt = tile_begin + mt_local;
     if (mt >= tile_start[nseg]) return;
     int lo_s = 0, hi_s = nseg;                                  // segment with tile_start[s] <= mt < tile_start[s+1]
     while (hi_s - lo_s > 1) {
@@ -222,7 +224,7 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
             for (int r = 0; r < 4; ++r) {
                 int row = wm * 64 + i * 16 + fq * 4 + r;
                 if (row < cnt) {
-                    float *dst = P + (int64_t)(base + row) * cout + n0 + wn * 128 + fl;
+                    float *dst = P + (int64_t)(base - pair_base + row) * cout + n0 + wn * 128 + fl;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dst[j * 16] = acc[i][j][r];
                 }
@@ -248,7 +250,7 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
                        const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
                        const int32_t *__restrict__ tile_start, int nseg, int kv,
                        const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
-                       float *__restrict__ P, int n_tiles, int ablate) {
+                       float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -257,7 +259,9 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
     const int64_t nb = gridDim.x, per_xcd = nb >> 3;
     const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int nt = (int)(lb % n_tiles);
-    const int mt = (int)(lb / n_tiles);
+    const int mt_local = (int)(lb / n_tiles);
+    if (mt_local >= tile_count) return;
+    const int mt = tile_begin + mt_local;
     if (mt >= tile_start[nseg]) return;
     int lo_s = 0, hi_s = nseg;                                  // segment with tile_start[s] <= mt < tile_start[s+1]
     while (hi_s - lo_s > 1) {
@@ -334,7 +338,7 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
                 int grow = wm * 64 + i * 16 + row;
                 if (grow < cnt) {
                     float4 v = *reinterpret_cast<const float4 *>(st + row * EP + c4 * 4);
-                    *reinterpret_cast<float4 *>(P + (int64_t)(base + grow) * cout + n0 + wn * 128 + c4 * 4) = v;
+                    *reinterpret_cast<float4 *>(P + (int64_t)(base - pair_base + grow) * cout + n0 + wn * 128 + c4 * 4) = v;
                 }
             }
             gp_wave_sync();
@@ -347,8 +351,11 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
                                    int cout, const float *__restrict__ scale, const float *__restrict__ shift,
                                    const float *__restrict__ residual, int64_t ld_res, int relu,
                                    float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ y_hi,
-                                   _Float16 *__restrict__ y_lo, int64_t ld_yh) {
+                                   _Float16 *__restrict__ y_lo, int64_t ld_yh, int64_t row_begin, int64_t row_count,
+                                   int pair_base) {
     int64_t u = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (u >= row_count) return;
+    u += row_begin;
     if (u >= nv) return;
     int lane = gp_lane();
     int mypos = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
@@ -357,7 +364,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
         for (int k = 0; k < kv; ++k) {
             int pos = __shfl(mypos, k, 64);
             if (pos >= 0) {
-                float4 t = *reinterpret_cast<const float4 *>(P + (int64_t)pos * cout + c);
+                float4 t = *reinterpret_cast<const float4 *>(P + (int64_t)(pos - pair_base) * cout + c);
                 a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
             }
         }
@@ -482,7 +489,8 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                                     const float *scale, const float *shift, const float *residual, int64_t ld_res,
                                     int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
-                                    void *stream_) {
+                                    int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
+                                    const int32_t *chunk_pair_off_host, void *stream_) {
     GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && nseg > 0 && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
     GP_CHECK_ARG(!x_hi || (ld_xh % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0), "gp_sparse_conv_f16x3: pre-split rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (y_lo && ld_yh % 4 == 0), "gp_sparse_conv_f16x3: y_hi/y_lo come as a pair");
@@ -500,21 +508,35 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_CHECK_ARG(cout % TN == 0, "gp_sparse_conv_f16x3: cout=%d must be a multiple of %d on this path", cout, TN);
     hipStream_t s = gp_stream(stream_);
     int n_tiles = cout / TN;
-    int64_t m_tiles_ub = num_pairs / TM + nseg;
-    int64_t nblocks = ((m_tiles_ub * n_tiles + 7) / 8) * 8;
-    if (x_hi && !(g_conv_ablate & 16))
-        conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
-            static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, nseg, kv,
-            static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate);
-    else {
-        GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
-        conv_phase1_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
-            x, ld_x, pair_in, pair_off, tile_start, nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout,
-            partial, n_tiles, g_conv_ablate);
+    // Chunked execution: phase 1 and phase 2 alternate over chunks of output rows so that the partial
+    // rows of a chunk (written by phase 1, read once by phase 2) stay in the 256 MiB Infinity Cache instead
+    // of making an HBM round trip; `partial` then only needs room for the largest chunk.
+    const bool chunked = num_chunks > 1 && chunk_tile_off_host && chunk_pair_off_host;
+    const int nchunk = chunked ? num_chunks : 1;
+    for (int c = 0; c < nchunk; ++c) {
+        int tile_begin = chunked ? chunk_tile_off_host[c] : 0;
+        int tile_count = chunked ? chunk_tile_off_host[c + 1] - tile_begin : (int)(num_pairs / TM + nseg);
+        int pair_base = chunked ? chunk_pair_off_host[c] : 0;
+        int64_t row_begin = chunked ? (int64_t)c * chunk_rows : 0;
+        int64_t row_count = chunked ? ((row_begin + chunk_rows < nv) ? chunk_rows : nv - row_begin) : nv;
+        if (tile_count > 0) {
+            int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
+            if (x_hi && !(g_conv_ablate & 16))
+                conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
+                    static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, nseg, kv,
+                    static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate,
+                    tile_begin, tile_count, pair_base);
+            else {
+                GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
+                conv_phase1_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
+                    x, ld_x, pair_in, pair_off, tile_start, nseg, kv, static_cast<const _Float16 *>(w_hi),
+                    static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate, tile_begin, tile_count, pair_base);
+            }
+        }
+        conv_phase2_kernel<<<(unsigned)((row_count * 64 + 255) / 256), 256, 0, s>>>(
+            partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
+            static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base);
     }
-    conv_phase2_kernel<<<(unsigned)((nv * 64 + 255) / 256), 256, 0, s>>>(partial, pair_pos, nv, kv, cout, scale, shift, residual,
-                                                                        ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
-                                                                        static_cast<_Float16 *>(y_lo), ld_yh);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -179,12 +179,14 @@ class ConvPairs:
         self.pair_in, self.pair_pos, self.pair_off, self.tile_start = pair_in, pair_pos, seg_off, tile_start
         self.nseg, self.num_pairs, self.nv = nseg, num_pairs, nv
         self.partial = None
+        self.chunk_rows, self.num_chunks, self.chunk_tile_off, self.chunk_pair_off = 0, 1, None, None
 
 
-def conv_pairs_build(nbr_map, chunk_rows=None):
+def conv_pairs_build(nbr_map, chunk_rows=16384):
     """nbr_map i32 [27,nv] -> ConvPairs.  One host sync (number of pairs, to size the partial buffer).
-    chunk_rows: optional chunk-major pair order (measured slower than plain offset-major on MI355X:
-    2.36 vs 2.04 ms per 512->512 layer at chunk 2048; default = one chunk)."""
+    chunk_rows: pairs are ordered chunk-major and phase 1 / phase 2 run chunk by chunk, so the partial
+    buffer only holds one chunk (62k..245k pairs instead of ~1M per 134k voxels).  Speed is flat from 8192
+    rows up (2.06 ms per 512->512 layer); 2048-row chunks cost 15 % (more partial tiles).  None = one chunk."""
     lib = _lib.load()
     kv, nv = nbr_map.shape
     dev = nbr_map.device
@@ -198,8 +200,18 @@ def conv_pairs_build(nbr_map, chunk_rows=None):
     tile_start = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     check(lib.gp_conv_pairs_build(_ptr(nbr_map), nv, kv, chunk_rows, _ptr(pair_in), _ptr(pair_pos), _ptr(seg_off),
                                   _ptr(tile_start), _ptr(ws), ws.numel(), _stream()), "gp_conv_pairs_build")
-    num_pairs = int(seg_off[nseg].item())
-    return ConvPairs(pair_in, pair_pos, seg_off, tile_start, nseg, num_pairs, nv)
+    nchunks = nseg // kv
+    bounds = torch.stack([seg_off[::kv], tile_start[::kv]]).cpu().tolist()     # the one host sync of this call
+    num_pairs = bounds[0][-1]
+    cp = ConvPairs(pair_in, pair_pos, seg_off, tile_start, nseg, num_pairs, nv)
+    if nchunks > 1:
+        cp.chunk_rows, cp.num_chunks = chunk_rows, nchunks
+        cp.chunk_pair_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[0])
+        cp.chunk_tile_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[1])
+        cp.max_chunk_pairs = max(bounds[0][i + 1] - bounds[0][i] for i in range(nchunks))
+    else:
+        cp.max_chunk_pairs = num_pairs
+    return cp
 
 
 def conv_weights_split(w, scale_pow2):
@@ -233,7 +245,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     nv = pairs.nv
     dev = w_hi.device
     if pairs.partial is None or pairs.partial.shape[1] < cout:
-        pairs.partial = torch.empty((pairs.num_pairs, cout), dtype=torch.float32, device=dev)
+        pairs.partial = torch.empty((max(pairs.max_chunk_pairs, 1), cout), dtype=torch.float32, device=dev)
     if out is None:
         out = torch.empty((nv, cout), dtype=torch.float32, device=dev)
     xh, xl = x_split if x_split is not None else (None, None)
@@ -243,7 +255,9 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    _ptr(pairs.pair_off), _ptr(pairs.tile_start), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
                                    _ptr(pairs.partial), _ptr(scale), _ptr(shift), _ptr(residual),
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
-                                   out.stride(0), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0, _stream()),
+                                   out.stride(0), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
+                                   int(pairs.chunk_rows), int(pairs.num_chunks), pairs.chunk_tile_off, pairs.chunk_pair_off,
+                                   _stream()),
           "gp_sparse_conv_f16x3")
     return out
 

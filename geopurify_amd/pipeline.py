@@ -267,8 +267,14 @@ class HotPath:
         text_norm = torch.nn.functional.normalize(vlm.text_embed, dim=-1).contiguous()
         Q, D = vlm.mask_embed.shape[1:]
         C = text_norm.shape[0]
-        f_seg = torch.empty((max(V, 1), Q, D), dtype=torch.float32, device=dev)
-        l_seg = torch.empty((max(V, 1), Q, C), dtype=torch.float32, device=dev)
+        # per-(view, segment) tables for ALL source views in one launch when the VLM outputs are batched
+        batched = hasattr(vlm, "mask_embed") and vlm.mask_embed.dim() == 3 and vlm.mask_embed.is_contiguous()
+        n_tab = vlm.mask_embed.shape[0] if batched else max(V, 1)
+        f_seg = torch.empty((n_tab, Q, D), dtype=torch.float32, device=dev)
+        l_seg = torch.empty((n_tab, Q, C), dtype=torch.float32, device=dev)
+        if batched:
+            ops.segment_tables(vlm.mask_embed.view(n_tab * Q, D), text_norm, vlm.logit_scale,
+                               f_seg.view(n_tab * Q, D), l_seg.view(n_tab * Q, C))
         cnt = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         segs = []
         ws_m = ws_n = None
@@ -287,7 +293,8 @@ class HotPath:
             covered = (seg >= 0).to(torch.uint8)
             nn = ops.nn1_masked(xyz, covered, 1 - covered, workspace=ws_n)
             seg = torch.where(nn >= 0, seg[nn.clamp(min=0)], seg)
-            ops.segment_tables(out["mask_embed"].contiguous(), text_norm, out["logit_scale"], f_seg[i], l_seg[i])
+            if not batched:
+                ops.segment_tables(out["mask_embed"].contiguous(), text_norm, out["logit_scale"], f_seg[i], l_seg[i])
             ops.pv_count(v.pt, cnt)
             segs.append(seg)
         start = ops.exclusive_scan_i64(cnt)
@@ -296,7 +303,7 @@ class HotPath:
         pvv = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         pvs = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         for i, v in enumerate(batch.views):
-            ops.pv_fill(v.pt, segs[i], i, start, cursor, pvv, pvs)
+            ops.pv_fill(v.pt, segs[i], v.src_view if batched else i, start, cursor, pvv, pvs)
         F = torch.empty((N, D), dtype=torch.float32, device=dev)
         seen = ops.fuse_views_top3(start, pvv, pvs, N, f_seg, l_seg, F)
         # scene-level fill of never-seen points (:687-696)

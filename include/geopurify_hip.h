@@ -132,7 +132,11 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                          const float *scale, const float *shift, const float *residual, int64_t ld_res,
                          int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
-                         void *stream);
+                         int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
+                         const int32_t *chunk_pair_off_host, void *stream);
+/* Chunked execution (num_chunks > 1, pairs built with the same chunk_rows): phase 1 / phase 2 alternate  */
+/* per chunk so that `partial` (then sized for the largest chunk) stays in the Infinity Cache;             */
+/* chunk_tile_off_host / chunk_pair_off_host = tile_start / seg_off at the chunk boundaries [num_chunks+1]. */
 /* in-place row L2 normalisation, F.normalize(p=2, dim=1, eps=1e-12) (affinity_module.py:1547)     */
 int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
 

@@ -20,8 +20,9 @@ cs = coords[perm.long()].contiguous()
 grid = ops.grid_build(cs)
 nm = ops.kernel_map_build(grid, cs)
 import sys as _s
-CHUNK = int(os.environ.get('GP_CHUNK', '1073741824'))
-pairs = ops.conv_pairs_build(nm, CHUNK)
+CHUNK = int(os.environ.get('GP_CHUNK', '0'))
+pairs = ops.conv_pairs_build(nm, CHUNK if CHUNK > 0 else None)
+print('chunks', pairs.num_chunks, 'max chunk pairs', pairs.max_chunk_pairs, flush=True)
 Nv = cs.shape[0]
 print("Nv", Nv, "pairs", pairs.num_pairs, flush=True)
 X = torch.randn(Nv, 512, device="cuda")

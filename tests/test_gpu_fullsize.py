@@ -1,0 +1,174 @@
+"""Full-size (BASELINE config S: 150k points, ~130k voxels, K=96, D=512) checks through size-independent
+properties -- sortedness, first-occurrence, row-stochasticity, constant preservation, linearity, checksums,
+agreement between independent kernels -- plus the edge cases of the domain (dropped views, tiny inputs,
+invalid arguments).  The oracle cannot run at this size in seconds; these properties can."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dataclasses
+    from geopurify_amd import ops, pipeline as pl, synthetic as syn
+    cfg = dataclasses.replace(syn.CONFIGS["S"], num_views=3)
+    scene = syn.make_scene(cfg, 4242)
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, 4242)
+    coords = torch.from_numpy(scene.coords).cuda()
+    vox = ops.voxelize(coords, rigid)
+    ci = vox["coords_aug"].to(torch.int32).contiguous()
+    perm, rank = ops.morton_order(ci)
+    cs = ci[perm.long()].contiguous()
+    grid = ops.grid_build(cs)
+    nbr = ops.knn_lattice(grid, cs, perm, 96)
+    torch.manual_seed(0)
+    E = torch.nn.functional.normalize(torch.randn(cs.shape[0], 128, device="cuda"), dim=1)
+    w = ops.affinity_softmax(E, nbr, 20.0)
+    return dict(ops=ops, pl=pl, syn=syn, cfg=cfg, scene=scene, rigid=rigid, coords=coords, vox=vox, cs=cs, perm=perm,
+                rank=rank, grid=grid, nbr=nbr, w=w, E=E)
+
+
+def test_voxelizer_properties_full_size(big):
+    ops, vox, coords, rigid = big["ops"], big["vox"], big["coords"], big["rigid"]
+    N, nv = coords.shape[0], vox["nv"]
+    assert 0.7 * N < nv < N
+    h = ops.fnv_hash(vox["coords_aug"].contiguous()).cpu().numpy().view(np.uint64)
+    assert (h[1:] > h[:-1]).all()                                     # ascending hash, no duplicate voxels
+    inv, inds = vox["inds_reconstruct"], vox["inds"]
+    assert int(inv.min()) == 0 and int(inv.max()) == nv - 1
+    assert torch.equal(inv[inds], torch.arange(nv, device="cuda"))   # representative maps to its own voxel
+    first = torch.full((nv,), N, dtype=torch.int64, device="cuda").scatter_reduce(0, inv, torch.arange(N, device="cuda"), "amin")
+    assert torch.equal(first, inds)                                   # inds = FIRST point of every voxel
+    homo = torch.cat([coords, torch.ones(N, 1, dtype=torch.float64, device="cuda")], 1)
+    c = torch.floor(homo @ torch.from_numpy(rigid).cuda().T[:, :3])
+    c = c - c.amin(0)
+    # fp64 matmul order may differ in the last ulp: allow a floor flip on a vanishing fraction of points
+    same = (vox["coords_aug"][inv] == c).all(1)
+    assert same.float().mean() > 0.99999
+    seg = vox["seg_start"]
+    assert int(seg[0]) == 0 and int(seg[-1]) == N and (seg[1:] > seg[:-1]).all()
+
+
+def test_knn_properties_full_size(big):
+    cs, nbr, perm = big["cs"].long(), big["nbr"].long(), big["perm"].long()
+    Nv, K = nbr.shape
+    assert int(nbr.min()) >= 0 and int(nbr.max()) < Nv
+    assert (nbr != torch.arange(Nv, device="cuda")[:, None]).all()               # self dropped
+    d2 = ((cs[nbr] - cs[:, None, :]) ** 2).sum(-1)
+    key = d2 * (1 << 20) + perm[nbr]
+    assert (key[:, 1:] > key[:, :-1]).all()                                         # strictly (d2, id) ascending => distinct
+    # exactness against random non-neighbours: none may beat the K-th neighbour
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rows = torch.randint(0, Nv, (4000,), device="cuda", generator=g)
+    cand = torch.randint(0, Nv, (4000, 512), device="cuda", generator=g)
+    dc = ((cs[cand] - cs[rows][:, None, :]) ** 2).sum(-1)
+    kc = dc * (1 << 20) + perm[cand]
+    is_nb = (cand[:, :, None] == nbr[rows][:, None, :]).any(-1) | (cand == rows[:, None])
+    assert (kc[~is_nb] > key[rows][:, -1:].expand(-1, 512)[~is_nb]).all()
+    # local exactness: the 6 lattice neighbours, when they exist, are always among the 96
+    nm = big["ops"].kernel_map_build(big["grid"], big["cs"])
+    for k in (4, 10, 12, 14, 16, 22):                                               # face neighbours
+        m = nm[k].long()
+        has = m >= 0
+        assert (nbr[has] == m[has][:, None]).any(1).all()
+
+
+def test_affinity_rows_are_stochastic(big):
+    w = big["w"]
+    assert (w >= 0).all() and (w.sum(1) - 1).abs().max() < 1e-5
+
+
+def test_pooling_properties_full_size(big):
+    ops, nbr, w = big["ops"], big["nbr"], big["w"]
+    Nv, D = nbr.shape[0], 512
+    tiles = ops.pool_tiles_build(nbr, w, 8)
+    blocks = ops.pool_blocks_build(tiles)
+    X = torch.randn(Nv, 544, device="cuda")
+    Y = torch.randn(Nv, 544, device="cuda")
+    def P(z, mode):
+        out = torch.empty(Nv, D, device="cuda")
+        if mode == "ell":
+            ops.pool_ell(z, nbr, w, D, out)
+        elif mode == "tiles":
+            ops.pool_tiles_apply(z, tiles, D, out)
+        else:
+            ops.pool_blocks_apply(z, blocks, D, out)
+        return out
+    ones = torch.ones(Nv, 544, device="cuda")
+    for mode in ("ell", "tiles") + (("blocks",) if blocks.ok else ()):
+        assert (P(ones, mode) - 1).abs().max() < 1e-5                                # A 1 = 1
+        lin = P((2.0 * X - 0.5 * Y).contiguous(), mode) - (2.0 * P(X, mode) - 0.5 * P(Y, mode))
+        assert lin.abs().max() < 1e-4                                                 # linearity
+        px = P(X, mode)
+        assert (px.amax(0) <= X[:, :D].amax(0) + 1e-5).all() and (px.amin(0) >= X[:, :D].amin(0) - 1e-5).all()   # convexity
+    assert (P(X, "tiles") - P(X, "ell")).abs().max() < 1e-5                          # independent kernels agree
+    if blocks.ok:
+        assert (P(X, "blocks") - P(X, "ell")).abs().max() < 1e-5
+
+
+def test_conv_paths_agree_full_size(big):
+    ops = big["ops"]
+    nm = ops.kernel_map_build(big["grid"], big["cs"])
+    pairs = ops.conv_pairs_build(nm)
+    assert pairs.num_chunks > 1
+    Nv = big["cs"].shape[0]
+    assert pairs.num_pairs == int((nm >= 0).sum())
+    assert (nm[13] == torch.arange(Nv, device="cuda")).all()                         # centre offset = identity
+    for k in (0, 7, 20):                                                             # map symmetry
+        u = torch.where(nm[k] >= 0)[0]
+        assert (nm[26 - k][nm[k][u].long()] == u).all()
+    torch.manual_seed(1)
+    X = torch.randn(Nv, 256, device="cuda")
+    W = torch.randn(27, 256, 256, device="cuda") * 0.02
+    hi, lo = ops.conv_weights_split(W, 32.0)
+    sc = torch.full((256,), 1 / 32.0, device="cuda")
+    a = ops.sparse_conv_f16x3(X, pairs, hi, lo, sc, None)
+    b = ops.sparse_conv(X, nm, W)
+    assert (a - b).abs().max() < 2e-5 * max(1.0, float(b.abs().max()))               # f16x3 == exact fp32 MFMA
+    xs = ops.split_f16(X)
+    c = ops.sparse_conv_f16x3(None, pairs, hi, lo, sc, None, x_split=xs)
+    assert torch.equal(a, c)                                                          # register path == LDS-DMA path
+    one = ops.conv_pairs_build(nm, None)
+    d = ops.sparse_conv_f16x3(X, one, hi, lo, sc, None)
+    assert torch.equal(a, d)                                                          # chunked == unchunked
+
+
+def test_mean_gather_checksum_full_size(big):
+    ops, vox = big["ops"], big["vox"]
+    N, nv = big["coords"].shape[0], vox["nv"]
+    F = torch.randn(N, 512, device="cuda")
+    out = torch.zeros(nv, 512, device="cuda")
+    ops.scatter_mean_csr(F, 512, vox["order"], vox["seg_start"], nv, out)
+    cnt = torch.diff(vox["seg_start"]).float()
+    assert ((out * cnt[:, None]).sum(0) - F.sum(0)).abs().max() < 0.05             # count-weighted checksum (fp32 sums of 150k terms)
+    g = ops.gather_rows(out, 512, vox["inds_reconstruct"])
+    assert torch.equal(g, out[vox["inds_reconstruct"]])
+
+
+def test_view_drop_and_edge_cases(big):
+    ops, pl, syn = big["ops"], big["pl"], big["syn"]
+    from geopurify_amd._lib import GeoPurifyHipError
+    import dataclasses
+    cfg = dataclasses.replace(syn.CONFIGS["T"], num_views=3)
+    scene = syn.make_scene(cfg, 9)
+    scene.views[1].depth[:] = 0.0                       # a view whose depth never matches: no visible point -> dropped
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), pl.scene_rigid_transform(cfg.voxel_size, 9), "cuda")
+    assert [v.src_view for v in batch.views] == [0, 2]
+    tup = batch.as_tuple()
+    assert tup[14].shape == (2 * cfg.num_points, 2) and int(tup[4][:, 0].max()) == 1      # view ids re-indexed after the drop
+    with pytest.raises(GeoPurifyHipError):
+        ops.voxelize(torch.zeros((0, 3), dtype=torch.float64, device="cuda"), np.eye(4))  # empty cloud rejected
+    c = torch.tensor([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=torch.int32, device="cuda")
+    perm, rank = ops.morton_order(c)
+    g = ops.grid_build(c[perm.long()].contiguous())
+    with pytest.raises(GeoPurifyHipError):
+        ops.knn_lattice(g, c[perm.long()].contiguous(), perm, 3)                          # needs more than K voxels
+    nb = ops.knn_lattice(g, c[perm.long()].contiguous(), perm, 2)
+    assert sorted(nb[0].tolist()) != [] and nb.shape == (3, 2)
+    huge = torch.tensor([[0, 0, 0], [40000, 0, 0]], dtype=torch.int32, device="cuda")
+    with pytest.raises(GeoPurifyHipError):
+        ops.grid_build(huge)                                                              # extent beyond 32768 -> GP_ERANGE
