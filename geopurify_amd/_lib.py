@@ -34,10 +34,10 @@ SIGNATURES = {
     "gp_sparse_conv": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P,
                                  c_int64, c_int32, _P, c_int64, _P]),
     "gp_conv_pairs_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "gp_conv_pairs_build": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gp_conv_pairs_build": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gp_conv_weights_split": (c_int32, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
     "gp_split_f16": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P]),
-    "gp_sparse_conv_f16x3": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_int32, c_int64, c_int64, c_int32, _P, _P,
+    "gp_sparse_conv_f16x3": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, c_int32, _P, _P,
                                        c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P,
                                        c_int64, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), _P]),
     "gp_l2norm_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P]),
@@ -53,6 +53,10 @@ SIGNATURES = {
     "gp_pool_blocks_count": (c_int32, [_P, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gp_pool_blocks_fill": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gp_pool_blocks_apply": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, _P]),
+    "gp_pool_mfma_workspace_bytes": (c_size_t, [c_int64]),
+    "gp_pool_mfma_count": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
+    "gp_pool_mfma_fill": (c_int32, [_P, _P, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P]),
+    "gp_pool_mfma_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P, _P, c_int64, _P, c_int64, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_lift_dense_finish": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "gp_lift_masks_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

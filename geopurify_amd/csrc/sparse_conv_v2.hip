@@ -73,6 +73,20 @@ __global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *
     if (u == (int64_t)c * ch) seg_off[c * kv + k] = s;           // first row of the (chunk, offset) segment
     if (i == total - 1) seg_off[(c + 1) * kv] = s + (in >= 0 ? 1 : 0);
 }
+// one descriptor per 256-pair tile: {offset k, first pair, pair count} -- a single 16-byte load in the
+// GEMM prologue instead of a dependent binary search over tile_start
+__global__ void tile_desc_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ tile_start, int nseg, int kv,
+                                 int4 *__restrict__ desc) {
+    int sgi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sgi >= nseg) return;
+    int t0 = tile_start[sgi], t1 = tile_start[sgi + 1];
+    int p0 = seg_off[sgi], p1 = seg_off[sgi + 1];
+    for (int t = t0; t < t1; ++t) {
+        int base = p0 + (t - t0) * TM;
+        desc[t] = make_int4(sgi % kv, base, min(TM, p1 - base), 0);
+    }
+}
+
 // tile_start[s] = number of TM-row tiles before segment s (serial scan over a few thousand segments)
 __global__ void tile_start_kernel(const int32_t *__restrict__ seg_off, int nseg, int32_t *__restrict__ tile_start) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -130,8 +144,8 @@ __device__ __forceinline__ void mma_step_f16x3(const V2Smem &sm, int buf, int wm
 // grid.x = (#m-tiles upper bound) * n_tiles ; tile -> offset k by a search in tile_off (device)
 __global__ void __launch_bounds__(NT2)
 conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
-                   const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, int nseg, int kv,
-                   const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
+                   const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc,
+                   int nseg, int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
                    float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
@@ -146,14 +160,8 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     if (mt_local >= tile_count) return;
     const int mt = tile_begin + mt_local;
     if (mt >= tile_start[nseg]) return;
-    int lo_s = 0, hi_s = nseg;                                  // segment with tile_start[s] <= mt < tile_start[s+1]
-    while (hi_s - lo_s > 1) {
-        int mid = (lo_s + hi_s) >> 1;
-        if (tile_start[mid] <= mt) lo_s = mid; else hi_s = mid;
-    }
-    const int k = lo_s % kv;
-    const int base = off[lo_s] + (mt - tile_start[lo_s]) * TM;
-    const int cnt = min(TM, off[lo_s + 1] - base);
+    const int4 td = tile_desc[mt];
+    const int k = td.x, base = td.y, cnt = td.z;
     const int n0 = nt * TN;
     // staging roles: A row = tid/2 (pair), half = tid%2 (16 channels); B col = tid/2, half = tid%2
     const int s_row = tid >> 1, s_half = tid & 1;
@@ -248,7 +256,7 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
 __global__ void __launch_bounds__(NT2)
 conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
                        const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
-                       const int32_t *__restrict__ tile_start, int nseg, int kv,
+                       const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
                        const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
                        float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -263,14 +271,8 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
     if (mt_local >= tile_count) return;
     const int mt = tile_begin + mt_local;
     if (mt >= tile_start[nseg]) return;
-    int lo_s = 0, hi_s = nseg;                                  // segment with tile_start[s] <= mt < tile_start[s+1]
-    while (hi_s - lo_s > 1) {
-        int mid = (lo_s + hi_s) >> 1;
-        if (tile_start[mid] <= mt) lo_s = mid; else hi_s = mid;
-    }
-    const int k = lo_s % kv;
-    const int base = off[lo_s] + (mt - tile_start[lo_s]) * TM;
-    const int cnt = min(TM, off[lo_s + 1] - base);
+    const int4 td = tile_desc[mt];
+    const int k = td.x, base = td.y, cnt = td.z;
     const int n0 = nt * TN;
     // DMA roles: wave wv stages rows [wv*32, wv*32+32) of each array, two instructions of 16 rows
     const int lrow = lane >> 2, lp = lane & 3;
@@ -443,9 +445,9 @@ extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {
 }
 
 extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t chunk_rows, int32_t *pair_in,
-                                   int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start, void *workspace,
-                                   size_t workspace_bytes, void *stream_) {
-    GP_CHECK_ARG(nbr_map && pair_in && pair_pos && seg_off && tile_start && workspace && nv > 0 && kv > 0, "gp_conv_pairs_build: null/empty argument");
+                                   int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start, int32_t *tile_desc,
+                                   void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(nbr_map && pair_in && pair_pos && seg_off && tile_start && tile_desc && workspace && nv > 0 && kv > 0, "gp_conv_pairs_build: null/empty argument");
     GP_CHECK_ARG((int64_t)kv * nv < (1ll << 31), "gp_conv_pairs_build: kernel map too large");
     GP_CHECK_ARG(chunk_rows >= TM, "gp_conv_pairs_build: chunk_rows=%d must be >= %d", chunk_rows, TM);
     int64_t total = (int64_t)kv * nv;
@@ -461,6 +463,7 @@ extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t k
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, f, sc, (int32_t)0, (size_t)total, rocprim::plus<int32_t>(), s));
     pair_emit_kernel<<<blocks, 256, 0, s>>>(nbr_map, sc, nv, kv, chunk_rows, pair_in, pair_pos, seg_off);
     tile_start_kernel<<<1, 64, 0, s>>>(seg_off, nseg, tile_start);
+    tile_desc_kernel<<<(nseg + 255) / 256, 256, 0, s>>>(seg_off, tile_start, nseg, kv, reinterpret_cast<int4 *>(tile_desc));
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -484,14 +487,14 @@ extern "C" int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, 
 
 extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
                                     const int32_t *pair_in, const int32_t *pair_pos,
-                                    const int32_t *pair_off, const int32_t *tile_start, int32_t nseg,
-                                    int64_t num_pairs, int64_t nv, int32_t kv,
+                                    const int32_t *pair_off, const int32_t *tile_start, const int32_t *tile_desc,
+                                    int32_t nseg, int64_t num_pairs, int64_t nv, int32_t kv,
                                     const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                                     const float *scale, const float *shift, const float *residual, int64_t ld_res,
                                     int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                                     int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
                                     const int32_t *chunk_pair_off_host, void *stream_) {
-    GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && nseg > 0 && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
+    GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && tile_desc && nseg > 0 && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
     GP_CHECK_ARG(!x_hi || (ld_xh % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0), "gp_sparse_conv_f16x3: pre-split rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (y_lo && ld_yh % 4 == 0), "gp_sparse_conv_f16x3: y_hi/y_lo come as a pair");
     GP_CHECK_ARG(nv > 0 && num_pairs > 0 && (kv == 27 || kv == 1), "gp_sparse_conv_f16x3: bad sizes");
@@ -523,13 +526,13 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
             if (x_hi && !(g_conv_ablate & 16))
                 conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
-                    static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, nseg, kv,
+                    static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv,
                     static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate,
                     tile_begin, tile_count, pair_base);
             else {
                 GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
                 conv_phase1_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
-                    x, ld_x, pair_in, pair_off, tile_start, nseg, kv, static_cast<const _Float16 *>(w_hi),
+                    x, ld_x, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi),
                     static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate, tile_begin, tile_count, pair_base);
             }
         }

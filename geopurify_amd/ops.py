@@ -198,12 +198,14 @@ def conv_pairs_build(nbr_map, chunk_rows=16384):
     pair_pos = torch.empty((kv, nv), dtype=torch.int32, device=dev)
     seg_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     tile_start = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    tile_desc = torch.empty(((kv * nv) // 256 + nseg + 1, 4), dtype=torch.int32, device=dev)
     check(lib.gp_conv_pairs_build(_ptr(nbr_map), nv, kv, chunk_rows, _ptr(pair_in), _ptr(pair_pos), _ptr(seg_off),
-                                  _ptr(tile_start), _ptr(ws), ws.numel(), _stream()), "gp_conv_pairs_build")
+                                  _ptr(tile_start), _ptr(tile_desc), _ptr(ws), ws.numel(), _stream()), "gp_conv_pairs_build")
     nchunks = nseg // kv
     bounds = torch.stack([seg_off[::kv], tile_start[::kv]]).cpu().tolist()     # the one host sync of this call
     num_pairs = bounds[0][-1]
     cp = ConvPairs(pair_in, pair_pos, seg_off, tile_start, nseg, num_pairs, nv)
+    cp.tile_desc = tile_desc
     if nchunks > 1:
         cp.chunk_rows, cp.num_chunks = chunk_rows, nchunks
         cp.chunk_pair_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[0])
@@ -252,7 +254,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     yh, yl = out_split if out_split is not None else (None, None)
     check(lib.gp_sparse_conv_f16x3(_ptr(x), x.stride(0) if x is not None else 0, _ptr(xh), _ptr(xl),
                                    xh.stride(0) if xh is not None else 0, _ptr(pairs.pair_in), _ptr(pairs.pair_pos),
-                                   _ptr(pairs.pair_off), _ptr(pairs.tile_start), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
+                                   _ptr(pairs.pair_off), _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
                                    _ptr(pairs.partial), _ptr(scale), _ptr(shift), _ptr(residual),
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
                                    out.stride(0), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
@@ -368,6 +370,47 @@ def pool_blocks_apply(x, blocks, d, out):
                                    _ptr(blocks.we_pos), _ptr(blocks.we_w), t.nv, int(d), _ptr(out), out.stride(0),
                                    _stream()), "gp_pool_blocks_apply")
     return out
+
+
+class PoolMfma:
+    """Affinity operator in matrix-core form: per 64-row block the padded neighbour union and the dense
+    [64 x union] weight block, pre-split to f16 hi/lo in MFMA A-fragment order."""
+
+    def __init__(self, bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total):
+        self.bu_off, self.bu_n, self.bu_row, self.wa_hi, self.wa_lo, self.nv, self.total = bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total
+
+
+def pool_mfma_build(nbr, w):
+    """One host sync (total padded union rows, to size the arrays)."""
+    lib = _lib.load()
+    nv, k = nbr.shape
+    dev = nbr.device
+    nb = (nv + 63) // 64
+    ws = _ws(lib.gp_pool_mfma_workspace_bytes(nv), dev)
+    bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+    bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
+    check(lib.gp_pool_mfma_count(_ptr(nbr), nv, int(k), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(), _stream()),
+          "gp_pool_mfma_count")
+    total = int(bu_off[nb].item())
+    bu_row = torch.empty(total, dtype=torch.int32, device=dev)
+    wa_hi = torch.empty(total // 32 * 4 * 64 * 8, dtype=torch.float16, device=dev)
+    wa_lo = torch.empty_like(wa_hi)
+    check(lib.gp_pool_mfma_fill(_ptr(nbr), _ptr(w), nv, int(k), _ptr(bu_off), _ptr(bu_n), total, _ptr(bu_row),
+                                _ptr(wa_hi), _ptr(wa_lo), _stream()), "gp_pool_mfma_fill")
+    return PoolMfma(bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total)
+
+
+def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
+    """x_split / out_split: (hi, lo) f16 [Nv, >=d] pairs; out_f32 fp32 [Nv, >=d]; at least one output."""
+    lib = _lib.load()
+    xh, xl = x_split
+    assert xh.stride(0) == xl.stride(0)
+    yh, yl = out_split if out_split is not None else (None, None)
+    check(lib.gp_pool_mfma_apply(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.wa_hi),
+                                 _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl),
+                                 yh.stride(0) if yh is not None else 0, _ptr(out_f32),
+                                 out_f32.stride(0) if out_f32 is not None else 0, _stream()), "gp_pool_mfma_apply")
+    return out_f32 if out_f32 is not None else out_split
 
 
 # ------------------------------------------------------------------------------------------ rows 5-7

@@ -364,6 +364,17 @@ class HotPath:
             blocks = ops.pool_blocks_build(tiles)
             if not blocks.ok:
                 blocks = None
+        if self.pool_mode == "mfma" and D == 512 and 64 * self.K <= 8192 and self.num_iters >= 1:
+            # matrix-core pooling: operands stay split (hi, lo) f16 between applications, fp32 only at the end
+            op = ops.pool_mfma_build(nbr, w)
+            sp = [ops.split_f16(X, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))]
+            for t in range(self.num_iters):
+                last = t == self.num_iters - 1
+                ops.pool_mfma_apply(sp[t % 2], op, D, out_split=None if last else sp[(t + 1) % 2],
+                                    out_f32=bufs[0] if last else None)
+            out = ops.gather_rows(bufs[0], D, batch.scene_inds_reconstruct, row_map=rank)
+            self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8)}
+            return out
         for t in range(self.num_iters):
             if blocks is not None:
                 ops.pool_blocks_apply(cur, blocks, D, bufs[t % 2])

@@ -117,6 +117,7 @@ int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t
 size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv);
 int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t chunk_rows,
                         int32_t *pair_in, int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start,
+                        int32_t *tile_desc /* i32 [num_pairs/256 + nseg, 4]: {k, first pair, count, 0} per tile */,
                         void *workspace, size_t workspace_bytes, void *stream);
 int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2,
                           void *w_hi, void *w_lo, void *stream);
@@ -127,8 +128,8 @@ int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, v
                  void *stream);
 int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
                          const int32_t *pair_in, const int32_t *pair_pos,
-                         const int32_t *seg_off, const int32_t *tile_start, int32_t nseg,
-                         int64_t num_pairs, int64_t nv, int32_t kv,
+                         const int32_t *seg_off, const int32_t *tile_start, const int32_t *tile_desc,
+                         int32_t nseg, int64_t num_pairs, int64_t nv, int32_t kv,
                          const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                          const float *scale, const float *shift, const float *residual, int64_t ld_res,
                          int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
@@ -189,6 +190,21 @@ int gp_pool_blocks_fill(const int64_t *tile_off, const int32_t *u_row, const flo
 int gp_pool_blocks_apply(const float *x, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                          const int64_t *tile_off, const int32_t *we_pos, const float *we_w, int64_t nv,
                          int32_t d, float *y, int64_t ld_y, void *stream);
+
+/* Matrix-core variant (d = 512): 64-row blocks, the block's neighbour union swept in steps of 32 rows */
+/* on v_mfma_f32_16x16x32_f16 with split operands (x = hi + lo in f16; hi*hi + hi*lo + lo*hi in fp32).  */
+/* bu_off i64 [nblocks+1] (padded union rows, multiples of 32), bu_n i32 [nblocks] (unpadded sizes),     */
+/* bu_row i32 [total], wa_hi/wa_lo f16 [total/32 * 4 * 64 * 8] (weights in MFMA A-fragment order).       */
+/* apply: x_hi/x_lo f16 [*, ld_x] -> y_hi/y_lo f16 (nullable pair) and/or y_f32 (nullable).              */
+size_t gp_pool_mfma_workspace_bytes(int64_t nv);
+int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int64_t *bu_off, int32_t *bu_n,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, const int64_t *bu_off,
+                      const int32_t *bu_n, int64_t total_rows, int32_t *bu_row, void *wa_hi, void *wa_lo,
+                      void *stream);
+int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
+                       const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
+                       void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */

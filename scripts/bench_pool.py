@@ -54,11 +54,20 @@ for R in (4, 8, 16):
 blocks = ops.pool_blocks_build(tiles[8])
 print("blocks ok", blocks.ok, "block union rows/row", (int(blocks.bu_off[-1]) / Nv) if blocks.ok else None, flush=True)
 variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4] + [("blocks (64 rows share LDS x)", "blocks")]
+mf = ops.pool_mfma_build(nbr, w)
+print("mfma union rows/row (padded)", mf.total / Nv, flush=True)
+xs = ops.split_f16(X, D)
+ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+variants += [("mfma f16x3 (split out)", "mfma"), ("mfma f16x3 (fp32 out)", "mfma32")]
 res = {}
 for rnd in range(3):
     for name, v in variants:
         if v is None:
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
+        elif v == "mfma":
+            t = timeit(lambda: ops.pool_mfma_apply(xs, mf, D, out_split=ys))
+        elif v == "mfma32":
+            t = timeit(lambda: ops.pool_mfma_apply(xs, mf, D, out_f32=Y))
         elif v == "blocks":
             t = timeit(lambda: ops.pool_blocks_apply(X, blocks, D, Y))
         else:

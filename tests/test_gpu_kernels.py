@@ -526,6 +526,61 @@ def test_pool_tiles_matches_ell_and_oracle(ops, R):
     assert (ca.cpu().double() - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("n_vox", [2500, 2531])
+def test_pool_mfma_matches_ell_and_oracle(ops, n_vox):
+    """Matrix-core pooling (split f16 operands, fp32 accumulation) against the ELL gather and the oracle
+    (models/affinity_module.py:1575-1587: torch.sparse.mm repeated num_iters times)."""
+    rng = np.random.default_rng(14)
+    c = surface_voxels(rng, n_vox)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, K, D = len(c), 96, 512
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    E = F.normalize(torch.randn(Nv, 128), dim=1)
+    w = ops.affinity_softmax(dev(E), nbr, 20.0)
+    op = ops.pool_mfma_build(nbr, w)
+    # structure: padded sorted unions, every (row, neighbour, weight) exactly once in A-fragment order
+    bo, bn, br = op.bu_off.cpu().numpy(), op.bu_n.cpu().numpy(), op.bu_row.cpu().numpy()
+    wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, 4, 64, 8) / 1024.0
+    nbc, wc = nbr.cpu().numpy(), w.cpu().numpy()
+    assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0
+    for b in (0, len(bn) // 2, len(bn) - 1):
+        rows = np.arange(b * 64, min(b * 64 + 64, Nv))
+        u = br[bo[b]:bo[b] + bn[b]]
+        assert (np.diff(u) > 0).all() and set(u) == set(nbc[rows].reshape(-1))
+        assert (br[bo[b] + bn[b]:bo[b + 1]] == u[0]).all()
+        dense = np.zeros((64, bo[b + 1] - bo[b]), np.float64)
+        pos = {v: i for i, v in enumerate(u)}
+        for r_i, row in enumerate(rows):
+            for j in range(K):
+                dense[r_i, pos[nbc[row, j]]] = wc[row, j]
+        blk = wa[bo[b] // 32:bo[b + 1] // 32]                           # [steps, wave, lane, j]
+        got = np.zeros_like(dense)
+        for s_ in range(blk.shape[0]):
+            for wv in range(4):
+                for lane in range(64):
+                    got[wv * 16 + lane % 16, s_ * 32 + (lane // 16) * 8:s_ * 32 + (lane // 16) * 8 + 8] = blk[s_, wv, lane]
+        assert np.abs(got - dense).max() < 1e-7
+    X = torch.randn(Nv, 544)
+    Xd = dev(X)
+    T = 5
+    sp = [ops.split_f16(Xd, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))]
+    out = torch.empty((Nv, D), device="cuda")
+    b_ = [torch.empty((Nv, D), device="cuda") for _ in range(2)]
+    cb = Xd
+    for t in range(T):
+        last = t == T - 1
+        ops.pool_mfma_apply(sp[t % 2], op, D, out_split=None if last else sp[(t + 1) % 2], out_f32=out if last else None)
+        ops.pool_ell(cb, nbr, w, D, b_[t % 2]); cb = b_[t % 2]
+    assert (out - cb).abs().max() < 2e-5                               # tolerance: fp32-class split arithmetic
+    ref = o_aff.pool_gather(X[:, :D], nbr.cpu().long(), w.cpu(), T)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    # both outputs at once agree with each other
+    y2 = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+    o2 = torch.empty((Nv, D), device="cuda")
+    ops.pool_mfma_apply(sp[0], op, D, out_split=y2, out_f32=o2)
+    assert ((y2[0].float() + y2[1].float()) - o2).abs().max() < 1e-6
+
+
 def test_pool_blocks_matches_tiles_and_oracle(ops):
     rng = np.random.default_rng(13)
     c = surface_voxels(rng, 2500)
