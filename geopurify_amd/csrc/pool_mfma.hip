@@ -124,130 +124,220 @@ __global__ void pm_weights_kernel(const int32_t *__restrict__ nbr, const float *
 }
 
 // ------------------------------------------------------------------------------------------------ apply
-struct PmSmem {
-    _Float16 xh[2][PM_KS][PM_D];     // 2 x 32 KiB
-    _Float16 xl[2][PM_KS][PM_D];     // 2 x 32 KiB
-};
+// One workgroup = 64 rows x 128 columns (grid = row blocks x 4 column quarters, the 4 quarters of a row
+// block adjacent on one XCD); 2 workgroups per CU.  A 3-deep ring of stages is filled by LDS-DMA two steps
+// ahead (~100 KiB in flight per CU: below that the gather is latency-bound, Little's law at ~14 TB/s of L2
+// bandwidth).  A stage carries everything step k needs: 32 union rows x 128 columns x {hi, lo}, the four
+// waves' weight fragments, and the row ids of stage k+2 (read back when that stage is issued), so the stage
+// hand-over is the only synchronisation in the loop.
+//
+// Synchronisation is hand-counted: the LDS reads are inline asm with explicit lgkmcnt waits (a
+// compiler-visible LDS read would wait for EVERY outstanding LDS-DMA, since the compiler cannot see that
+// they target other ring slots, and serialise the ring), and the hand-over is `s_waitcnt vmcnt(N);
+// s_barrier` with N = the DMA instructions issued for the later stage (loads return in order).
+constexpr int PQ_NC = 128;                       // columns per workgroup
+constexpr int PQ_NST = 3;                        // ring stages
+constexpr int PQ_PLANE = PM_KS * PQ_NC * 2;      // 8 KiB: 32 rows x 256 B
+constexpr int PQ_OFF_W = 2 * PQ_PLANE;           // weights: hi 4 x 1 KiB, lo 4 x 1 KiB
+constexpr int PQ_OFF_ID = PQ_OFF_W + 8192;       // row ids: 4 waves x 256 B (64 lanes x 4 B per DMA, 8 ids used)
+constexpr int PQ_STAGE = PQ_OFF_ID + 1024;       // 25600 B
+constexpr int PQ_DMA_PER_STAGE = 7;              // per wave: 4 x rows, 2 x weights, 1 x ids
+constexpr int PQ_EP = PQ_NC + 4;                 // epilogue staging pitch (floats)
+constexpr size_t PQ_SMEM_BYTES = (size_t)PQ_NST * PQ_STAGE;
+static_assert((size_t)PM_W * 16 * PQ_EP * sizeof(float) <= PQ_SMEM_BYTES, "epilogue staging must fit in the ring");
+static_assert(2 * PQ_STAGE < 65536 && PQ_NST == 3, "LDS offsets are 16-bit immediates: slots 0,1 from one base, slot 2 from a second");
 
-constexpr size_t PM_EPI_BYTES = (size_t)PM_W * 16 * PM_EP * sizeof(float);
-constexpr size_t PM_SMEM_BYTES = sizeof(PmSmem) > PM_EPI_BYTES ? sizeof(PmSmem) : PM_EPI_BYTES;
-
-__device__ __forceinline__ f16x8 pm_tr8(const _Float16 *p0, const _Float16 *p1) {
-    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p0);
-    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p1);
-    f16x8 r;
-    __builtin_memcpy(&r, &a, 8);
-    __builtin_memcpy(reinterpret_cast<char *>(&r) + 8, &b, 8);
-    return r;
+template <int OFF>
+__device__ __forceinline__ void pq_tr(s16x4 &d, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void pq_rd128(f16x8 &d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void pq_rd64(int2 &d, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void pq_wait_lgkm(s16x4 (&f)[2][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%[n])"
+                 : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]),
+                   "+v"(f[1][1][0]), "+v"(f[1][1][1])
+                 : [n] "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void pq_wait_lgkm3(int2 &id, f16x8 &a, f16x8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(id), "+v"(a), "+v"(b) : [n] "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void pq_handover() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ f16x8 pq_cat(s16x4 a, s16x4 b) {
+    typedef short s16x8 __attribute__((vector_size(16)));
+    s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, v);
+}
+// transposed reads of 2 column blocks (CB0, CB0+1): f[u][plane][half].  Ring slots 0,1 are addressed from
+// the slot-0 base registers (J = 0,1), slot 2 from a second set of base registers with J = 0
+// (lgkmcnt is a 4-bit counter: groups of 8 reads, at most 11 LDS operations outstanding)
+template <int J, int CB0>
+__device__ __forceinline__ void pq_read_group(s16x4 (&f)[2][2][2], const uint32_t (&addr)[8]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        pq_tr<(J & 1) * PQ_STAGE>(f[u][0][0], addr[CB0 + u]);
+        pq_tr<(J & 1) * PQ_STAGE + 512>(f[u][0][1], addr[CB0 + u]);
+        pq_tr<(J & 1) * PQ_STAGE + PQ_PLANE>(f[u][1][0], addr[CB0 + u]);
+        pq_tr<(J & 1) * PQ_STAGE + PQ_PLANE + 512>(f[u][1][1], addr[CB0 + u]);
+    }
+}
+__device__ __forceinline__ void pq_mma_group(f32x4 *acc, const s16x4 (&f)[2][2][2], f16x8 ah, f16x8 al) {
+    f16x8 bh[2], bl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { bh[u] = pq_cat(f[u][0][0], f[u][0][1]); bl[u] = pq_cat(f[u][1][0], f[u][1][1]); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[u], acc[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[u], acc[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[u], acc[u], 0, 0, 0);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
                  const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
                  const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
                  _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
                  int64_t ld_yf, int64_t per_xcd) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    PmSmem &sm = *reinterpret_cast<PmSmem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);     // XCD-contiguous block order
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);    // XCD-contiguous order
+    const int64_t b = lb >> 2;
+    const int col0 = (int)(lb & 3) * PQ_NC;
     if (b >= nblocks) return;
     const int64_t ub0 = bu_off[b];
-    const int nsteps = (int)((bu_off[b + 1] - ub0) / PM_KS);
+    const int n = (int)((bu_off[b + 1] - ub0) / PM_KS);                            // steps (>= 1)
     const int64_t ks0 = ub0 / PM_KS;
 
-    // DMA staging: wave wv moves rows 8wv .. 8wv+7 of the step, both planes, one 1-KiB piece per row;
-    // lane l writes physical chunk l, i.e. fetches logical chunk l ^ swz(row)
-    auto issue = [&](int s, int buf) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = wv * 8 + i;
-            const int row = __builtin_amdgcn_readfirstlane(bu_row[ub0 + (int64_t)s * PM_KS + r]);
-            const int64_t src = (int64_t)row * ld_x + ((lane ^ pm_swz(r)) * 8);
-            glds16(x_hi + src, &sm.xh[buf][r][0]);
-            glds16(x_lo + src, &sm.xl[buf][r][0]);
-        }
-    };
+    // ---- DMA roles: wave wv stages union rows 8wv..8wv+7 of a step; one instruction = 4 rows x 256 B.
+    //      instruction i (0,1), lane quarter u = lane>>4 -> row 8wv + 2u + i, stored in LDS row slot
+    //      8wv + 4i + u; lane chunk c = lane&15 lands in physical 16-B chunk c and fetches logical chunk
+    //      c ^ 2t(row), t(row) = (row & 3) | ((row >> 3) & 1) << 2   (conflict-free transposed reads)
+    const int du = lane >> 4, dc = lane & 15;
+    const int64_t dsrc0 = col0 + ((dc ^ (2 * ((2 * (du & 1) + 0) | ((wv & 1) << 2)))) * 8);
+    const int64_t dsrc1 = col0 + ((dc ^ (2 * ((2 * (du & 1) + 1) | ((wv & 1) << 2)))) * 8);
+    const int32_t *idg = bu_row + ub0 + 8 * wv;                                    // this wave's row ids, step 0
     const _Float16 *wah = wa_hi + ((ks0 * PM_W + wv) * 64 + lane) * 8;
     const _Float16 *wal = wa_lo + ((ks0 * PM_W + wv) * 64 + lane) * 8;
-    constexpr int64_t WSTEP = (int64_t)PM_W * 64 * 8;                 // halfs per k-step of weights
+    constexpr int64_t WSTEP = (int64_t)PM_W * 64 * 8;
+    // stage k -> ring slot: rows(k), weights(k), ids(min(k+2, n-1))
+    auto issue = [&](int2 id, int k, int slot) {
+        unsigned char *dst = smem_raw + slot * PQ_STAGE;
+        const int64_t s0 = (int64_t)id.x * ld_x + dsrc0, s1 = (int64_t)id.y * ld_x + dsrc1;
+        glds16(x_hi + s0, dst + (8 * wv) * 256);
+        glds16(x_lo + s0, dst + PQ_PLANE + (8 * wv) * 256);
+        glds16(x_hi + s1, dst + (8 * wv) * 256 + 1024);
+        glds16(x_lo + s1, dst + PQ_PLANE + (8 * wv) * 256 + 1024);
+        glds16(wah + (int64_t)k * WSTEP, dst + PQ_OFF_W + wv * 1024);
+        glds16(wal + (int64_t)k * WSTEP, dst + PQ_OFF_W + 4096 + wv * 1024);
+        const int kid = k + 2 < n ? k + 2 : n - 1;
+        // 16 lanes x 4 B: the wave's 8 ids (+ 8 more, always inside the block's padded union)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(idg + (int64_t)kid * PM_KS + (lane & 7)),
+                                         (__attribute__((address_space(3))) void *)(dst + PQ_OFF_ID + wv * 256), 4, 0, 0);
+    };
 
-    f32x4 acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // transposed-read addressing: group g = lane>>4 owns k rows 8g..8g+7; lane 4q+p of the group supplies
-    // row 8g+q (second read: +4), logical columns 4p..4p+3 of the 16-column block
+    // ---- read roles: 16-lane group g owns k rows 8g..8g+7; lane 4q+p supplies row 8g+q (LDS slot
+    //      8g + 4(q&1) + (q>>1); the second read, row 8g+q+4, is 2 slots = 512 B further), logical
+    //      columns 4p..4p+3 of the 16-column block
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int r_a = 8 * g + q, r_b = r_a + 4;
-    const int sw_a = pm_swz(r_a), sw_b = pm_swz(r_b);
-    const int half_off = (p & 1) * 4;                                   // halfs inside the 16-byte chunk
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+    uint32_t addr[8];
+    {
+        const uint32_t rowb = (uint32_t)(8 * g + 4 * (q & 1) + (q >> 1)) * 256u + (uint32_t)((p >> 1) * 16 + (p & 1) * 8);
+        const uint32_t t = (uint32_t)(q | ((g & 1) << 2));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) addr[k] = lds0 + ((rowb + 32u * k) ^ (t << 5));
+    }
+    const uint32_t addr_w = lds0 + PQ_OFF_W + wv * 1024 + lane * 16;
+    const uint32_t addr_id = lds0 + PQ_OFF_ID + wv * 256 + du * 8;
+    uint32_t addr2[8];                                                  // the same, based at ring slot 2
+#pragma unroll
+    for (int k = 0; k < 8; ++k) addr2[k] = addr[k] + 2 * PQ_STAGE;
+    const uint32_t addr_w2 = addr_w + 2 * PQ_STAGE, addr_id2 = addr_id + 2 * PQ_STAGE;
 
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: stages 0 and 1 in flight (a one-step block stages its only step twice: no branches here,
+    //      so that the compiler's own wait for the two id loads sits before the first DMA and nowhere else)
+    {
+        const int k1 = n > 1 ? 1 : 0;
+        const int2 i0 = *reinterpret_cast<const int2 *>(idg + 2 * du);
+        const int2 i1 = *reinterpret_cast<const int2 *>(idg + k1 * PM_KS + 2 * du);
+        asm volatile("" ::"v"(i0.x), "v"(i0.y), "v"(i1.x), "v"(i1.y));    // both id loads land before the first DMA
+        issue(i0, 0, 0);
+        issue(i1, k1, 1);
+        pq_handover<PQ_DMA_PER_STAGE>();
+    }
+    s16x4 f0[2][2][2], f1[2][2][2];
     f16x8 ah, al;
-    if (nsteps > 0) {
-        issue(0, 0);
-        ah = *reinterpret_cast<const f16x8 *>(wah);
-        al = *reinterpret_cast<const f16x8 *>(wal);
-    }
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        f16x8 ah_n = ah, al_n = al;
-        if (s + 1 < nsteps) {
-            issue(s + 1, buf ^ 1);
-            ah_n = *reinterpret_cast<const f16x8 *>(wah + (s + 1) * WSTEP);
-            al_n = *reinterpret_cast<const f16x8 *>(wal + (s + 1) * WSTEP);
+    int2 idn;
+    for (int s0 = 0; s0 < n; s0 += PQ_NST) {
+#define PQ_STEP(J, JO, A, AW, AID)                                                                              \
+        if (s0 + J < n) {                                                                                       \
+            const int s = s0 + J;                                                                               \
+            pq_rd64<JO * PQ_STAGE>(idn, AID);                                                                   \
+            pq_rd128<JO * PQ_STAGE>(ah, AW);                                                                    \
+            pq_rd128<JO * PQ_STAGE + 4096>(al, AW);                                                             \
+            pq_read_group<JO, 0>(f0, A);                                                                        \
+            pq_wait_lgkm3<8>(idn, ah, al);                                                                      \
+            if (s + 2 < n) issue(idn, s + 2, (J + 2) % PQ_NST);                                                 \
+            pq_read_group<JO, 2>(f1, A);                                                                        \
+            pq_wait_lgkm<8>(f0);                                                                                \
+            pq_mma_group(acc, f0, ah, al);                                                                      \
+            pq_read_group<JO, 4>(f0, A);                                                                        \
+            pq_wait_lgkm<8>(f1);                                                                                \
+            pq_mma_group(acc + 2, f1, ah, al);                                                                  \
+            pq_read_group<JO, 6>(f1, A);                                                                        \
+            pq_wait_lgkm<8>(f0);                                                                                \
+            pq_mma_group(acc + 4, f0, ah, al);                                                                  \
+            pq_wait_lgkm<0>(f1);                                                                                \
+            pq_mma_group(acc + 6, f1, ah, al);                                                                  \
+            if (s + 2 < n) pq_handover<PQ_DMA_PER_STAGE>(); else pq_handover<0>();                              \
         }
-        const _Float16 *xh_a = &sm.xh[buf][r_a][0], *xh_b = &sm.xh[buf][r_b][0];
-        const _Float16 *xl_a = &sm.xl[buf][r_a][0], *xl_b = &sm.xl[buf][r_b][0];
-#pragma unroll
-        for (int cb4 = 0; cb4 < 32; cb4 += 4) {
-            f16x8 bh[4], bl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = 2 * (cb4 + u) + (p >> 1);                 // logical 16-byte chunk
-                const int oa = ((c ^ sw_a) * 8) + half_off, ob = ((c ^ sw_b) * 8) + half_off;
-                bh[u] = pm_tr8(xh_a + oa, xh_b + ob);
-                bl[u] = pm_tr8(xl_a + oa, xl_b + ob);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[cb4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[u], acc[cb4 + u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[cb4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[u], acc[cb4 + u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[cb4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[u], acc[cb4 + u], 0, 0, 0);
-        }
-        ah = ah_n;
-        al = al_n;
-        __syncthreads();
+        PQ_STEP(0, 0, addr, addr_w, addr_id)
+        PQ_STEP(1, 1, addr, addr_w, addr_id)
+        PQ_STEP(2, 0, addr2, addr_w2, addr_id2)
+#undef PQ_STEP
     }
-    // ---- epilogue through LDS: wave's 16 x 512 fp32 tile -> row-major, then coalesced split/fp32 stores
-    constexpr int EP = PM_EP;                                           // floats per staged row (bank-skewed)
-    float *st = reinterpret_cast<float *>(smem_raw) + wv * (16 * EP);
+    // ---- epilogue through LDS (the ring is drained: the last hand-over waited for vmcnt(0))
+    constexpr float inv = 1.f / PM_WSCALE;
+    float *st = reinterpret_cast<float *>(smem_raw) + wv * (16 * PQ_EP);
     const int fl = lane & 15, fq = lane >> 4;
 #pragma unroll
-    for (int cb = 0; cb < 32; ++cb)
+    for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * EP + cb * 16 + fl] = acc[cb][r];
+        for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * PQ_EP + cb * 16 + fl] = acc[cb][r] * inv;
     gp_wave_sync();
     const int64_t row0 = b * PM_ROWS + wv * 16;
-    for (int t = 0; t < 32; ++t) {                                      // 16 rows x 128 float4 = 2048 float4 / 64 lanes
-        int idx = t * 64 + lane;
-        int row = idx >> 7, c4 = idx & 127;
-        int64_t grow = row0 + row;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {                                    // 16 rows x 32 float4 per wave
+        const int idx = it * 64 + lane;
+        const int row = idx >> 5, c4 = idx & 31;
+        const int64_t grow = row0 + row;
         if (grow < nv) {
-            float4 v = *reinterpret_cast<const float4 *>(st + row * EP + c4 * 4);
-            constexpr float inv = 1.f / PM_WSCALE;
-            v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+            float4 v = *reinterpret_cast<const float4 *>(st + row * PQ_EP + c4 * 4);
             float xv[4] = {v.x, v.y, v.z, v.w};
             f16x4 h, l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { h[i] = (_Float16)xv[i]; l[i] = (_Float16)(xv[i] - (float)h[i]); }
             if (y_hi) {
-                *reinterpret_cast<f16x4 *>(y_hi + grow * ld_y + c4 * 4) = h;
-                *reinterpret_cast<f16x4 *>(y_lo + grow * ld_y + c4 * 4) = l;
+                *reinterpret_cast<f16x4 *>(y_hi + grow * ld_y + col0 + c4 * 4) = h;
+                *reinterpret_cast<f16x4 *>(y_lo + grow * ld_y + col0 + c4 * 4) = l;
             }
-            if (y_f32) *reinterpret_cast<float4 *>(y_f32 + grow * ld_yf + c4 * 4) = v;
+            if (y_f32) *reinterpret_cast<float4 *>(y_f32 + grow * ld_yf + col0 + c4 * 4) = v;
         }
     }
 }
@@ -319,12 +409,12 @@ extern "C" int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld
     static bool attr_set = false;
     if (!attr_set) {
         GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_SMEM_BYTES));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)PQ_SMEM_BYTES));
         attr_set = true;
     }
     int64_t nb = (nv + PM_ROWS - 1) / PM_ROWS;
-    int64_t per_xcd = (nb + 7) / 8;
-    pool_mfma_kernel<<<(unsigned)(per_xcd * 8), 256, PM_SMEM_BYTES, gp_stream(stream_)>>>(
+    int64_t per_xcd = (nb * (PM_D / PQ_NC) + 7) / 8;
+    pool_mfma_kernel<<<(unsigned)(per_xcd * 8), 256, PQ_SMEM_BYTES, gp_stream(stream_)>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
         static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
         static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd);
