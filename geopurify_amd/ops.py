@@ -373,31 +373,32 @@ def pool_blocks_apply(x, blocks, d, out):
 
 
 class PoolMfma:
-    """Affinity operator in matrix-core form: per 64-row block the padded neighbour union and the dense
-    [64 x union] weight block, pre-split to f16 hi/lo in MFMA A-fragment order."""
+    """Affinity operator in matrix-core form: per block of block_rows rows the padded neighbour union and the
+    dense [block_rows x union] weight block, pre-split to f16 hi/lo in MFMA A-fragment order."""
 
-    def __init__(self, bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total):
-        self.bu_off, self.bu_n, self.bu_row, self.wa_hi, self.wa_lo, self.nv, self.total = bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total
+    def __init__(self, bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows):
+        self.bu_off, self.bu_n, self.bu_row, self.wa_hi, self.wa_lo = bu_off, bu_n, bu_row, wa_hi, wa_lo
+        self.nv, self.total, self.block_rows = nv, total, block_rows
 
 
-def pool_mfma_build(nbr, w):
+def pool_mfma_build(nbr, w, block_rows=64):
     """One host sync (total padded union rows, to size the arrays)."""
     lib = _lib.load()
     nv, k = nbr.shape
     dev = nbr.device
-    nb = (nv + 63) // 64
-    ws = _ws(lib.gp_pool_mfma_workspace_bytes(nv), dev)
+    nb = (nv + block_rows - 1) // block_rows
+    ws = _ws(lib.gp_pool_mfma_workspace_bytes(nv, block_rows), dev)
     bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
     bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
-    check(lib.gp_pool_mfma_count(_ptr(nbr), nv, int(k), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(), _stream()),
-          "gp_pool_mfma_count")
+    check(lib.gp_pool_mfma_count(_ptr(nbr), nv, int(k), int(block_rows), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(),
+                                 _stream()), "gp_pool_mfma_count")
     total = int(bu_off[nb].item())
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
-    wa_hi = torch.empty(total // 32 * 4 * 64 * 8, dtype=torch.float16, device=dev)
+    wa_hi = torch.empty(total // 32 * (block_rows // 16) * 64 * 8, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
-    check(lib.gp_pool_mfma_fill(_ptr(nbr), _ptr(w), nv, int(k), _ptr(bu_off), _ptr(bu_n), total, _ptr(bu_row),
-                                _ptr(wa_hi), _ptr(wa_lo), _stream()), "gp_pool_mfma_fill")
-    return PoolMfma(bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total)
+    check(lib.gp_pool_mfma_fill(_ptr(nbr), _ptr(w), nv, int(k), int(block_rows), _ptr(bu_off), _ptr(bu_n), total,
+                                _ptr(bu_row), _ptr(wa_hi), _ptr(wa_lo), _stream()), "gp_pool_mfma_fill")
+    return PoolMfma(bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows)
 
 
 def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
@@ -407,7 +408,7 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
     assert xh.stride(0) == xl.stride(0)
     yh, yl = out_split if out_split is not None else (None, None)
     check(lib.gp_pool_mfma_apply(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.wa_hi),
-                                 _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl),
+                                 _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows), _ptr(yh), _ptr(yl),
                                  yh.stride(0) if yh is not None else 0, _ptr(out_f32),
                                  out_f32.stride(0) if out_f32 is not None else 0, _stream()), "gp_pool_mfma_apply")
     return out_f32 if out_f32 is not None else out_split

@@ -240,9 +240,9 @@ class HotPath:
     constants (affinity_module.py:1492-1493,1584-1587) exposed as options."""
 
     def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda",
-                 pool_mode="tiles", pool_tile_rows=8):
+                 pool_mode="tiles", pool_tile_rows=8, pool_block_rows=64):
         self.student = student
-        self.pool_mode, self.pool_tile_rows = pool_mode, pool_tile_rows
+        self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
         self.device = torch.device(device)
@@ -364,9 +364,9 @@ class HotPath:
             blocks = ops.pool_blocks_build(tiles)
             if not blocks.ok:
                 blocks = None
-        if self.pool_mode == "mfma" and D == 512 and 64 * self.K <= 8192 and self.num_iters >= 1:
+        if self.pool_mode == "mfma" and D == 512 and self.pool_block_rows * self.K <= 16384 and self.num_iters >= 1:
             # matrix-core pooling: operands stay split (hi, lo) f16 between applications, fp32 only at the end
-            op = ops.pool_mfma_build(nbr, w)
+            op = ops.pool_mfma_build(nbr, w, self.pool_block_rows)
             sp = [ops.split_f16(X, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))]
             for t in range(self.num_iters):
                 last = t == self.num_iters - 1

@@ -191,20 +191,22 @@ int gp_pool_blocks_apply(const float *x, int64_t ld_x, const int64_t *bu_off, co
                          const int64_t *tile_off, const int32_t *we_pos, const float *we_w, int64_t nv,
                          int32_t d, float *y, int64_t ld_y, void *stream);
 
-/* Matrix-core variant (d = 512): 64-row blocks, the block's neighbour union swept in steps of 32 rows */
-/* on v_mfma_f32_16x16x32_f16 with split operands (x = hi + lo in f16; hi*hi + hi*lo + lo*hi in fp32).  */
+/* Matrix-core variant (d = 512): blocks of block_rows (64 or 128) rows, the block's neighbour union    */
+/* swept in steps of 32 rows on v_mfma_f32_16x16x32_f16 with split operands (x = hi + lo in f16;        */
+/* hi*hi + hi*lo + lo*hi accumulated in fp32).  nblocks = ceil(nv / block_rows), nw = block_rows / 16.   */
 /* bu_off i64 [nblocks+1] (padded union rows, multiples of 32), bu_n i32 [nblocks] (unpadded sizes),     */
-/* bu_row i32 [total], wa_hi/wa_lo f16 [total/32 * 4 * 64 * 8] (weights in MFMA A-fragment order).       */
+/* bu_row i32 [total], wa_hi/wa_lo f16 [total/32 * nw * 64 * 8] (weights x 2^10 in MFMA A-fragment order).*/
 /* apply: x_hi/x_lo f16 [*, ld_x] -> y_hi/y_lo f16 (nullable pair) and/or y_f32 (nullable).              */
-size_t gp_pool_mfma_workspace_bytes(int64_t nv);
-int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int64_t *bu_off, int32_t *bu_n,
-                       void *workspace, size_t workspace_bytes, void *stream);
-int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, const int64_t *bu_off,
-                      const int32_t *bu_n, int64_t total_rows, int32_t *bu_row, void *wa_hi, void *wa_lo,
-                      void *stream);
+size_t gp_pool_mfma_workspace_bytes(int64_t nv, int32_t block_rows);
+int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t block_rows, int64_t *bu_off,
+                       int32_t *bu_n, void *workspace, size_t workspace_bytes, void *stream);
+int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t block_rows,
+                      const int64_t *bu_off, const int32_t *bu_n, int64_t total_rows, int32_t *bu_row,
+                      void *wa_hi, void *wa_lo, void *stream);
 int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
                        const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
-                       void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, void *stream);
+                       int32_t block_rows, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
+                       int64_t ld_yf, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */

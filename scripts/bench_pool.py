@@ -12,7 +12,7 @@ from geopurify_amd import _lib, ops, pipeline as pl, synthetic as syn  # noqa: E
 
 cfg = syn.CONFIGS["S"]
 import dataclasses
-cfg = dataclasses.replace(cfg, num_views=1)
+cfg = dataclasses.replace(cfg, num_views=1, num_points=int(sys.argv[2]) if len(sys.argv) > 2 else cfg.num_points)
 sc = syn.make_scene(cfg, 5557)
 rigid = pl.scene_rigid_transform(cfg.voxel_size, 5557)
 vox = ops.voxelize(torch.from_numpy(sc.coords).cuda(), rigid)
@@ -54,20 +54,28 @@ for R in (4, 8, 16):
 blocks = ops.pool_blocks_build(tiles[8])
 print("blocks ok", blocks.ok, "block union rows/row", (int(blocks.bu_off[-1]) / Nv) if blocks.ok else None, flush=True)
 variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4] + [("blocks (64 rows share LDS x)", "blocks")]
-mf = ops.pool_mfma_build(nbr, w)
-print("mfma union rows/row (padded)", mf.total / Nv, flush=True)
+mf = {}
+for BR in (64, 128):
+    t0 = time.time(); mf[BR] = ops.pool_mfma_build(nbr, w, BR); torch.cuda.synchronize()
+    print(f"mfma BR={BR}: union rows/row (padded) {mf[BR].total / Nv:.2f}  build {1e3 * (time.time() - t0):.2f} ms", flush=True)
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
-variants += [("mfma f16x3 (split out)", "mfma"), ("mfma f16x3 (fp32 out)", "mfma32")]
+variants += [("mfma64 f16x3 (split out)", ("mfma", 64)), ("mfma64 f16x3 (fp32 out)", ("mfma32", 64)),
+             ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0)), ("mfma128 8w x (16r x 256c) (split out)", ("mfma", 128, 1))]
+ABL = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # pool_mfma ablation bits (timing only, results invalid)
+lib.gp_debug_set(4, ABL)
+if len(sys.argv) > 1:                                   # e.g. "mfma": only variants whose name contains the word
+    variants = [v for v in variants if sys.argv[1] in v[0]]
 res = {}
 for rnd in range(3):
     for name, v in variants:
         if v is None:
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
-        elif v == "mfma":
-            t = timeit(lambda: ops.pool_mfma_apply(xs, mf, D, out_split=ys))
-        elif v == "mfma32":
-            t = timeit(lambda: ops.pool_mfma_apply(xs, mf, D, out_f32=Y))
+        elif v[0] == "mfma":
+            lib.gp_debug_set(7, v[2] if len(v) > 2 else 0)
+            t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
+        elif v[0] == "mfma32":
+            t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_f32=Y))
         elif v == "blocks":
             t = timeit(lambda: ops.pool_blocks_apply(X, blocks, D, Y))
         else:

@@ -526,8 +526,8 @@ def test_pool_tiles_matches_ell_and_oracle(ops, R):
     assert (ca.cpu().double() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("n_vox", [2500, 2531])
-def test_pool_mfma_matches_ell_and_oracle(ops, n_vox):
+@pytest.mark.parametrize("n_vox,BR", [(2500, 64), (2531, 64), (2500, 128), (2531, 128)])
+def test_pool_mfma_matches_ell_and_oracle(ops, n_vox, BR):
     """Matrix-core pooling (split f16 operands, fp32 accumulation) against the ELL gather and the oracle
     (models/affinity_module.py:1575-1587: torch.sparse.mm repeated num_iters times)."""
     rng = np.random.default_rng(14)
@@ -537,18 +537,19 @@ def test_pool_mfma_matches_ell_and_oracle(ops, n_vox):
     nbr = ops.knn_lattice(grid, cs, perm, K)
     E = F.normalize(torch.randn(Nv, 128), dim=1)
     w = ops.affinity_softmax(dev(E), nbr, 20.0)
-    op = ops.pool_mfma_build(nbr, w)
+    op = ops.pool_mfma_build(nbr, w, BR)
+    NW = BR // 16
     # structure: padded sorted unions, every (row, neighbour, weight) exactly once in A-fragment order
     bo, bn, br = op.bu_off.cpu().numpy(), op.bu_n.cpu().numpy(), op.bu_row.cpu().numpy()
-    wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, 4, 64, 8) / 1024.0
+    wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, NW, 64, 8) / 1024.0
     nbc, wc = nbr.cpu().numpy(), w.cpu().numpy()
     assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0
     for b in (0, len(bn) // 2, len(bn) - 1):
-        rows = np.arange(b * 64, min(b * 64 + 64, Nv))
+        rows = np.arange(b * BR, min(b * BR + BR, Nv))
         u = br[bo[b]:bo[b] + bn[b]]
         assert (np.diff(u) > 0).all() and set(u) == set(nbc[rows].reshape(-1))
         assert (br[bo[b] + bn[b]:bo[b + 1]] == u[0]).all()
-        dense = np.zeros((64, bo[b + 1] - bo[b]), np.float64)
+        dense = np.zeros((BR, bo[b + 1] - bo[b]), np.float64)
         pos = {v: i for i, v in enumerate(u)}
         for r_i, row in enumerate(rows):
             for j in range(K):
@@ -556,7 +557,7 @@ def test_pool_mfma_matches_ell_and_oracle(ops, n_vox):
         blk = wa[bo[b] // 32:bo[b + 1] // 32]                           # [steps, wave, lane, j]
         got = np.zeros_like(dense)
         for s_ in range(blk.shape[0]):
-            for wv in range(4):
+            for wv in range(NW):
                 for lane in range(64):
                     got[wv * 16 + lane % 16, s_ * 32 + (lane // 16) * 8:s_ * 32 + (lane // 16) * 8 + 8] = blk[s_, wv, lane]
         assert np.abs(got - dense).max() < 1e-7
