@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="S", choices=["P", "S", "M", "T"])
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
+    ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma", "tiles", "ell"])
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams: consecutive scenes alternate streams so that one scene's\n                    loader/lift kernels overlap the previous scene's pooling tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,6 +58,20 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def pmc_traffic(kernel, nv):
+    """HBM-side bytes per launch of the pooling kernel from the committed rocprofv3 PMC passes
+    (profiles/pool_pmc.json: FETCH_SIZE / WRITE_SIZE in KiB on an S-shaped voxel set, separate passes;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950), scaled to this
+    scene's voxel count.  null when no counters were collected for this kernel."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pool_pmc.json")) as f:
+            rec = json.load(f)[kernel]
+        b = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024 * nv / rec["nv"]
+        return {"traffic": int(b), "traffic_source": f"profiles/pool_pmc.json ({rec['profile']})"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 class PoolTimer:
     """HIP events around every pooling launch, on the stream the kernels are launched on."""
 
@@ -67,7 +82,7 @@ class PoolTimer:
 
     def wrap(self, ops):
         timer = self
-        for name in ("pool_ell", "pool_tiles_apply"):
+        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply"):
             orig = getattr(ops, name)
 
             def timed(*a, _orig=orig, _name=name, **k):
@@ -176,7 +191,7 @@ def main():
         rigids.append(pl.scene_rigid_transform(cfg.voxel_size, seed))
     sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
     student = pl.StudentWeights(sd, dev)
-    hp = pl.HotPath(student, cfg.mask_shape, K=96, sharpen=20.0, num_iters=args.pool_iters, device=dev)
+    hp = pl.HotPath(student, cfg.mask_shape, K=96, sharpen=20.0, num_iters=args.pool_iters, device=dev, pool_mode=args.pool_mode)
     counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device=dev)
     pool_timer = PoolTimer()
     pool_timer.wrap(ops)
@@ -244,6 +259,13 @@ def main():
         Nv = hp.stats["Nv"]
         D = cfg.feat_dim
         pool_ms = pool_timer.mean_ms()
+        # the same launches with nothing else on the GPU (with --streams 2 the timed region overlaps the pooling
+        # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth)
+        pool_timer.events, pool_timer.enabled = [], True
+        hp._pool(*hp._last_pool_inputs)
+        torch.cuda.synchronize()
+        pool_timer.enabled = False
+        pool_ms_alone = pool_timer.mean_ms()
         pool_bytes = Nv * (2 * D * 4 + 96 * 8)           # algorithmic bytes per application of A
         achieved = pool_bytes / (pool_ms * 1e-3) / 1e9
         stages = stage.table()
@@ -259,11 +281,12 @@ def main():
                                    f"pool_iters={args.pool_iters}, student 518->512x9->128 random-init",
                        "sharding": f"1 scene per GPU x {world}, one int64 all-reduce of IoU counts",
                        "streams": len(streams)},
-            "roofline": {"kernel": ("pool_tiles_kernel" if pool_timer.kernel == "pool_tiles_apply" else "pool_ell_kernel")
-                         + " (affinity pooling, one application of A)", "bound": "hbm",
+            "roofline": {"kernel": hp.stats["pool_kernel"] + " (affinity pooling, one application of A)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], Nv),
+                         "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4),
+                         "avg_launch_ms_isolated": round(pool_ms_alone, 4),
+                         "frac_isolated": round(pool_bytes / (pool_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "stages_ms_per_scene": {k: round(v / args.steps, 3) for k, v in stages.items()},
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
         }

@@ -4,7 +4,7 @@
 
 #include "gp_common.h"
 
-extern int g_gp_knobs[8];
+extern int g_gp_knobs[16];
 
 namespace {
 

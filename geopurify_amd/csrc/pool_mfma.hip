@@ -18,7 +18,7 @@
 
 #include "gp_common.h"
 
-extern int g_gp_knobs[8];
+extern int g_gp_knobs[16];
 
 namespace {
 
@@ -53,12 +53,15 @@ __device__ __forceinline__ void bitonic_sort_lds(int *a, int n_pow2, int tid, in
         }
 }
 
-// sorted unique union of the neighbour ids of rows [b*br, b*br+br).  count pass: bu_n / padded count;
-// fill pass: bu_row (padding repeats the first id; its weights stay zero).
+// sorted unique union of the neighbour ids of rows [b*br, b*br+br): de-duplicated through an LDS hash table
+// (the union is ~7 % of the br*k ids), then a bitonic sort of the unique ids only.
+// count pass: bu_n / padded count; fill pass: bu_row (padding repeats the first id; its weights stay zero).
+constexpr int PM_HS = 16384;          // hash slots (>= the largest possible union, so insertion always ends)
 __global__ void __launch_bounds__(1024)
 pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int64_t *__restrict__ padded_cnt,
                 int32_t *__restrict__ bu_n, const int64_t *__restrict__ bu_off, int32_t *__restrict__ bu_row) {
-    extern __shared__ int s_ids[];                       // np2 ints
+    extern __shared__ int s_mem[];                       // keys[PM_HS] | dense[np2(br*k)]
+    int *keys = s_mem, *dense = s_mem + PM_HS;
     __shared__ int s_wcnt[16];
     __shared__ int s_base;
     const int64_t b = blockIdx.x;
@@ -66,24 +69,27 @@ pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int6
     const int64_t r0 = b * br;
     const int rows = (int)((nv - r0) < br ? (nv - r0) : br);
     const int n = rows * k;
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < np2; i += 1024) s_ids[i] = i < n ? nbr[r0 * k + i] : INT32_MAX;
-    __syncthreads();
-    bitonic_sort_lds(s_ids, np2, tid, 1024);
+    for (int i = tid; i < PM_HS; i += 1024) keys[i] = -1;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    const int64_t o = bu_row ? bu_off[b] : 0;
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        int i = i0 + tid;
-        int head = (i < n) && (i == 0 || s_ids[i] != s_ids[i - 1]);
-        unsigned long long m = __ballot(head);
+    for (int i = tid; i < n; i += 1024) {
+        const int id = nbr[r0 * k + i];
+        unsigned h = ((unsigned)id * 2654435761u) >> 18;                // 14 bits
+        while (true) {
+            const int old = atomicCAS(&keys[h], -1, id);
+            if (old == -1 || old == id) break;
+            h = (h + 1) & (PM_HS - 1);
+        }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < PM_HS; i0 += 1024) {                          // compact the occupied slots
+        const int key = keys[i0 + tid];
+        const unsigned long long m = __ballot(key >= 0);
         if (lane == 0) s_wcnt[wv] = __popcll(m);
         __syncthreads();
         int before = s_base;
         for (int w = 0; w < wv; ++w) before += s_wcnt[w];
-        int r = before + __popcll(m & ((1ull << lane) - 1ull));
-        if (head && bu_row) bu_row[o + r] = s_ids[i];
+        if (key >= 0) dense[before + __popcll(m & ((1ull << lane) - 1ull))] = key;
         __syncthreads();
         if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += s_wcnt[w]; s_base += tot; }
         __syncthreads();
@@ -91,9 +97,15 @@ pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int6
     const int U = s_base, Up = (U + PM_KS - 1) / PM_KS * PM_KS;
     if (!bu_row) {
         if (tid == 0) { padded_cnt[b] = Up; bu_n[b] = U; }
-    } else {
-        for (int i = U + tid; i < Up; i += 1024) bu_row[o + i] = s_ids[0];
+        return;
     }
+    int np2 = 1;
+    while (np2 < U) np2 <<= 1;
+    for (int i = U + tid; i < np2; i += 1024) dense[i] = INT32_MAX;
+    __syncthreads();
+    bitonic_sort_lds(dense, np2, tid, 1024);
+    const int64_t o = bu_off[b];
+    for (int i = tid; i < Up; i += 1024) bu_row[o + i] = i < U ? dense[i] : dense[0];
 }
 
 // scatter the ELL weights into MFMA A-fragment order: wa[(kstep*nw + wave)*64 + lane][8], lane = (k>>3)*16 + m
@@ -421,7 +433,13 @@ int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
     }
     int64_t nb = (nv + G::BR - 1) / G::BR;
     int64_t per_xcd = (nb * (PM_D / NC) + 7) / 8;
-    pool_mfma_kernel<NW, NC, MT, CGN><<<(unsigned)(per_xcd * 8), NW * 64, G::SMEM, s>>>(
+    size_t smem = G::SMEM;
+    if (g_gp_knobs[9] > 0 && G::SMEM < 90 * 1024) {       // tuning aid: force one workgroup per CU
+        smem = 90 * 1024;
+        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel<NW, NC, MT, CGN>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    pool_mfma_kernel<NW, NC, MT, CGN><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
         static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
         static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4]);
@@ -454,9 +472,9 @@ extern "C" int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int
     if (!cv.ok()) { gp_set_error("gp_pool_mfma_count: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(cnt + nb, 0, sizeof(int64_t), s));
-    size_t sm = (size_t)pm_np2((int64_t)block_rows * k) * sizeof(int);
+    size_t sm = (size_t)(PM_HS + pm_np2((int64_t)block_rows * k)) * sizeof(int);
     GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pm_union_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     PM_MAXID * (int)sizeof(int)));
+                                     (PM_HS + PM_MAXID) * (int)sizeof(int)));
     pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, cnt, bu_n, nullptr, nullptr);
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, cnt, bu_off, (int64_t)0, (size_t)(nb + 1), rocprim::plus<int64_t>(), s));
     GP_CHECK_LAUNCH();
@@ -476,9 +494,9 @@ extern "C" int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv,
     size_t wbytes = (size_t)(total_rows / PM_KS) * (block_rows / 16) * 64 * 8 * sizeof(_Float16);
     GP_CHECK_HIP(hipMemsetAsync(wa_hi, 0, wbytes, s));
     GP_CHECK_HIP(hipMemsetAsync(wa_lo, 0, wbytes, s));
-    size_t sm = (size_t)pm_np2((int64_t)block_rows * k) * sizeof(int);
+    size_t sm = (size_t)(PM_HS + pm_np2((int64_t)block_rows * k)) * sizeof(int);
     GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pm_union_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     PM_MAXID * (int)sizeof(int)));
+                                     (PM_HS + PM_MAXID) * (int)sizeof(int)));
     pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, nullptr, nullptr, bu_off, bu_row);
     int64_t ne = nv * k;
     pm_weights_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(nbr, w, nv, k, block_rows, bu_off, bu_n, bu_row,
@@ -501,7 +519,5 @@ extern "C" int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld
     hipStream_t s = gp_stream(stream_);
     if (block_rows == 64)
         return pm_launch<4, 128, 1, 1>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, s);
-    if (g_gp_knobs[7] == 1)                               // 8 waves x (16 rows x 256 columns): tuning reference
-        return pm_launch<8, 256, 1, 1>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, s);
     return pm_launch<8, 256, 2, 2>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, s);
 }

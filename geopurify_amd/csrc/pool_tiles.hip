@@ -222,7 +222,7 @@ size_t scan64_tmp(int64_t n) {
 
 }  // namespace
 
-extern int g_gp_knobs[8];
+extern int g_gp_knobs[16];
 #define g_pool_nf4 g_gp_knobs[1]
 #define g_pool_unroll g_gp_knobs[2]
 

@@ -432,7 +432,7 @@ size_t scan_tmp32(int64_t n) {
 
 }  // namespace
 
-extern int g_gp_knobs[8];
+extern int g_gp_knobs[16];
 #define g_conv_ablate g_gp_knobs[3]
 
 extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {

@@ -240,7 +240,7 @@ class HotPath:
     constants (affinity_module.py:1492-1493,1584-1587) exposed as options."""
 
     def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda",
-                 pool_mode="tiles", pool_tile_rows=8, pool_block_rows=64):
+                 pool_mode="auto", pool_tile_rows=8, pool_block_rows=64):
         self.student = student
         self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
         self.mask_shape = tuple(mask_shape)
@@ -354,17 +354,31 @@ class HotPath:
         E = st.forward(X, nbr_map)
         nbr = ops.knn_lattice(grid, cs, perm, self.K)
         w = ops.affinity_softmax(E, nbr, self.sharpen)
-        bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
-        cur = X
+        self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12
+        out = self._pool(X, nbr, w, Nv, D)
+        out = ops.gather_rows(out, D, batch.scene_inds_reconstruct, row_map=rank)
+        self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8),
+                      "pool_kernel": self._pool_kernel}
+        return out
+
+    def _pool(self, X, nbr, w, Nv, D):
+        """Row 12: num_iters applications of the row-stochastic affinity operator (affinity_module.py:1575-1587).
+        pool_mode: "auto" (matrix cores when the shape allows, else tiles, else ELL), "mfma", "tiles", "blocks", "ell"."""
+        dev = X.device
+        mode = self.pool_mode
+        mfma_ok = D == 512 and self.pool_block_rows * self.K <= 16384 and self.num_iters >= 1
         R = self.pool_tile_rows
-        use_tiles = self.pool_mode in ("tiles", "blocks") and self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
-        tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
-        blocks = None
-        if use_tiles and self.pool_mode == "blocks" and R == 8 and D == 512:
-            blocks = ops.pool_blocks_build(tiles)
-            if not blocks.ok:
-                blocks = None
-        if self.pool_mode == "mfma" and D == 512 and self.pool_block_rows * self.K <= 16384 and self.num_iters >= 1:
+        tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
+        if mode == "auto":
+            mode = "mfma" if (mfma_ok and self.num_iters >= 3) else ("tiles" if tiles_ok else "ell")
+        if mode == "mfma" and not mfma_ok:
+            raise ValueError(f"pool_mode='mfma' needs D == 512 and block_rows*K <= 16384 (D={D}, K={self.K})")
+        bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
+        if self.num_iters == 0:
+            bufs[0].copy_(X[:, :D])
+            self._pool_kernel = "none"
+            return bufs[0]
+        if mode == "mfma":
             # matrix-core pooling: operands stay split (hi, lo) f16 between applications, fp32 only at the end
             op = ops.pool_mfma_build(nbr, w, self.pool_block_rows)
             sp = [ops.split_f16(X, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))]
@@ -372,9 +386,16 @@ class HotPath:
                 last = t == self.num_iters - 1
                 ops.pool_mfma_apply(sp[t % 2], op, D, out_split=None if last else sp[(t + 1) % 2],
                                     out_f32=bufs[0] if last else None)
-            out = ops.gather_rows(bufs[0], D, batch.scene_inds_reconstruct, row_map=rank)
-            self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8)}
-            return out
+            self._pool_kernel = "pool_mfma_kernel"
+            return bufs[0]
+        use_tiles = mode in ("tiles", "blocks") and tiles_ok
+        tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
+        blocks = None
+        if use_tiles and mode == "blocks" and R == 8 and D == 512:
+            blocks = ops.pool_blocks_build(tiles)
+            if not blocks.ok:
+                blocks = None
+        cur = X
         for t in range(self.num_iters):
             if blocks is not None:
                 ops.pool_blocks_apply(cur, blocks, D, bufs[t % 2])
@@ -383,9 +404,8 @@ class HotPath:
             else:
                 ops.pool_ell(cur, nbr, w, D, bufs[t % 2])
             cur = bufs[t % 2]
-        out = ops.gather_rows(cur, D, batch.scene_inds_reconstruct, row_map=rank)
-        self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8)}
-        return out
+        self._pool_kernel = "pool_blocks_kernel" if blocks is not None else ("pool_tiles_kernel" if use_tiles else "pool_ell_kernel")
+        return cur
 
     def evaluate_scene(self, batch: SceneBatch, vlm):
         if isinstance(vlm, DenseFeatureVLM):

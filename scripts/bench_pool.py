@@ -56,14 +56,19 @@ print("blocks ok", blocks.ok, "block union rows/row", (int(blocks.bu_off[-1]) / 
 variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4] + [("blocks (64 rows share LDS x)", "blocks")]
 mf = {}
 for BR in (64, 128):
+    mf[BR] = ops.pool_mfma_build(nbr, w, BR); torch.cuda.synchronize()
     t0 = time.time(); mf[BR] = ops.pool_mfma_build(nbr, w, BR); torch.cuda.synchronize()
-    print(f"mfma BR={BR}: union rows/row (padded) {mf[BR].total / Nv:.2f}  build {1e3 * (time.time() - t0):.2f} ms", flush=True)
+    print(f"mfma BR={BR}: union rows/row (padded) {mf[BR].total / Nv:.2f}  build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
+for R in (8,):
+    t0 = time.time(); ops.pool_tiles_build(nbr, w, R); torch.cuda.synchronize()
+    print(f"tiles R={R}: build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
-variants += [("mfma64 f16x3 (split out)", ("mfma", 64)), ("mfma64 f16x3 (fp32 out)", ("mfma32", 64)),
-             ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0)), ("mfma128 8w x (16r x 256c) (split out)", ("mfma", 128, 1))]
+variants += [("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
+             ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0))]
 ABL = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # pool_mfma ablation bits (timing only, results invalid)
 lib.gp_debug_set(4, ABL)
+lib.gp_debug_set(9, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
 if len(sys.argv) > 1:                                   # e.g. "mfma": only variants whose name contains the word
     variants = [v for v in variants if sys.argv[1] in v[0]]
 res = {}
@@ -72,9 +77,10 @@ for rnd in range(3):
         if v is None:
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
         elif v[0] == "mfma":
-            lib.gp_debug_set(7, v[2] if len(v) > 2 else 0)
+            lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
         elif v[0] == "mfma32":
+            lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_f32=Y))
         elif v == "blocks":
             t = timeit(lambda: ops.pool_blocks_apply(X, blocks, D, Y))

@@ -56,6 +56,32 @@ def test_refine_stage_given_oracle_lift(env):
     assert d < 1e-4, d                                    # north_star: pooled features within 1e-4 fp32
 
 
+@pytest.fixture(scope="module")
+def env512(env):
+    """The same tiny scene with 512-d features (the shape the tiled and matrix-core pooling kernels serve)."""
+    import dataclasses
+    pl, syn = env["pl"], env["syn"]
+    cfg = dataclasses.replace(env["cfg"], feat_dim=512)
+    vlm_np = syn.make_vlm_outputs(cfg, cfg.num_views, 322)
+    sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=128, embed=128, num_blocks=1, seed=5)
+    K, T = 32, 4
+    ref = o_pipe.evaluate_scene_oracle(env["scene"], vlm_np, sd, env["rigid"], K=K, num_iters=T)
+    return dict(cfg=cfg, sd=sd, ref=ref, K=K, T=T)
+
+
+@pytest.mark.parametrize("pool_mode,block_rows", [("auto", 64), ("mfma", 64), ("mfma", 128), ("tiles", 64), ("ell", 64)])
+def test_refine_every_pooling_kernel_d512(env, env512, pool_mode, block_rows):
+    """rows 8-12 at D = 512 through each pooling kernel (matrix-core, tiled, ELL): same oracle, same tolerance."""
+    pl, b, ref = env["pl"], env["batch"], env512["ref"]
+    hp = pl.HotPath(pl.StudentWeights(env512["sd"], "cuda"), env512["cfg"].mask_shape, K=env512["K"],
+                    num_iters=env512["T"], device="cuda", pool_mode=pool_mode, pool_block_rows=block_rows)
+    out = hp.refine(b, ref["lifted"].cuda().contiguous())
+    d = (out.cpu() - ref["scene_features"]).abs().max()
+    assert d < 1e-4, d                                    # north_star: pooled features within 1e-4 fp32
+    want = {"auto": "pool_mfma_kernel", "mfma": "pool_mfma_kernel", "tiles": "pool_tiles_kernel", "ell": "pool_ell_kernel"}
+    assert hp.stats["pool_kernel"] == want[pool_mode]
+
+
 def test_end_to_end_features_and_labels(env):
     hp, b, pl, cfg, ref = env["hp"], env["batch"], env["pl"], env["cfg"], env["ref"]
     res = hp.evaluate_scene(b, pl.SyntheticVLM(env["vlm_np"], "cuda"))
