@@ -58,6 +58,24 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0      # dense f16/bf16 matrix-core peak, MI355X_MICROARCH.md
+
+
+def conv_roofline(timer):
+    """The student's 512->512 submanifold convolution layers (conv_phase1_dma_kernel + conv_phase2_kernel):
+    every fp32-class product is three f16 MFMAs (hi*hi + hi*lo + lo*hi), so the issued rate is 3 x the
+    algorithmic one; `frac` prices the ISSUED f16 flops against the dense f16 peak."""
+    r = timer.summary()
+    if r is None:
+        return None
+    ms, flop = r
+    issued = 3.0 * flop / (ms * 1e-3) / 1e12
+    return {"kernel": "conv_phase1_dma_kernel + conv_phase2_kernel (one 512->512 layer)", "bound": "mfma",
+            "achieved": round(issued, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / MFMA_F16_PEAK_TFLOPS, 4),
+            "algorithmic_tflops": round(flop / (ms * 1e-3) / 1e12, 1), "algorithmic_flop_per_layer": flop,
+            "avg_layer_ms": round(ms, 4)}
+
+
 def pmc_traffic(kernel, nv):
     """HBM-side bytes per launch of the pooling kernel from the committed rocprofv3 PMC passes
     (profiles/pool_pmc.json: FETCH_SIZE / WRITE_SIZE in KiB on an S-shaped voxel set, separate passes;
@@ -100,6 +118,38 @@ class PoolTimer:
 
     def mean_ms(self):
         return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else float("nan")
+
+
+class ConvTimer:
+    """HIP events around every 3x3x3 convolution layer of the student (both kernels of a layer)."""
+
+    def __init__(self):
+        self.events = []                                  # (e0, e1, cin, cout, pairs)
+        self.enabled = False
+
+    def wrap(self, ops):
+        timer, orig = self, ops.sparse_conv_f16x3
+
+        def timed(x, pairs, w_hi, w_lo, *a, **k):
+            if not timer.enabled:
+                return orig(x, pairs, w_hi, w_lo, *a, **k)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = orig(x, pairs, w_hi, w_lo, *a, **k)
+            e1.record(s)
+            timer.events.append((e0, e1, int(w_hi.shape[2]), int(w_hi.shape[1]), int(pairs.num_pairs)))
+            return r
+        ops.sparse_conv_f16x3 = timed
+
+    def summary(self):
+        """Layers with cin == cout == 512 (8 of the 9): mean time, fp32-equivalent and issued (3 x f16) TFLOP/s."""
+        ev = [(a.elapsed_time(b), ci, co, p) for a, b, ci, co, p in self.events if ci == co]
+        if not ev:
+            return None
+        ms = float(np.mean([e[0] for e in ev]))
+        flop = float(np.mean([2.0 * e[3] * e[1] * e[2] for e in ev]))
+        return ms, flop
 
 
 class StageTimer:
@@ -195,6 +245,8 @@ def main():
     counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device=dev)
     pool_timer = PoolTimer()
     pool_timer.wrap(ops)
+    conv_timer = ConvTimer()
+    conv_timer.wrap(ops)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
@@ -237,7 +289,7 @@ def main():
     barrier()
     log("timing")
     counts.zero_()
-    pool_timer.enabled = True
+    pool_timer.enabled = conv_timer.enabled = True
     stage = StageTimer()
     t0 = time.perf_counter()
     last = None
@@ -248,7 +300,7 @@ def main():
         dist.all_reduce(counts)                       # the one collective: int64 [3,C] IoU counts
     barrier()
     dt = time.perf_counter() - t0
-    pool_timer.enabled = False
+    pool_timer.enabled = conv_timer.enabled = False
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -287,6 +339,7 @@ def main():
                          "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4),
                          "avg_launch_ms_isolated": round(pool_ms_alone, 4),
                          "frac_isolated": round(pool_bytes / (pool_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline_conv": conv_roofline(conv_timer),
             "stages_ms_per_scene": {k: round(v / args.steps, 3) for k, v in stages.items()},
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
         }

@@ -399,7 +399,7 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
         const int idx = it * 64 + lane;
         const int row = idx / C4, c4 = idx % C4;
         const int64_t grow = row0 + row;
-        if (grow < nv) {
+        if (grow < nv && !(ablate & 16)) {      // tuning aid: bit 4 skips the output stores
             float xv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
             f16x4 h, l;
 #pragma unroll
