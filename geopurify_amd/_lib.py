@@ -24,6 +24,8 @@ SIGNATURES = {
     "gp_fnv_hash_f64": (c_int32, [_P, c_int64, _P, _P]),
     "gp_project_points_f64": (c_int32, [_P, c_int64, POINTER(c_double), c_double, c_double, c_double,
                                         c_double, _P, c_int32, c_int32, c_int32, c_double, _P, _P, _P]),
+    "gp_render_depth_f64": (c_int32, [_P, c_int64, POINTER(c_double), c_double, c_double, c_double, c_double,
+                                      c_int32, c_int32, c_int32, _P, _P]),
     "gp_morton_order_workspace_bytes": (c_size_t, [c_int64]),
     "gp_morton_order": (c_int32, [_P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gp_grid_bytes": (c_size_t, [c_int64, POINTER(c_int32)]),
@@ -58,6 +60,8 @@ SIGNATURES = {
     "gp_pool_mfma_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P]),
     "gp_pool_mfma_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),
+    "gp_lift_dense_bilinear_accum": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P,
+                                               c_int64, _P, _P]),
     "gp_lift_dense_finish": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "gp_lift_masks_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "gp_lift_masks_view": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32,

@@ -24,6 +24,42 @@ __global__ void lift_dense_accum_kernel(const float *__restrict__ feat2d, int d,
     if (lane == 0) cnt[p] += 1.0f;
 }
 
+// LSeg-style lift (affinity_module.py:404-433): the reference resizes the [D,h,w] feature map to the image size with
+// F.interpolate(bilinear, align_corners=True) and then samples it at the visible pixels; here the resize is evaluated
+// only at those pixels.  Arithmetic follows torch's CPU kernel to the bit: source = scale*i in fp32, lambda clipped to
+// [0,1], value = fma(w0, a, w1*b) per axis (rows of the two source lines first, then the two lines).
+__device__ __forceinline__ void bilinear_tap(float scale, int64_t i, int in_size, int &i0, int &i1, float &w0, float &w1) {
+    float real = scale * (float)i;
+    int f = (int)floorf(real);
+    i0 = f < in_size - 1 ? f : in_size - 1;
+    float lam = real - (float)i0;
+    lam = lam < 0.f ? 0.f : (lam > 1.f ? 1.f : lam);
+    i1 = i0 + 1 < in_size - 1 ? i0 + 1 : in_size - 1;
+    w0 = 1.f - lam;
+    w1 = lam;
+}
+__global__ void lift_dense_bilinear_accum_kernel(const float *__restrict__ feat, int d, int h, int w, float scale_h,
+                                                 float scale_w, const int64_t *__restrict__ pt,
+                                                 const int64_t *__restrict__ x, const int64_t *__restrict__ y, int64_t n_v,
+                                                 float *__restrict__ sum, int64_t ld_sum, float *__restrict__ cnt) {
+    int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (i >= n_v) return;
+    int lane = gp_lane();
+    int64_t p = pt[i];
+    int r0, r1, c0, c1;
+    float wr0, wr1, wc0, wc1;
+    bilinear_tap(scale_h, x[i], h, r0, r1, wr0, wr1);
+    bilinear_tap(scale_w, y[i], w, c0, c1, wc0, wc1);
+    int64_t plane = (int64_t)h * w;
+    for (int c = lane; c < d; c += 64) {
+        const float *f = feat + c * plane;
+        float top = __builtin_fmaf(wc0, f[(int64_t)r0 * w + c0], wc1 * f[(int64_t)r0 * w + c1]);
+        float bot = __builtin_fmaf(wc0, f[(int64_t)r1 * w + c0], wc1 * f[(int64_t)r1 * w + c1]);
+        sum[p * ld_sum + c] += __builtin_fmaf(wr0, top, wr1 * bot);
+    }
+    if (lane == 0) cnt[p] += 1.0f;
+}
+
 __global__ void lift_dense_finish_kernel(float *__restrict__ sum, int64_t ld_sum, int d, const float *__restrict__ cnt,
                                          int64_t n, uint8_t *__restrict__ seen) {
     int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
@@ -224,6 +260,21 @@ extern "C" int gp_lift_dense_accum(const float *feat2d, int32_t d, int32_t heigh
     if (n_v == 0) return GP_OK;
     lift_dense_accum_kernel<<<(int)((n_v * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat2d, d, height, width, pt,
                                                                                             x, y, n_v, sum, ld_sum, cnt);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_lift_dense_bilinear_accum(const float *feat, int32_t d, int32_t h, int32_t w, int32_t out_h, int32_t out_w,
+                                            const int64_t *pt, const int64_t *x, const int64_t *y, int64_t n_v, float *sum,
+                                            int64_t ld_sum, float *cnt, void *stream_) {
+    GP_CHECK_ARG(feat && pt && x && y && sum && cnt, "gp_lift_dense_bilinear_accum: null argument");
+    GP_CHECK_ARG(d > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, "gp_lift_dense_bilinear_accum: bad shape");
+    if (n_v == 0) return GP_OK;
+    // area_pixel_compute_scale<float>(in, out, align_corners=true): (in-1)/(out-1) in fp32, 0 for a single output pixel
+    const float sh = out_h > 1 ? (float)(h - 1) / (float)(out_h - 1) : 0.f;
+    const float sw = out_w > 1 ? (float)(w - 1) / (float)(out_w - 1) : 0.f;
+    lift_dense_bilinear_accum_kernel<<<(int)((n_v * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, d, h, w, sh, sw, pt, x, y,
+                                                                                                     n_v, sum, ld_sum, cnt);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -135,6 +135,29 @@ __global__ void project_kernel(const double *__restrict__ c, int64_t n, Mat44 M,
     }
 }
 
+// z-buffer of the cloud itself (fusion_util.py:126-130, depth given as a str): depth[v,u] = min z over the
+// points with z > 0.2 that project inside the cut bound; pixels nobody hits keep 999999.  Positive doubles
+// order like their bit patterns, so the minimum is an integer atomicMin (order-independent => exact).
+__global__ void depth_fill_kernel(double *__restrict__ depth, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) depth[i] = 999999.0;
+}
+__global__ void render_depth_kernel(const double *__restrict__ c, int64_t n, Mat44 M, double fx, double fy, double cx,
+                                    double cy, int W, int H, int cut, double *__restrict__ depth) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = c[i * 3], y = c[i * 3 + 1], z = c[i * 3 + 2];
+    double p0 = dot4_blas(M.m[0], x, y, z), p1 = dot4_blas(M.m[1], x, y, z), p2 = dot4_blas(M.m[2], x, y, z);
+    double u = (p0 * fx) / p2 + cx;
+    double v = (p1 * fy) / p2 + cy;
+    double ur = rint(u), vr = rint(v);
+    bool finite = (fabs(ur) < 9.0e15) && (fabs(vr) < 9.0e15);
+    long long ui = finite ? (long long)ur : -1, vi = finite ? (long long)vr : -1;
+    bool inside = finite && ui >= cut && vi >= cut && ui < (long long)W - cut && vi < (long long)H - cut;
+    if (inside && p2 > 0.2)
+        atomicMin(reinterpret_cast<unsigned long long *>(depth + vi * W + ui), (unsigned long long)__double_as_longlong(p2));
+}
+
 size_t sort_tmp_bytes(int64_t n) {
     size_t t = 0;
     (void)rocprim::radix_sort_pairs(nullptr, t, (uint64_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr,
@@ -218,6 +241,22 @@ extern "C" int gp_project_points_f64(const double *coords, int64_t n, const doub
         for (int k = 0; k < 4; ++k) M.m[a][k] = w2c_host[a * 4 + k];
     project_kernel<<<(int)((n + 255) / 256), 256, 0, gp_stream(stream_)>>>(coords, n, M, fx, fy, cx, cy, depth, width,
                                                                           height, cut_bound, vis_thres, mapping, weight);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_render_depth_f64(const double *coords, int64_t n, const double *w2c_host, double fx, double fy, double cx,
+                                   double cy, int32_t width, int32_t height, int32_t cut_bound, double *depth,
+                                   void *stream_) {
+    GP_CHECK_ARG(coords && w2c_host && depth && n > 0, "gp_render_depth_f64: null/empty argument");
+    GP_CHECK_ARG(width > 0 && height > 0, "gp_render_depth_f64: bad image size %dx%d", width, height);
+    Mat44 M;
+    for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < 4; ++k) M.m[a][k] = w2c_host[a * 4 + k];
+    hipStream_t s = gp_stream(stream_);
+    int64_t px = (int64_t)width * height;
+    depth_fill_kernel<<<(int)((px + 255) / 256), 256, 0, s>>>(depth, px);
+    render_depth_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(coords, n, M, fx, fy, cx, cy, width, height, cut_bound, depth);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

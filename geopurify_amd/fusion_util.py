@@ -30,8 +30,11 @@ def adjust_intrinsic(intrinsic, intrinsic_image_dim, image_dim):
 def _run(w2c, coords, depth, K, image_dim, cut, tau, want_weight):
     c = torch.as_tensor(np.ascontiguousarray(coords, dtype=np.float64)).cuda()
     if isinstance(depth, str):
-        raise NotImplementedError("depth='render' (z-buffer mode, fusion_util.py:126-130) is a SURVEY 8f 'next' row")
-    d = None if depth is None else torch.as_tensor(np.ascontiguousarray(depth, dtype=np.float64)).cuda()
+        if not want_weight:                              # only the ScanNet mapper has the render branch (:126-130)
+            raise TypeError("the Matterport mapper takes a depth map or None (fusion_util.py:45-82)")
+        d = ops.render_depth(c, w2c, K[0][0], K[1][1], K[0][2], K[1][2], image_dim[0], image_dim[1], cut)
+    else:
+        d = None if depth is None else torch.as_tensor(np.ascontiguousarray(depth, dtype=np.float64)).cuda()
     out = ops.project_points(c, w2c, K[0][0], K[1][1], K[0][2], K[1][2], d, image_dim[0], image_dim[1], cut, tau,
                              want_weight=want_weight)
     if want_weight:

@@ -80,6 +80,16 @@ def project_points(coords, w2c, fx, fy, cx, cy, depth, width, height, cut_bound,
     return (mapping, weight) if want_weight else mapping
 
 
+def render_depth(coords, w2c, fx, fy, cx, cy, width, height, cut_bound):
+    """z-buffer of the cloud (ScanNet mapper, depth given as a str: fusion_util.py:126-130) -> f64 [H,W]."""
+    lib = _lib.load()
+    _chk(coords, torch.float64, "coords")
+    depth = torch.empty((height, width), dtype=torch.float64, device=coords.device)
+    check(lib.gp_render_depth_f64(_ptr(coords), coords.shape[0], _dbl16(w2c), float(fx), float(fy), float(cx), float(cy),
+                                  int(width), int(height), int(cut_bound), _ptr(depth), _stream()), "gp_render_depth_f64")
+    return depth
+
+
 # ------------------------------------------------------------------------------------------ order / grid
 def morton_order(coords_i32):
     lib = _lib.load()
@@ -420,6 +430,15 @@ def lift_dense_accum(feat2d, pt, x, y, sum_, cnt):
     d, H, W = feat2d.shape
     check(lib.gp_lift_dense_accum(_ptr(feat2d), d, H, W, _ptr(pt), _ptr(x), _ptr(y), pt.shape[0], _ptr(sum_),
                                   sum_.stride(0), _ptr(cnt), _stream()), "gp_lift_dense_accum")
+
+
+def lift_dense_bilinear_accum(feat_lo, out_h, out_w, pt, x, y, sum_, cnt):
+    """LSeg path: feat_lo fp32 [D,h,w]; (x, y) index the [out_h, out_w] image the reference resizes the map to."""
+    lib = _lib.load()
+    d, h, w = feat_lo.shape
+    check(lib.gp_lift_dense_bilinear_accum(_ptr(feat_lo), d, h, w, int(out_h), int(out_w), _ptr(pt), _ptr(x), _ptr(y),
+                                           pt.shape[0], _ptr(sum_), sum_.stride(0), _ptr(cnt), _stream()),
+          "gp_lift_dense_bilinear_accum")
 
 
 def lift_dense_finish(sum_, d, cnt):

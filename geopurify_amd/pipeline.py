@@ -234,6 +234,18 @@ class DenseFeatureVLM:
         self.logit_scale = float(logit_scale)
 
 
+class LSegFeatureVLM:
+    """LSeg-style dense features at the network's own resolution: feat_lo [V,D,h,w] (the reference runs LSeg on a
+    320x240 resize and interpolates the output back to the image size, affinity_module.py:384-414)."""
+
+    def __init__(self, feat_lo, image_shape, text_embed, logit_scale, device="cuda"):
+        dev = torch.device(device)
+        self.feat_lo = torch.as_tensor(feat_lo).to(dev).contiguous()
+        self.image_shape = tuple(int(v) for v in image_shape)          # (H, W) of the images the pixels index
+        self.text_embed = torch.as_tensor(text_embed).to(dev)
+        self.logit_scale = float(logit_scale)
+
+
 # --------------------------------------------------------------------------------------------------
 class HotPath:
     """evaluate_scene on the device.  K, sharpen and num_iters are the reference's hard-coded
@@ -326,6 +338,22 @@ class HotPath:
         src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
         return ops.gather_rows(s, D, src), vlm.text_embed, vlm.logit_scale
 
+    def lift_lseg(self, batch: SceneBatch, vlm: LSegFeatureVLM):
+        """lift_lseg_features (affinity_module.py:348-452): bilinear(align_corners=True) resize of each view's
+        low-resolution map, sampled at the visible pixels, mean over views, unseen points <- nearest seen point."""
+        dev = self.device
+        N = batch.scene_coords.shape[0]
+        D = vlm.feat_lo.shape[1]
+        H, W = vlm.image_shape
+        s = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(N, dtype=torch.float32, device=dev)
+        for v in batch.views:
+            ops.lift_dense_bilinear_accum(vlm.feat_lo[v.src_view], H, W, v.pt, v.x, v.y, s, cnt)
+        seen = ops.lift_dense_finish(s, D, cnt)
+        nn = ops.nn1_masked(batch.scene_coords, seen, 1 - seen)
+        src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
+        return ops.gather_rows(s, D, src), vlm.text_embed, vlm.logit_scale
+
     # ---- rows 8-12 ------------------------------------------------------------------------------
     def refine(self, batch: SceneBatch, F):
         """evaluate_scene after the lift (affinity_module.py:1524-1589). F fp32 [N,D] -> [N,D]."""
@@ -408,7 +436,9 @@ class HotPath:
         return cur
 
     def evaluate_scene(self, batch: SceneBatch, vlm):
-        if isinstance(vlm, DenseFeatureVLM):
+        if isinstance(vlm, LSegFeatureVLM):
+            F, text, scale = self.lift_lseg(batch, vlm)
+        elif isinstance(vlm, DenseFeatureVLM):
             F, text, scale = self.lift_dense(batch, vlm)
         else:
             F, text, scale = self.lift_masks(batch, vlm)

@@ -64,6 +64,12 @@ int gp_project_points_f64(const double *coords, int64_t n, const double *w2c_hos
                           const double *depth, int32_t width, int32_t height,
                           int32_t cut_bound, double vis_thres,
                           int64_t *mapping, double *weight, void *stream);
+/* Depth "render" mode of the ScanNet mapper (fusion_util.py:126-130, compute_mapping(depth=<str>)):  */
+/* depth f64 [H,W] = 999999 everywhere, then the minimum camera-space z over the points with z > 0.2   */
+/* that project inside the cut bound; feed it to gp_project_points_f64 for the occlusion test.        */
+int gp_render_depth_f64(const double *coords, int64_t n, const double *w2c_host,
+                        double fx, double fy, double cx, double cy, int32_t width, int32_t height,
+                        int32_t cut_bound, double *depth, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Internal voxel order + lattice grid (shared by kernel-map build and kNN).                     */
@@ -214,6 +220,12 @@ int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const i
 int gp_lift_dense_accum(const float *feat2d, int32_t d, int32_t height, int32_t width,
                         const int64_t *pt, const int64_t *x, const int64_t *y, int64_t n_v,
                         float *sum, int64_t ld_sum, float *cnt, void *stream);
+/* gp_lift_dense_bilinear_accum: the LSeg path (affinity_module.py:404-433): feat f32 [d,h,w] is the network's    */
+/* low-resolution map; the reference's F.interpolate(bilinear, align_corners=True) to [out_h,out_w] is evaluated   */
+/* only at the sampled pixels (x = row, y = col of the full-size image), bit-identical to torch's CPU kernel.      */
+int gp_lift_dense_bilinear_accum(const float *feat, int32_t d, int32_t h, int32_t w, int32_t out_h, int32_t out_w,
+                                 const int64_t *pt, const int64_t *x, const int64_t *y, int64_t n_v,
+                                 float *sum, int64_t ld_sum, float *cnt, void *stream);
 /* gp_lift_dense_finish: out = sum / (cnt==0 ? 1e-6 : cnt); seen[p] = cnt > 1e-5 (u8).             */
 int gp_lift_dense_finish(float *sum, int64_t ld_sum, int32_t d, const float *cnt, int64_t n,
                          uint8_t *seen, void *stream);

@@ -127,6 +127,14 @@ def lift_dense(feat2d_views, point_idx_views, x_views, y_views, scene_coords):
     return out, seen
 
 
+def lift_lseg(feat_lo_views, image_shape, point_idx_views, x_views, y_views, scene_coords):
+    """affinity_module.py:404-452: each view's low-resolution map [D,h,w] is resized to the image size with
+    F.interpolate(bilinear, align_corners=True) (torch CPU here), then lifted exactly as lift_dense."""
+    full = [F.interpolate(f.unsqueeze(0), size=tuple(image_shape), mode="bilinear", align_corners=True).squeeze(0)
+            for f in feat_lo_views]
+    return lift_dense(full, point_idx_views, x_views, y_views, scene_coords)
+
+
 # --------------------------------------------------------------------------------------------
 # row 6: mask-embedding lift for one view
 # --------------------------------------------------------------------------------------------

@@ -47,7 +47,7 @@ def loader_math(scene, rigid, val_keep=10_000_000):
 
 
 def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=19, vectorised=True,
-                          dense_feat=None, timings=None, num_blocks=None, knn_impl="exact"):
+                          dense_feat=None, timings=None, num_blocks=None, knn_impl="exact", lseg_feat=None):
     """Returns dict(scene_features [N,D], text_features, logit_scale, + intermediates)."""
     cfg = scene.cfg
     t0 = time.perf_counter()
@@ -65,7 +65,11 @@ def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=1
     xyz32 = torch.from_numpy(scene.coords).float()
     text = torch.from_numpy(vlm["text_embed"])
     scale = float(vlm["logit_scale"])
-    if dense_feat is not None:
+    if lseg_feat is not None:                            # LSeg path: (feat_lo [V,D,h,w], image_shape (H,W))
+        feats = [torch.from_numpy(lseg_feat[0][v["src_view"]]) for v in ld["views"]]
+        Fp, _ = lift.lift_lseg(feats, lseg_feat[1], [v["pt"] for v in ld["views"]], [v["x"] for v in ld["views"]],
+                               [v["y"] for v in ld["views"]], xyz32)
+    elif dense_feat is not None:
         feats = [torch.from_numpy(dense_feat[v["src_view"]]) for v in ld["views"]]
         Fp, _ = lift.lift_dense(feats, [v["pt"] for v in ld["views"]], [v["x"] for v in ld["views"]],
                                 [v["y"] for v in ld["views"]], xyz32)

@@ -46,9 +46,20 @@ def _finish(p, pi, image_dim, cut, depth, tau):
     return mapping.T
 
 
+def render_depth(p, pi, image_dim, cut):
+    """fusion_util.py:126-130 (depth passed as a str): z-buffer of the cloud itself, 999999 where nothing lands."""
+    inside = ((pi[0] >= cut) * (pi[1] >= cut) * (pi[0] < image_dim[0] - cut) * (pi[1] < image_dim[1] - cut))
+    depth = np.ones((image_dim[1], image_dim[0])) * 999999
+    ok = inside & (p[2] > 0.2)
+    np.minimum.at(depth, (pi[1][ok], pi[0][ok]), p[2][ok])      # the reference's sequential loop keeps the minimum
+    return depth
+
+
 def compute_mapping_scannet(world_view_transform, coords, depth, K, image_dim, cut, tau):
     """fusion_util.py:99-147.  K is the already-rescaled intrinsics (scannet_intrinsics)."""
     p, pi = _project(np.asarray(world_view_transform).T, coords, K)
+    if isinstance(depth, str):
+        depth = render_depth(p, pi, image_dim, cut)
     mapping = _finish(p, pi, image_dim, cut, depth, tau)
     dist = np.sqrt((pi[0] - image_dim[0] / 2) ** 2 + (pi[1] - image_dim[1] / 2) ** 2)
     return mapping, np.exp(-dist / 10)

@@ -132,6 +132,11 @@ def gold_mapping():
                sn_tau=np.float64(0.05), sn_mapping=m, sn_weight=wgt, sn_z=z)
     m2, _ = mapper.compute_mapping(wvt, pts, None)
     out["sn_mapping_nodepth"] = m2
+    # ---- "render" mode (depth passed as a str): the z-buffer of the cloud itself; a denser cloud with points behind
+    #      each other along the rays (two shells) so that the buffer really occludes
+    pts_r = np.concatenate([pts, pts * np.array([1.0, 1.0, 1.0]) + 0.35 * (pts - np.array([1.5, -1.5, 1.0]))])
+    m3, _ = mapper.compute_mapping(wvt, pts_r, "render")
+    out.update(sn_points_render=pts_r, sn_mapping_render=m3)
     # ---- exact-arithmetic edge cases: identity pose, power-of-two focal
     Ke = make_intrinsic(256.0, 256.0, 64.0, 48.0)
     mapper_e = PointCloudToImageMapper((128, 96), 0.05, 10, Ke)   # cx,cy already half size

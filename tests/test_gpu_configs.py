@@ -60,3 +60,30 @@ def test_config_m_shape_matterport_mapper():
     counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device="cuda")
     hp.classify_and_count(res, batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
     assert int(counts[2].sum()) == int((scene.labels < cfg.num_classes).sum())
+
+
+def test_lseg_path_low_resolution_feature_maps():
+    """the LSeg-style lift (bilinear align_corners=True resize of the network's [D,h,w] map, evaluated
+    only at the visible pixels) through the whole scene path against the oracle (torch CPU F.interpolate)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from geopurify_amd import pipeline as pl
+    from geopurify_amd import synthetic as syn
+    cfg = dataclasses.replace(syn.CONFIGS["T"], feat_dim=32)
+    seed = 23
+    scene = syn.make_scene(cfg, seed)
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, seed)
+    sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=128, embed=128, num_blocks=1, seed=seed)
+    rng = np.random.default_rng(seed)
+    H, W = cfg.mask_shape
+    feat_lo = rng.normal(size=(cfg.num_views, cfg.feat_dim, 30, 40)).astype(np.float32)      # 4x below the image size
+    text = rng.normal(size=(cfg.num_classes, cfg.feat_dim)).astype(np.float32)
+    ref = o_pipe.evaluate_scene_oracle(scene, {"text_embed": text, "logit_scale": np.float32(14.0)}, sd, rigid, K=32,
+                                       num_iters=3, lseg_feat=(feat_lo, (H, W)))
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+    hp = pl.HotPath(pl.StudentWeights(sd, "cuda"), cfg.mask_shape, K=32, num_iters=3, device="cuda")
+    vlm = pl.LSegFeatureVLM(feat_lo, (H, W), text, 14.0, "cuda")
+    F, _, _ = hp.lift_lseg(batch, vlm)
+    assert (F.cpu() - ref["lifted"]).abs().max() <= 1e-6
+    res = hp.evaluate_scene(batch, vlm)
+    assert (res["scene_features"].cpu() - ref["scene_features"]).abs().max() < 1e-4

@@ -96,6 +96,16 @@ def test_project_golden_scannet(ops, golden_dir):
     m2 = ops.project_points(dev(g["sn_points"]), w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], None, W, H,
                             int(g["sn_cut"]), float(g["sn_tau"]))
     assert np.array_equal(m2.cpu().numpy(), g["sn_mapping_nodepth"])
+    # "render" mode: z-buffer of the cloud (atomicMin on the fp64 bit pattern), then the same occlusion test
+    from geopurify_amd.fusion_util import PointCloudToImageMapper
+    mapper = PointCloudToImageMapper((W, H), float(g["sn_tau"]), int(g["sn_cut"]), g["sn_K_native"])
+    m3, w3 = mapper.compute_mapping(g["sn_wvt"], g["sn_points_render"], "render")
+    assert np.array_equal(m3, g["sn_mapping_render"])
+    pr = dev(g["sn_points_render"])
+    d = ops.render_depth(pr, w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], W, H, int(g["sn_cut"]))
+    from oracle import project as o_proj
+    p_, pi_ = o_proj._project(w2c, g["sn_points_render"], K)
+    assert np.array_equal(d.cpu().numpy(), o_proj.render_depth(p_, pi_, (W, H), int(g["sn_cut"])))
 
 
 def test_project_golden_edges_and_matterport(ops, golden_dir):
@@ -294,6 +304,34 @@ def test_lift_dense(ops):
     nn = ops.nn1(dev(xyz)[seen].contiguous(), dev(xyz)[~seen].contiguous())
     s[~seen] = s[seen][nn]
     assert torch.equal(s.cpu(), ref)                                 # same order of fp32 adds -> bit exact
+
+
+def test_lift_lseg_bilinear_sampling(ops):
+    """LSeg path: the bilinear(align_corners=True) resize evaluated only at the sampled pixels equals
+    torch's CPU resize + lift to the bit (same fp32 operation order, fma form pinned in the kernel)."""
+    rng = np.random.default_rng(17)
+    N, D, h, w, H, W, V = 3000, 64, 24, 32, 61, 83, 3                  # odd output size: non-trivial fractional taps
+    xyz = torch.from_numpy(rng.normal(size=(N, 3)).astype(np.float32))
+    feats, pis, xs, ys = [], [], [], []
+    for v in range(V):
+        pi = np.sort(rng.choice(N - 100, 900, replace=False))
+        feats.append(torch.from_numpy(rng.normal(size=(D, h, w)).astype(np.float32)))
+        pis.append(torch.from_numpy(pi))
+        x = rng.integers(0, H, 900); y = rng.integers(0, W, 900)
+        x[:4] = [0, H - 1, 0, H - 1]; y[:4] = [0, 0, W - 1, W - 1]      # the four corners (clamped taps)
+        xs.append(torch.from_numpy(x)), ys.append(torch.from_numpy(y))
+    ref, seen_ref = o_lift.lift_lseg(feats, (H, W), pis, xs, ys, xyz)
+    s = torch.zeros((N, D), device="cuda")
+    cnt = torch.zeros(N, device="cuda")
+    for v in range(V):
+        ops.lift_dense_bilinear_accum(dev(feats[v]), H, W, dev(pis[v]), dev(xs[v]), dev(ys[v]), s, cnt)
+    seen = ops.lift_dense_finish(s, D, cnt).bool()
+    assert torch.equal(seen.cpu(), seen_ref)
+    nn = ops.nn1(dev(xyz)[seen].contiguous(), dev(xyz)[~seen].contiguous())
+    s[~seen] = s[seen][nn]
+    d = (s.cpu() - ref).abs().max().item()
+    assert d <= 1e-6, d                                               # tolerance 1e-6 (fp32); bit-exact where the host
+    assert (s.cpu() == ref).float().mean() > 0.999                    # libm/fma conventions agree (they do on x86-64 torch CPU)
 
 
 def test_nn1_exact(ops):

@@ -51,6 +51,12 @@ def test_mapping_scannet(golden_dir):
                                             int(g["sn_cut"]), float(g["sn_tau"]))
     assert np.array_equal(m2, g["sn_mapping_nodepth"])
     assert m[:, 2].sum() > 500
+    # depth passed as a str: z-buffer of the cloud itself (fusion_util.py:126-130)
+    m3, _ = project.compute_mapping_scannet(g["sn_wvt"], g["sn_points_render"], "render", K, dim,
+                                            int(g["sn_cut"]), float(g["sn_tau"]))
+    assert np.array_equal(m3, g["sn_mapping_render"])
+    n = len(g["sn_points"])
+    assert m3[:n, 2].sum() > 500 and m3[n:, 2].sum() < m3[:n, 2].sum() // 10     # the far shell is occluded
 
 
 def test_mapping_edge_cases(golden_dir):
