@@ -80,6 +80,17 @@ SIGNATURES = {
     "gp_visible_lists": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gp_classify_argmax": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_float, _P, _P, _P]),
     "gp_rows_argmax": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
+    "gp_col_stats_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "gp_col_stats": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
+    "gp_bn_train_apply": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64,
+                                    _P, _P, c_int64, c_float, _P, _P, _P]),
+    "gp_bn_train_backward": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64,
+                                       _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "gp_infonce_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "gp_infonce_fwd_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, c_int64, c_int32, c_float, _P, _P, c_int64,
+                                     _P, c_size_t, _P]),
+    "gp_adamw_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
+    "gp_knn_points_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "gp_iou_hist_i64": (c_int32, [_P, _P, c_int64, c_int32, POINTER(c_int64), c_int32, _P, _P]),
 }
 

@@ -581,3 +581,88 @@ def iou_hist(pred, target, num_classes, ignore_ids, counts):
     check(lib.gp_iou_hist_i64(_ptr(pred), _ptr(target), pred.shape[0], int(num_classes), ig, len(ignore_ids),
                               _ptr(counts), _stream()), "gp_iou_hist_i64")
     return counts
+
+
+# ------------------------------------------------------------------------------------------ training step
+def col_stats(y, c=None):
+    """mean, biased variance of the rows of y fp32 [nv, >=c] (BatchNorm1d training statistics)."""
+    lib = _lib.load()
+    nv = y.shape[0]
+    c = y.shape[1] if c is None else c
+    ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c), y.device)
+    mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    var = torch.empty(c, dtype=torch.float32, device=y.device)
+    check(lib.gp_col_stats(_ptr(y), y.stride(0), nv, int(c), _ptr(mean), _ptr(var), _ptr(ws), ws.numel(), _stream()), "gp_col_stats")
+    return mean, var
+
+
+def bn_train_apply(y, mean, var, gamma, beta, eps, residual=None, relu=True, want_split=False, momentum=0.1,
+                   running_mean=None, running_var=None):
+    lib = _lib.load()
+    nv, c = y.shape[0], mean.shape[0]
+    out = torch.empty((nv, c), dtype=torch.float32, device=y.device)
+    hi = lo = None
+    if want_split:
+        hi = torch.empty((nv, c), dtype=torch.float16, device=y.device)
+        lo = torch.empty((nv, c), dtype=torch.float16, device=y.device)
+    check(lib.gp_bn_train_apply(_ptr(y), y.stride(0), nv, int(c), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps),
+                                _ptr(residual), residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
+                                out.stride(0), _ptr(hi), _ptr(lo), hi.stride(0) if hi is not None else 0, float(momentum),
+                                _ptr(running_mean), _ptr(running_var), _stream()), "gp_bn_train_apply")
+    return out, ((hi, lo) if want_split else None)
+
+
+def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False):
+    """Returns dy, dgamma, dbeta (, dz).  act: post-ReLU activation (mask) or None."""
+    lib = _lib.load()
+    nv, c = y.shape[0], mean.shape[0]
+    dev = y.device
+    dy = torch.empty((nv, c), dtype=torch.float32, device=dev)
+    dz = torch.empty((nv, c), dtype=torch.float32, device=dev) if want_dz else None
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c) + 2 * c * 4 + 512, dev)
+    check(lib.gp_bn_train_backward(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y),
+                                   y.stride(0), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), nv, int(c), _ptr(dy), dy.stride(0),
+                                   _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(),
+                                   _stream()), "gp_bn_train_backward")
+    return (dy, dgamma, dbeta, dz) if want_dz else (dy, dgamma, dbeta)
+
+
+def infonce_fwd_bwd(e, sample_to_voxel, point_to_batch, num_anchors, num_negatives, temperature):
+    """loss (0-d device tensor) and d loss / d e of the InfoNCE over (anchor | positive | negatives) samples."""
+    lib = _lib.load()
+    nv, d = e.shape
+    ns = sample_to_voxel.shape[0]
+    _chk(sample_to_voxel, torch.int64, "sample_to_voxel")
+    _chk(point_to_batch, torch.int64, "point_to_batch")
+    assert point_to_batch.shape[0] == num_anchors * (2 + num_negatives)
+    loss = torch.empty((), dtype=torch.float32, device=e.device)
+    de = torch.empty((nv, d), dtype=torch.float32, device=e.device)
+    ws = _ws(lib.gp_infonce_workspace_bytes(ns, d), e.device)
+    check(lib.gp_infonce_fwd_bwd(_ptr(e), e.stride(0), nv, int(d), _ptr(sample_to_voxel), ns, _ptr(point_to_batch),
+                                 int(num_anchors), int(num_negatives), float(temperature), _ptr(loss), _ptr(de), de.stride(0),
+                                 _ptr(ws), ws.numel(), _stream()), "gp_infonce_fwd_bwd")
+    return loss, de
+
+
+def adamw_step_(param, grad, exp_avg, exp_avg_sq, lr, step, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8):
+    lib = _lib.load()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _chk(t, torch.float32, "adamw tensor")
+        assert t.is_contiguous() and t.numel() == param.numel()
+    check(lib.gp_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
+                            float(betas[1]), float(eps), float(weight_decay), int(step), _stream()), "gp_adamw_step")
+    return param
+
+
+def knn_points(xyz, queries, k):
+    """xyz fp32 [N,3]; queries i64 [A] row ids -> i64 [A,k] nearest other rows, (d^2, id) order."""
+    lib = _lib.load()
+    _chk(xyz, torch.float32, "xyz")
+    _chk(queries, torch.int64, "queries")
+    out = torch.empty((queries.shape[0], k), dtype=torch.int64, device=xyz.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=xyz.device)
+    check(lib.gp_knn_points_f32(_ptr(xyz), xyz.shape[0], _ptr(queries), queries.shape[0], int(k), _ptr(out), _ptr(flag),
+                                _stream()), "gp_knn_points_f32")
+    return out, flag

@@ -1,0 +1,239 @@
+"""Training step of the Student Affinity Network on the device.
+
+Mirrors models/affinity_module.py:1099-1237 (sample_contrastive_pairs_hybrid + SonataXAffinityTrainer.forward) and
+run/train.py:188-198,320-325,346-353 (AdamW with three parameter groups, LinearLR -> CosineAnnealingLR).
+
+What runs where:
+  * 3x3x3 convolutions, forward and data-gradient: gp_sparse_conv_f16x3 (dgrad = the same operator with weights
+    V[k] = W[26-k]^T; gradients are scaled by a power of two before the f16 hi/lo split so that they stay normal);
+  * BatchNorm(training), ReLU masks, InfoNCE forward+backward, AdamW, anchors' K nearest points: train.hip;
+  * weight gradients dW[k] = X[in_k]^T dY[out_k], the 512->128 output layer and the anchors x points similarity:
+    plain dense GEMMs through torch.matmul (rocBLAS) -- library GEMMs on gathered rows, not hand-written kernels;
+  * set logic (unique / argmax / topk of the sampler): torch device ops, as in the reference.
+The teacher (Sonata) is not available offline: its per-point features are an input tensor.
+Deviation: the voxel input is [mean lifted feature | mean geometry] (518 channels) as in
+evaluate_scene; the released forward feeds 512 channels into the 518-channel layer and cannot run.
+"""
+import math
+
+import torch
+
+from . import ops
+from .pipeline import CONV_PAD, GEO_DIM, _pad_to
+
+N_MACRO = 48                                   # affinity_module.py:1122
+GROUP_LR = {"input": 0.1, "middle": 1.0, "output": 5.0}          # run/train.py:193-195
+W_POW2 = 16.0                                  # weights (|w| << 1) are split as 16*w; undone by the scale vector
+
+
+def param_group(name):
+    return "input" if name.startswith("input_layer") else ("output" if name.startswith("output_layer") else "middle")
+
+
+def lr_schedule(step_index, base_lr, group, warmup_iters, main_iters):
+    """SequentialLR([LinearLR(1e-6 -> 1, warmup_iters), CosineAnnealingLR(T_max=main_iters, eta_min=base_lr*1e-3)])
+    evaluated in closed form for optimizer step number `step_index` (0-based) (run/train.py:320-325)."""
+    lr0 = base_lr * GROUP_LR[group]
+    if step_index < warmup_iters:
+        return lr0 * (1e-6 + (1.0 - 1e-6) * step_index / max(warmup_iters, 1))
+    t = min(step_index - warmup_iters, main_iters)
+    eta_min = base_lr * 1e-3
+    return eta_min + (lr0 - eta_min) * 0.5 * (1.0 + math.cos(math.pi * t / max(main_iters, 1)))
+
+
+# --------------------------------------------------------------------------------------------------
+def sample_contrastive_pairs_hybrid(F_teacher, neighbor_indices, anchor_indices, num_negatives):
+    """affinity_module.py:1113-1136 after the randperm (anchors are the caller's draw).  neighbor_indices i64 [A,K]
+    are the anchors' rows of the point kNN.  Returns positive [A], negative [A, num_negatives]."""
+    Fn = torch.nn.functional.normalize(F_teacher, p=2, dim=1)
+    sim = Fn[anchor_indices] @ Fn.t()
+    A, N = sim.shape
+    rows = torch.arange(A, device=sim.device)
+    pos_sim = sim.clone()
+    pos_sim[rows, anchor_indices] = float("-inf")
+    positive = torch.argmax(pos_sim, dim=1)
+    del pos_sim
+    sim[rows, anchor_indices] = float("inf")          # in place, as the reference (sim_matrix_neg aliases the matrix)
+    sim[rows, positive] = float("inf")
+    _, macro = torch.topk(sim, k=N_MACRO, largest=False, dim=1)
+    sims_local = torch.gather(sim, 1, neighbor_indices)
+    _, hardest = torch.topk(sims_local, k=num_negatives - N_MACRO, largest=False, dim=1)
+    micro = torch.gather(neighbor_indices, 1, hardest)
+    return positive, torch.cat([macro, micro], dim=1)
+
+
+# --------------------------------------------------------------------------------------------------
+class StudentTrainer:
+    """fp32 master weights of an AffinityPredictor (ME state_dict layout) + BatchNorm running statistics + AdamW
+    state, and the forward/backward of one scene."""
+
+    def __init__(self, state_dict, device="cuda", base_lr=1e-4, weight_decay=1e-5, temperature=0.07, bn_momentum=0.1,
+                 bn_eps=1e-5, warmup_iters=0, main_iters=1):
+        dev = torch.device(device)
+        self.device = dev
+        sd = {k: v.detach().clone() for k, v in state_dict.items()}
+        w0 = sd["input_layer.0.kernel"].float()
+        self.cin, self.hidden = w0.shape[1], w0.shape[2]
+        self.cin_pad = _pad_to(self.cin, CONV_PAD)
+        w0p = torch.zeros((27, self.cin_pad, self.hidden), dtype=torch.float32)
+        w0p[:, :self.cin] = w0
+        sd["input_layer.0.kernel"] = w0p
+        self.num_blocks = 0
+        while f"res_blocks.{self.num_blocks}.conv1.kernel" in sd:
+            self.num_blocks += 1
+        self.params, self.buffers = {}, {}
+        for k, v in sd.items():
+            if k.endswith("kernel") or k.endswith(".bn.weight") or k.endswith(".bn.bias"):
+                self.params[k] = v.float().to(dev).contiguous()
+            elif k.endswith("running_mean") or k.endswith("running_var"):
+                self.buffers[k] = v.float().to(dev).contiguous()
+        self.embed = self.params["output_layer.kernel"].shape[1]
+        self.base_lr, self.weight_decay, self.temperature = base_lr, weight_decay, temperature
+        self.bn_momentum, self.bn_eps = bn_momentum, bn_eps
+        self.warmup_iters, self.main_iters = warmup_iters, main_iters
+        self.opt_state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.params.items()}
+        self.steps_done = 0
+        self.fast = self.hidden % 256 == 0           # f16x3 matrix-core path; else the exact fp32 MFMA kernel
+
+    # ---- state_dict in the reference layout (input kernel un-padded) -----------------------------------
+    def state_dict(self):
+        out = {k: v.clone() for k, v in self.params.items()}
+        out["input_layer.0.kernel"] = out["input_layer.0.kernel"][:, :self.cin].contiguous()
+        out.update({k: v.clone() for k, v in self.buffers.items()})
+        return out
+
+    # ---- convolutions ---------------------------------------------------------------------------------
+    def _conv(self, x, x_split, w, ctx):
+        """raw submanifold convolution y = sum_k x[nbr_k] @ w[k] (no BN, no ReLU)."""
+        if self.fast and w.shape[2] % 256 == 0:
+            hi, lo = ops.conv_weights_split(w, W_POW2)
+            scale = ctx["inv_pow2"][w.shape[2]]
+            return ops.sparse_conv_f16x3(x, ctx["pairs"], hi, lo, scale, None, relu=False, x_split=x_split)
+        return ops.sparse_conv(x, ctx["nbr_map"], w)
+
+    def _dgrad(self, dy, w, ctx):
+        """dx = sum_k dy[nbr_k] @ w[26-k]^T."""
+        v = w.flip(0).transpose(1, 2).contiguous()
+        if self.fast and v.shape[2] % 256 == 0:
+            amax = dy.abs().amax().clamp_min(1e-30)
+            s = torch.exp2(torch.floor(torch.log2(1.0 / amax)))          # device scalar, no host sync
+            dys = dy * s
+            hi, lo = ops.conv_weights_split(v, W_POW2)
+            scale = ctx["inv_pow2"][v.shape[2]] / s
+            return ops.sparse_conv_f16x3(dys, ctx["pairs"], hi, lo, scale.contiguous(), None, relu=False, x_split=ops.split_f16(dys))
+        return ops.sparse_conv(dy, ctx["nbr_map"], v)
+
+    @staticmethod
+    def _wgrad(x, dy, ctx, cin):
+        """dW[k] = x[in_k]^T @ dy[out_k] (library GEMMs on gathered rows)."""
+        dw = torch.zeros((27, cin, dy.shape[1]), dtype=torch.float32, device=dy.device)
+        for k, (out_rows, in_rows) in enumerate(ctx["offset_pairs"]):
+            if out_rows.numel():
+                dw[k] = x[in_rows, :cin].t() @ dy[out_rows]
+        return dw
+
+    # ---- one scene: loss and gradients --------------------------------------------------------------
+    def forward_backward(self, X, nbr_map, sample_to_voxel, point_to_batch, num_anchors, num_negatives, update_running=True):
+        """X fp32 [Nv, cin_pad] voxel inputs (rows in the order of nbr_map i32 [27,Nv]); sample_to_voxel i64 [S];
+        point_to_batch i64 [A*(2+Nn)].  Returns (loss 0-d device tensor, grads dict, embeddings [Nv, embed])."""
+        P, B = self.params, self.buffers
+        dev = X.device
+        Nv = X.shape[0]
+        ctx = {"nbr_map": nbr_map, "pairs": ops.conv_pairs_build(nbr_map) if self.fast else None,
+               "inv_pow2": {c: torch.full((c,), 1.0 / W_POW2, dtype=torch.float32, device=dev) for c in {self.hidden}}}
+        ctx["offset_pairs"] = []
+        for k in range(27):
+            m = nbr_map[k]
+            out_rows = torch.nonzero(m >= 0).squeeze(1)
+            ctx["offset_pairs"].append((out_rows, m[out_rows].long()))
+        mom = self.bn_momentum
+
+        def bn_fwd(y, prefix, residual=None, want_split=True):
+            mean, var = ops.col_stats(y)
+            rm, rv = (B[prefix + ".bn.running_mean"], B[prefix + ".bn.running_var"]) if update_running else (None, None)
+            out, sp = ops.bn_train_apply(y, mean, var, P[prefix + ".bn.weight"], P[prefix + ".bn.bias"], self.bn_eps, residual=residual,
+                                         relu=True, want_split=want_split and self.fast, momentum=mom, running_mean=rm, running_var=rv)
+            return out, sp, (mean, var)
+
+        # ---------------- forward (activations kept for the backward pass)
+        saved = []
+        xs = ops.split_f16(X, self.cin_pad) if self.fast else None
+        y0 = self._conv(X, xs, P["input_layer.0.kernel"], ctx)
+        h, hs, st0 = bn_fwd(y0, "input_layer.1")
+        blocks = []
+        for i in range(self.num_blocks):
+            y1 = self._conv(h, hs, P[f"res_blocks.{i}.conv1.kernel"], ctx)
+            a1, a1s, st1 = bn_fwd(y1, f"res_blocks.{i}.norm1")
+            y2 = self._conv(a1, a1s, P[f"res_blocks.{i}.conv2.kernel"], ctx)
+            h2, h2s, st2 = bn_fwd(y2, f"res_blocks.{i}.norm2", residual=h)
+            blocks.append((h, y1, a1, st1, y2, st2, h2))
+            h, hs = h2, h2s
+        E = h @ P["output_layer.kernel"]
+        loss, dE = ops.infonce_fwd_bwd(E, sample_to_voxel, point_to_batch, num_anchors, num_negatives, self.temperature)
+
+        # ---------------- backward
+        g = {}
+        g["output_layer.kernel"] = h.t() @ dE
+        dh = dE @ P["output_layer.kernel"].t()
+        for i in reversed(range(self.num_blocks)):
+            h_in, y1, a1, st1, y2, st2, h_out = blocks[i]
+            dy2, dg2, db2, dz = ops.bn_train_backward(dh, h_out, y2, st2[0], st2[1], self.bn_eps, P[f"res_blocks.{i}.norm2.bn.weight"],
+                                                      want_dz=True)
+            g[f"res_blocks.{i}.norm2.bn.weight"], g[f"res_blocks.{i}.norm2.bn.bias"] = dg2, db2
+            g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, dy2, ctx, self.hidden)
+            da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx)
+            dy1, dg1, db1 = ops.bn_train_backward(da1, a1, y1, st1[0], st1[1], self.bn_eps, P[f"res_blocks.{i}.norm1.bn.weight"])
+            g[f"res_blocks.{i}.norm1.bn.weight"], g[f"res_blocks.{i}.norm1.bn.bias"] = dg1, db1
+            g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, dy1, ctx, self.hidden)
+            dh = dz + self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx)
+        h0 = blocks[0][0] if self.num_blocks else h
+        dy0, dg0, db0 = ops.bn_train_backward(dh, h0, y0, st0[0], st0[1], self.bn_eps, P["input_layer.1.bn.weight"])
+        g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
+        g["input_layer.0.kernel"] = self._wgrad(X, dy0, ctx, self.cin_pad)
+        return loss, g, E
+
+    # ---- optimizer ---------------------------------------------------------------------------------------
+    def optimizer_step(self, grads):
+        """AdamW (run/train.py:198) with the three learning-rate groups and the warm-up/cosine schedule."""
+        self.steps_done += 1
+        for name, p in self.params.items():
+            lr = lr_schedule(self.steps_done - 1, self.base_lr, param_group(name), self.warmup_iters, self.main_iters) \
+                if (self.warmup_iters or self.main_iters > 1) else self.base_lr * GROUP_LR[param_group(name)]
+            m, v = self.opt_state[name]
+            ops.adamw_step_(p, grads[name].contiguous(), m, v, lr, self.steps_done, weight_decay=self.weight_decay)
+
+    # ---- one scene of the reference's forward (everything after the lift) -------------------------------------
+    def scene_step(self, F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, anchor_indices, num_negatives=63, K=96,
+                   optimize=True):
+        """F_lift fp32 [N,D] lifted 2D features, gauss fp32 [N,6], inds_reconstruct i64 [N] point -> voxel row,
+        coords_3d [Nv,3] integer voxel coordinates (float or int), xyz fp32 [N,3], F_teacher fp32 [N,Dt],
+        anchor_indices i64 [A] (the reference's randperm draw).  Returns dict(loss, ...)."""
+        dev = self.device
+        nbrs, flag = ops.knn_points(xyz.contiguous(), anchor_indices, K)
+        positive, negative = sample_contrastive_pairs_hybrid(F_teacher, nbrs, anchor_indices, num_negatives)
+        if int(flag.item()):
+            raise RuntimeError("knn_points: degenerate duplicate points around an anchor")
+        A = anchor_indices.shape[0]
+        all_idx, point_to_batch = torch.unique(torch.cat([anchor_indices, positive, negative.flatten()]), return_inverse=True)
+        vox = inds_reconstruct[all_idx]
+        uniq_vox, sample_to_voxel = torch.unique(vox, return_inverse=True)
+        # voxel subset in Morton order (kernel map, conv tiles and BN are order-independent up to fp32 summation order)
+        cs_ref = coords_3d[uniq_vox].floor().to(torch.int32).contiguous()
+        perm, rank = ops.morton_order(cs_ref)
+        cs = cs_ref[perm.long()].contiguous()
+        s2v = rank.long()[sample_to_voxel].contiguous()
+        order = torch.sort(s2v, stable=True).indices
+        Nvs = cs.shape[0]
+        seg = torch.zeros(Nvs + 1, dtype=torch.int64, device=dev)
+        seg[1:] = torch.bincount(s2v, minlength=Nvs).cumsum(0)
+        D = F_lift.shape[1]
+        X = torch.zeros((Nvs, self.cin_pad), dtype=torch.float32, device=dev)
+        ops.scatter_mean_csr(F_lift[all_idx].contiguous(), D, order, seg, Nvs, X, col0=0)
+        ops.scatter_mean_csr(gauss[all_idx].contiguous(), GEO_DIM, order, seg, Nvs, X, col0=D)
+        grid = ops.grid_build(cs)
+        nbr_map = ops.kernel_map_build(grid, cs)
+        loss, grads, E = self.forward_backward(X, nbr_map, s2v, point_to_batch.contiguous(), A, num_negatives)
+        if optimize:
+            self.optimizer_step(grads)
+        return {"loss": loss, "grads": grads, "num_voxels": Nvs, "num_samples": int(all_idx.shape[0]), "positive": positive,
+                "negative": negative, "neighbors": nbrs, "perm": perm, "uniq_vox": uniq_vox, "embeddings": E}

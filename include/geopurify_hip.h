@@ -295,6 +295,43 @@ int gp_iou_hist_i64(const int64_t *pred, const int64_t *target, int64_t n, int32
                     const int64_t *ignore_ids_host, int32_t num_ignore, int64_t *counts,
                     void *stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* training step of the student (models/affinity_module.py:1138-1237,                */
+/* run/train.py:188-198,346-353).  Convolutions forward / dgrad reuse gp_sparse_conv_f16x3 (dgrad   */
+/* = the same operator with weights V[k] = W[26-k]^T); these are the remaining pieces.              */
+/* gp_col_stats: mean / biased variance of the rows (BatchNorm1d in training mode over voxel rows). */
+size_t gp_col_stats_workspace_bytes(int64_t nv, int32_t c);
+int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, float *mean, float *var,
+                 void *workspace, size_t workspace_bytes, void *stream);
+/* out = [relu]((y-mean)/sqrt(var+eps)*gamma + beta [+ residual]); out_hi/out_lo: optional split f16 */
+/* copy for the next convolution; running_mean/var (nullable) <- (1-m)*running + m*batch (unbiased var). */
+int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, const float *var,
+                      const float *gamma, const float *beta, float eps, const float *residual, int64_t ld_res,
+                      int32_t relu, float *out, int64_t ld_out, void *out_hi, void *out_lo, int64_t ld_split,
+                      float momentum, float *running_mean, float *running_var, void *stream);
+/* dz = dout*(act>0) (act NULL: no mask); dgamma = sum dz*xhat; dbeta = sum dz;                       */
+/* dy = gamma/sqrt(var+eps)*(dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) <- dz.                */
+/* workspace: gp_col_stats_workspace_bytes(nv, c) + 2*c*4 (rounded up to 256).                        */
+int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y,
+                         int64_t ld_y, const float *mean, const float *var, float eps, const float *gamma,
+                         int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz,
+                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+/* InfoNCE (affinity_module.py:1219-1233) forward + backward: samples s -> voxel rows sample_to_voxel[s]; */
+/* point_to_batch i64 [A*(2+Nn)] = sample ids of (anchors | positives | negatives row-major).           */
+/* loss f32 device scalar; de f32 [nv, d] = d loss / d e (overwritten).                                  */
+size_t gp_infonce_workspace_bytes(int64_t num_samples, int32_t d);
+int gp_infonce_fwd_bwd(const float *e, int64_t ld_e, int64_t nv, int32_t d, const int64_t *sample_to_voxel,
+                       int64_t num_samples, const int64_t *point_to_batch, int64_t num_anchors,
+                       int32_t num_negatives, float temperature, float *loss, float *de, int64_t ld_de,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* torch.optim.AdamW update of one flat fp32 tensor (run/train.py:198), step >= 1.                      */
+int gp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step, void *stream);
+/* K nearest other points of each query row (faiss.IndexFlatL2.search(K+1)[:,1:], affinity_module.py:1157-1166), */
+/* order (d^2 in fp64 of the fp32 coordinates, row id); *flag_dev != 0: degenerate duplicates, result invalid.   */
+int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *queries, int64_t num_queries, int32_t k,
+                      int64_t *out, int32_t *flag_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

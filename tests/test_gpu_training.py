@@ -1,0 +1,197 @@
+"""training step of the student (BatchNorm in training mode, InfoNCE, conv dgrad/wgrad, AdamW, the
+anchors' point kNN and the contrastive sampler) against the torch-autograd CPU oracle (oracle/train.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import student as o_student  # noqa: E402
+from oracle import train as o_train  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from geopurify_amd import ops as _ops
+    return _ops
+
+
+def dev(x):
+    return (torch.from_numpy(x) if isinstance(x, np.ndarray) else x).cuda().contiguous()
+
+
+def surface_voxels(rng, n):
+    """unique integer voxels on a few planes (27-neighbourhood occupancy like a scanned room)."""
+    pts = []
+    while len(pts) < n:
+        a, b = rng.integers(0, 60, 2)
+        pts.append((a, b, 5) if rng.random() < 0.5 else (a, 7, b))
+    return np.unique(np.array(pts, dtype=np.int64), axis=0)[:n]
+
+
+# ------------------------------------------------------------------------------------------ kernels
+def test_batchnorm_training_forward_backward(ops):
+    torch.manual_seed(0)
+    nv, c = 3001, 192
+    y = torch.randn(nv, c) * 2 + 0.5
+    res = torch.randn(nv, c)
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    rm, rv = torch.zeros(c), torch.ones(c)
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    out_ref = F.relu(F.batch_norm(yr, rm_ref, rv_ref, gr, br, training=True, momentum=0.1, eps=1e-5) + res)
+    dout = torch.randn(nv, c)
+    out_ref.backward(dout)
+    mean, var = ops.col_stats(dev(y))
+    assert (mean.cpu() - y.mean(0)).abs().max() < 1e-6 and (var.cpu() - y.var(0, unbiased=False)).abs().max() < 1e-5
+    rmd, rvd = dev(rm), dev(rv)
+    out, sp = ops.bn_train_apply(dev(y), mean, var, dev(gamma), dev(beta), 1e-5, residual=dev(res), relu=True, want_split=True,
+                                 momentum=0.1, running_mean=rmd, running_var=rvd)
+    assert (out.cpu() - out_ref.detach()).abs().max() < 1e-5
+    assert ((sp[0].float() + sp[1].float()) - out).abs().max() < 1e-6
+    assert (rmd.cpu() - rm_ref).abs().max() < 1e-6 and (rvd.cpu() - rv_ref).abs().max() < 1e-5
+    dy, dg, db, dz = ops.bn_train_backward(dev(dout), out, dev(y), mean, var, 1e-5, dev(gamma), want_dz=True)
+    assert (dy.cpu() - yr.grad).abs().max() < 1e-5
+    assert (dg.cpu() - gr.grad).abs().max() < 2e-3 and (db.cpu() - br.grad).abs().max() < 2e-3      # sums of 3001 terms
+    assert torch.equal(dz.cpu(), dout * (out_ref.detach() > 0))
+
+
+def test_infonce_forward_backward(ops):
+    torch.manual_seed(1)
+    nv, d, S, A, Nn = 500, 128, 700, 96, 63
+    E = torch.randn(nv, d)
+    s2v = torch.randint(0, nv, (S,))
+    p2b = torch.randint(0, S, (A * (2 + Nn),))
+    Er = E.clone().requires_grad_(True)
+    loss_ref = o_train.info_nce(Er[s2v], p2b, A, Nn, 0.07)
+    loss_ref.backward()
+    loss, dE = ops.infonce_fwd_bwd(dev(E), dev(s2v), dev(p2b), A, Nn, 0.07)
+    assert abs(float(loss) - float(loss_ref.detach())) < 1e-5 * max(1.0, abs(float(loss_ref.detach())))
+    assert (dE.cpu() - Er.grad).abs().max() < 1e-6 + 1e-4 * Er.grad.abs().max()
+
+
+def test_adamw_matches_torch(ops):
+    torch.manual_seed(2)
+    p0 = torch.randn(10007)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=3e-4, weight_decay=1e-5)
+    p, m, v = dev(p0.clone()), torch.zeros(10007, device="cuda"), torch.zeros(10007, device="cuda")
+    for step in range(1, 4):
+        g = torch.randn(10007)
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adamw_step_(p, dev(g), m, v, 3e-4, step, weight_decay=1e-5)
+    assert (p.cpu() - p_ref.detach()).abs().max() < 1e-6
+
+
+def test_knn_points_exact(ops):
+    rng = np.random.default_rng(3)
+    xyz = (rng.random((20000, 3)) * np.array([7, 5, 2.6])).astype(np.float32)
+    xyz[100] = xyz[50]                                               # an exact duplicate pair (distance 0 tie by id)
+    q = np.concatenate([[50, 100], rng.choice(20000, 200, replace=False)]).astype(np.int64)
+    out, flag = ops.knn_points(dev(xyz), dev(q), 96)
+    assert int(flag.item()) == 0
+    assert np.array_equal(out.cpu().numpy(), o_train.knn_points_bruteforce(xyz, q, 96))
+
+
+# ------------------------------------------------------------------------------------------ student forward/backward
+def _setup_student(hidden, num_blocks, seed, cin=38, nvox=1500, S=1200, A=64, Nn=63):
+    from geopurify_amd import pipeline as pl
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    coords = surface_voxels(rng, nvox)
+    nv = len(coords)
+    sd = pl.random_student_state_dict(cin, hidden=hidden, embed=128, num_blocks=num_blocks, seed=seed)
+    X = torch.randn(nv, cin) * 0.5
+    s2v = torch.randint(0, nv, (S,))
+    p2b = torch.randint(0, S, (A * (2 + Nn),))
+    return coords, sd, X, s2v, p2b, A, Nn
+
+
+@pytest.mark.parametrize("hidden,num_blocks", [(128, 1), (256, 2)])
+def test_student_training_step_matches_autograd(ops, hidden, num_blocks):
+    """loss, every gradient, the AdamW-updated weights and the BatchNorm running statistics of one step.
+    hidden=128: exact fp32 MFMA convolutions; hidden=256: the f16x3 matrix-core path (forward and dgrad)."""
+    from geopurify_amd.training import StudentTrainer
+    coords, sd, X, s2v, p2b, A, Nn = _setup_student(hidden, num_blocks, seed=5)
+    ref = o_train.train_step_oracle(sd, X, coords, s2v, p2b, A, Nn, 0.07, num_blocks, base_lr=1e-3, weight_decay=1e-2)
+    tr = StudentTrainer(sd, "cuda", base_lr=1e-3, weight_decay=1e-2)
+    cs_ref = dev(coords.astype(np.int32))
+    perm, rank = ops.morton_order(cs_ref)
+    cs = cs_ref[perm.long()].contiguous()
+    Xd = torch.zeros((len(coords), tr.cin_pad), device="cuda")
+    Xd[:, :X.shape[1]] = dev(X)[perm.long()]
+    nbr_map = ops.kernel_map_build(ops.grid_build(cs), cs)
+    loss, grads, E = tr.forward_backward(Xd, nbr_map, rank.long()[dev(s2v)].contiguous(), dev(p2b), A, Nn)
+    assert abs(float(loss) - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"]))
+    E_ref = ref["embeddings"]
+    assert (E.cpu()[rank.long().cpu()] - E_ref).abs().max() < 1e-3 * E_ref.abs().max()
+    for name, g_ref in ref["grads"].items():
+        g = grads[name].cpu()
+        if name == "input_layer.0.kernel":
+            assert float(g[:, X.shape[1]:].abs().max()) == 0.0        # padded input channels never receive gradient
+            g = g[:, :X.shape[1]]
+        err = (g - g_ref).abs().max() / (g_ref.abs().max() + 1e-12)
+        assert err < 5e-3, (name, float(err))                         # tolerance: fp32 sums in different orders, 2-5 layers deep
+    tr.optimizer_step(grads)
+    new = tr.state_dict()
+    for name, p_ref in ref["params"].items():
+        d = (new[name].cpu() - p_ref).abs()
+        # the first AdamW step moves a weight by lr * g / (|g| + 1e-8): where |g| is far above the 1e-8 epsilon the
+        # update is +-lr whatever the gradient's rounding; near zero it is ill-conditioned and only bounded by lr
+        g_ref = ref["grads"][name]
+        well = g_ref.abs() > 1e-5
+        assert d[well].max() < 2e-6 if well.any() else True, (name, float(d[well].max()))
+        assert d.max() <= 2.02e-3 * o_train.PARAM_GROUP_LR[o_train.param_group(name)], (name, float(d.max()))   # opposite signs at most
+    for prefix, (rm, rv) in ref["bn"].items():
+        assert (new[prefix + ".bn.running_mean"].cpu() - rm).abs().max() < 1e-4
+        assert (new[prefix + ".bn.running_var"].cpu() - rv).abs().max() < 1e-4
+
+
+def test_scene_training_step_end_to_end(ops):
+    """sampler (point kNN + teacher similarities) + voxel subset + student step on a tiny scene; the oracle is fed the
+    device's own anchors and replays everything else."""
+    from geopurify_amd import pipeline as pl
+    from geopurify_amd import synthetic as syn
+    from geopurify_amd.training import StudentTrainer
+    cfg = syn.CONFIGS["T"]
+    scene = syn.make_scene(cfg, 77)
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, 77)
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+    N = batch.scene_coords.shape[0]
+    g = torch.Generator().manual_seed(9)
+    D, Dt, A, Nn, K = 32, 48, 128, 63, 96
+    F_lift = torch.randn(N, D, generator=g)
+    F_teacher = torch.randn(N, Dt, generator=g)
+    anchors = torch.randperm(N, generator=g)[:A]
+    sd = pl.random_student_state_dict(D + pl.GEO_DIM, hidden=128, embed=128, num_blocks=1, seed=3)
+    tr = StudentTrainer(sd, "cuda", base_lr=1e-3)
+    xyz = batch.scene_coords.float().contiguous()
+    out = tr.scene_step(dev(F_lift), batch.scene_gauss_features, batch.scene_inds_reconstruct, batch.scene_coords_3d, xyz,
+                        dev(F_teacher), dev(anchors), num_negatives=Nn, K=K, optimize=False)
+    # ---- sampler parity
+    nbr_ref = o_train.knn_points_bruteforce(xyz.cpu().numpy(), anchors.numpy(), K)
+    assert np.array_equal(out["neighbors"].cpu().numpy(), nbr_ref)
+    pos_ref, neg_ref, _ = o_train.sample_pairs(F_teacher, torch.from_numpy(nbr_ref), anchors, Nn)
+    assert (out["positive"].cpu() == pos_ref).float().mean() > 0.98          # argmax / top-k near-ties inside GEMM rounding
+    same = [len(set(a.tolist()) & set(b.tolist())) for a, b in zip(out["negative"].cpu(), neg_ref)]
+    assert np.mean(same) > 0.98 * Nn
+    # ---- everything downstream of the sampler, replayed by the oracle on the device's own samples
+    pos, neg = out["positive"].cpu(), out["negative"].cpu()
+    inv = batch.scene_inds_reconstruct.cpu()
+    all_idx, p2b, uniq_vox, s2v = o_train.build_sample_sets(anchors, pos, neg, inv)
+    gauss = batch.scene_gauss_features.cpu()
+    Xv = torch.cat([o_train.scatter_mean_rows(F_lift[all_idx], s2v, len(uniq_vox)),
+                    o_train.scatter_mean_rows(gauss[all_idx], s2v, len(uniq_vox))], dim=1)
+    coords_v = batch.scene_coords_3d.cpu()[uniq_vox].floor().long().numpy()
+    ref = o_train.train_step_oracle(sd, Xv, coords_v, s2v, p2b, A, Nn, 0.07, 1)
+    assert out["num_voxels"] == len(uniq_vox) and out["num_samples"] == len(all_idx)
+    assert abs(float(out["loss"]) - ref["loss"]) < 2e-4 * max(1.0, abs(ref["loss"]))
+    for name in ("output_layer.kernel", "res_blocks.0.conv1.kernel", "input_layer.1.bn.weight"):
+        g_ref = ref["grads"][name]
+        gd = out["grads"][name].cpu()
+        assert (gd - g_ref).abs().max() / (g_ref.abs().max() + 1e-12) < 5e-3, name
