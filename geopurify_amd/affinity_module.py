@@ -89,7 +89,7 @@ class SonataXAffinityTrainer(nn.Module):
     use_lseg=True (dense-feature lift)."""
 
     def __init__(self, cfg, xdecoder_cfg=None, scene_config=None, device="cuda", use_lseg=True, vlm=None,
-                 feature_dim=512, embed_dim=128, hidden_dim=512):
+                 feature_dim=512, embed_dim=128, hidden_dim=512, teacher=None):
         super().__init__()
         self.cfg = cfg
         self.device = device
@@ -104,6 +104,10 @@ class SonataXAffinityTrainer(nn.Module):
         self.K = 96                               # :1492
         self.affinity_sharpen_factor = 20         # :1493
         self.num_pool_iters = 19                  # :1584-1587 (1 + 18)
+        self.teacher = teacher                    # stand-in for get_sonata_features (:995-1063)
+        self.num_anchors_per_scene = 4096         # :277
+        self.num_negatives_per_anchor = 63        # :278
+        self.info_nce_temperature = 0.07          # :279
 
     def _hot_path(self):
         dev = torch.device(self.device if self.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
@@ -142,5 +146,26 @@ class SonataXAffinityTrainer(nn.Module):
         return hp.evaluate_scene(batch, self.vlm)
 
     def forward(self, batch_data):
-        raise NotImplementedError("training step (Sonata-teacher distillation, affinity_module.py:1138-1237) is a "
-                                  "SURVEY.md 8f 'next' row; this round covers the inference hot path")
+        """Training forward (affinity_module.py:1138-1237): lift (no grad) -> teacher features -> contrastive sampling
+        -> student on the sampled voxels (BatchNorm in training mode) -> InfoNCE.  Returns the loss; `.backward()`
+        fills the student's gradients (HIP backward pass), so run/train.py's loop applies unchanged.
+        The Sonata teacher is not available offline: pass `teacher=callable(batch) -> [N, Dt]` to the constructor."""
+        from . import training
+        if self.vlm is None or self.teacher is None:
+            raise RuntimeError("training needs a 2D VLM (vlm=...) and a teacher (teacher=callable(batch) -> [N,Dt]); "
+                               "X-Decoder and Sonata themselves are out of scope")
+        dev = torch.device(self.device if self.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        hp = HotPath(None, tuple(self.cfg["mask_shape"] if isinstance(self.cfg, dict) else self.cfg.mask_shape), device=dev)   # lift only
+        batch = batch_data if isinstance(batch_data, SceneBatch) else self._batch_from_tuple(batch_data, hp.device)
+        with torch.no_grad():
+            if isinstance(self.vlm, pipeline.LSegFeatureVLM):
+                F_lift, _, _ = hp.lift_lseg(batch, self.vlm)
+            elif isinstance(self.vlm, pipeline.DenseFeatureVLM):
+                F_lift, _, _ = hp.lift_dense(batch, self.vlm)
+            else:
+                F_lift, _, _ = hp.lift_masks(batch, self.vlm)
+            F_teacher = self.teacher(batch).to(F_lift.device).float().contiguous()
+        return training.training_forward(self.affinity_student, F_lift, batch.scene_gauss_features, batch.scene_inds_reconstruct,
+                                         batch.scene_coords_3d, batch.scene_coords.float().contiguous(), F_teacher,
+                                         num_anchors=self.num_anchors_per_scene, num_negatives=self.num_negatives_per_anchor,
+                                         temperature=self.info_nce_temperature, K=self.K)

@@ -91,7 +91,7 @@ class StudentTrainer:
         self.base_lr, self.weight_decay, self.temperature = base_lr, weight_decay, temperature
         self.bn_momentum, self.bn_eps = bn_momentum, bn_eps
         self.warmup_iters, self.main_iters = warmup_iters, main_iters
-        self.opt_state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.params.items()}
+        self.opt_state = {}                          # name -> (exp_avg, exp_avg_sq), allocated on the first optimizer step
         self.steps_done = 0
         self.fast = self.hidden % 256 == 0           # f16x3 matrix-core path; else the exact fp32 MFMA kernel
 
@@ -199,6 +199,8 @@ class StudentTrainer:
         for name, p in self.params.items():
             lr = lr_schedule(self.steps_done - 1, self.base_lr, param_group(name), self.warmup_iters, self.main_iters) \
                 if (self.warmup_iters or self.main_iters > 1) else self.base_lr * GROUP_LR[param_group(name)]
+            if name not in self.opt_state:
+                self.opt_state[name] = (torch.zeros_like(p), torch.zeros_like(p))
             m, v = self.opt_state[name]
             ops.adamw_step_(p, grads[name].contiguous(), m, v, lr, self.steps_done, weight_decay=self.weight_decay)
 
@@ -237,3 +239,47 @@ class StudentTrainer:
             self.optimizer_step(grads)
         return {"loss": loss, "grads": grads, "num_voxels": Nvs, "num_samples": int(all_idx.shape[0]), "positive": positive,
                 "negative": negative, "neighbors": nbrs, "perm": perm, "uniq_vox": uniq_vox, "embeddings": E}
+
+
+class _LossWithGradients(torch.autograd.Function):
+    """Hands the gradients computed by the HIP backward pass to torch.autograd, so that the reference's training loop
+    (`loss = model(batch); loss.backward(); optimizer.step()`, run/train.py:346-353) runs unchanged."""
+
+    @staticmethod
+    def forward(ctx, loss, grads, *params):
+        ctx.grads = grads
+        return loss.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(g * gr for gr in ctx.grads)
+
+
+def training_forward(student_module, F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, num_anchors=4096,
+                     num_negatives=63, temperature=0.07, K=96, anchor_indices=None):
+    """SonataXAffinityTrainer.forward after the lift and the teacher (affinity_module.py:1157-1233) for an
+    AffinityPredictor-shaped nn.Module whose parameters live on the device.  Returns the loss as a tensor whose
+    .backward() fills the parameters' .grad; BatchNorm running statistics are updated in place."""
+    dev = F_lift.device
+    N = F_lift.shape[0]
+    A = min(num_anchors, N // 3)
+    if anchor_indices is None:
+        anchor_indices = torch.randperm(N, device=dev)[:A]               # affinity_module.py:1112
+    named = dict(student_module.named_parameters())
+    tr = StudentTrainer(student_module.state_dict(), dev, temperature=temperature,
+                        bn_momentum=student_module.input_layer[1].bn.momentum, bn_eps=student_module.input_layer[1].bn.eps)
+    out = tr.scene_step(F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, anchor_indices, num_negatives, K, optimize=False)
+    names = [n for n in named if n in out["grads"]]
+    grads = []
+    for n in names:
+        g = out["grads"][n]
+        if n == "input_layer.0.kernel":
+            g = g[:, :tr.cin].contiguous()
+        grads.append(g.view_as(named[n]))
+    with torch.no_grad():
+        for k, b in student_module.named_buffers():
+            if k in tr.buffers:
+                b.copy_(tr.buffers[k])
+            elif k.endswith("num_batches_tracked"):
+                b += 1
+    return _LossWithGradients.apply(out["loss"], grads, *[named[n] for n in names])

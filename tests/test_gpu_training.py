@@ -195,3 +195,43 @@ def test_scene_training_step_end_to_end(ops):
         g_ref = ref["grads"][name]
         gd = out["grads"][name].cpu()
         assert (gd - g_ref).abs().max() / (g_ref.abs().max() + 1e-12) < 5e-3, name
+
+
+def test_reference_training_loop_surface(ops):
+    """run/train.py:188-198,346-353 unchanged: optimizer from get_param_groups(), `loss = model(batch)`,
+    `loss.backward()`, `optimizer.step()` -- the gradients come from the HIP backward pass."""
+    from geopurify_amd import pipeline as pl
+    from geopurify_amd import synthetic as syn
+    from geopurify_amd.affinity_module import SonataXAffinityTrainer
+    cfg = syn.CONFIGS["T"]
+    scene = syn.make_scene(cfg, 78)
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, 78)
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+    vlm = pl.SyntheticVLM(syn.make_vlm_outputs(cfg, cfg.num_views, 78), "cuda")
+    N = batch.scene_coords.shape[0]
+    torch.manual_seed(11)
+    teacher_feats = torch.randn(N, 40, device="cuda")
+    model = SonataXAffinityTrainer({"mask_shape": cfg.mask_shape, "all_label": ["c%d" % i for i in range(cfg.num_classes)]},
+                                   device="cuda", use_lseg=False, vlm=vlm, feature_dim=cfg.feat_dim, hidden_dim=128,
+                                   teacher=lambda b: teacher_feats).to("cuda")
+    model.num_anchors_per_scene = 256
+    groups = model.affinity_student.get_param_groups()
+    base_lr = 1e-3
+    opt = torch.optim.AdamW([{"params": groups["input"], "lr": base_lr * 0.1}, {"params": groups["middle"], "lr": base_lr},
+                             {"params": groups["output"], "lr": base_lr * 5.0}], weight_decay=1e-5)
+    model.train()
+    w_before = model.affinity_student.output_layer.kernel.detach().clone()
+    rm_before = model.affinity_student.input_layer[1].bn.running_mean.clone()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model(batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and 2.0 < losses[0] < 6.0            # ~log(64) = 4.16 at random init
+    for p in model.affinity_student.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert not torch.equal(model.affinity_student.output_layer.kernel.detach(), w_before)
+    assert not torch.equal(model.affinity_student.input_layer[1].bn.running_mean, rm_before)
+    assert int(model.affinity_student.input_layer[1].bn.num_batches_tracked) == 3
