@@ -48,14 +48,20 @@ __global__ void __launch_bounds__(256) cs_var_kernel(const float *__restrict__ y
                                                      const float *__restrict__ mean, double *__restrict__ partial) {
     col_partial<1>(nv, c, partial, [&](int64_t r, int col, double *v) { double d = (double)y[r * ld + col] - (double)mean[col]; v[0] = d * d; });
 }
-// out[q][c] = scale * sum over chunks
-__global__ void cs_final_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c, double scale, float *__restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq * c) return;
-    int q = i / c, col = i % c;
+// out[q][c] = scale * sum over chunks: one workgroup per 64 columns, the chunks strided over 4 waves (fixed order)
+__global__ void __launch_bounds__(256) cs_final_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c, double scale,
+                                                       float *__restrict__ out) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                 // flat (q, col)
     double s = 0.0;
-    for (int64_t k = 0; k < nchunks; ++k) s += partial[(k * nq + q) * c + col];
-    out[i] = (float)(s * scale);
+    if (i < nq * c) {
+        const int q = i / c, col = i % c;
+        for (int64_t k = wv; k < nchunks; k += 4) s += partial[(k * nq + q) * c + col];
+    }
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && i < nq * c) out[i] = (float)((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale);
 }
 
 // ------------------------------------------------------------------------------------------------ BN forward / backward
@@ -287,9 +293,9 @@ extern "C" int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, f
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
     cs_sum_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
-    cs_final_kernel<<<(c + 255) / 256, 256, 0, s>>>(partial, nch, 1, c, 1.0 / (double)nv, mean);
+    cs_final_kernel<<<(c + 63) / 64, 256, 0, s>>>(partial, nch, 1, c, 1.0 / (double)nv, mean);
     cs_var_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, mean, partial);
-    cs_final_kernel<<<(c + 255) / 256, 256, 0, s>>>(partial, nch, 1, c, 1.0 / (double)nv, var);
+    cs_final_kernel<<<(c + 63) / 64, 256, 0, s>>>(partial, nch, 1, c, 1.0 / (double)nv, var);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -327,7 +333,7 @@ extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const fl
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
     bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
-    cs_final_kernel<<<(2 * c + 255) / 256, 256, 0, s>>>(partial, nch, 2, c, 1.0, sums);
+    cs_final_kernel<<<(2 * c + 63) / 64, 256, 0, s>>>(partial, nch, 2, c, 1.0, sums);
     int64_t n = nv * c;
     bn_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, nv, c,
                                                                      dy, ld_dy, dz_out, ld_dz);

@@ -102,3 +102,43 @@ def test_validation_driver_cli_and_dataset_name(tmp_path):
     assert validation.get_dataset_name("/x/matterport_3d_160") == "matterport"
     with pytest.raises(ValueError):
         validation.get_dataset_name("data/nuscenes")
+
+
+def test_lr_schedule_matches_torch_sequential_lr():
+    """run/train.py:320-325: LinearLR(1e-6 -> 1) for warmup_iters, then CosineAnnealingLR(eta_min = base_lr*1e-3),
+    three groups at 0.1x / 1x / 5x the base rate."""
+    import warnings
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+    from geopurify_amd.training import lr_schedule
+    base, warm, main = 1e-4, 6, 20
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(3)]
+    opt = torch.optim.AdamW([{"params": [ps[0]], "lr": base * 0.1}, {"params": [ps[1]], "lr": base}, {"params": [ps[2]], "lr": base * 5.0}])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sched = SequentialLR(opt, schedulers=[LinearLR(opt, start_factor=1e-6, end_factor=1.0, total_iters=warm),
+                                              CosineAnnealingLR(opt, T_max=main, eta_min=base * 1e-3)], milestones=[warm])
+        for step in range(warm + main):
+            got = [lr_schedule(step, base, g, warm, main) for g in ("input", "middle", "output")]
+            want = [g["lr"] for g in opt.param_groups]
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-12), (step, got, want)
+            opt.step()
+            sched.step()
+
+
+def test_oracle_adamw_is_torch_adamw():
+    """the oracle's written-out AdamW (oracle/train.py) against torch.optim.AdamW, three steps."""
+    from oracle import train as o_train
+    torch.manual_seed(0)
+    p0 = {"res_blocks.0.conv1.kernel": torch.randn(3, 4, 5), "output_layer.kernel": torch.randn(5, 2)}
+    ref = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    opt = torch.optim.AdamW([{"params": [ref["res_blocks.0.conv1.kernel"]], "lr": 1e-3}, {"params": [ref["output_layer.kernel"]], "lr": 5e-3}],
+                            weight_decay=1e-2)
+    cur, state = {k: v.clone() for k, v in p0.items()}, {}
+    for step in range(1, 4):
+        grads = {k: torch.randn_like(v) for k, v in p0.items()}
+        for k in ref:
+            ref[k].grad = grads[k].clone()
+        opt.step()
+        cur = o_train.adamw_step(cur, grads, state, step, 1e-3, 1e-2)
+    for k in ref:
+        assert (cur[k] - ref[k].detach()).abs().max() < 1e-6

@@ -77,3 +77,36 @@ def test_two_rank_gloo_allreduce_equals_single_process():
     lines = sharding.log_lines(s)
     assert lines[3].startswith("Val 2d result: mIoU_Base/mAcc_Base/allAcc_Base ") and len(lines) == 9
     assert 0 < s["All"]["mIoU"] < 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {"b.kernel": torch.randn(27, 6, 8, generator=g), "a.bn.weight": torch.randn(8, generator=g), "c.kernel": torch.randn(8, 4, generator=g)}
+    sharding.allreduce_mean_gradients(grads)
+    q.put((rank, {k: v.numpy().copy() for k, v in grads.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_is_the_mean():
+    """Training step, N > 1: one bucketed all-reduce of the student gradients, averaged (DDP semantics)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    want = {}
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        for k, shape in (("b.kernel", (27, 6, 8)), ("a.bn.weight", (8,)), ("c.kernel", (8, 4))):
+            want[k] = want.get(k, 0) + torch.randn(*shape, generator=g).numpy() / 2
+    for r in range(2):
+        for k in want:
+            assert np.allclose(res[r][k], want[k], atol=1e-6)
