@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams: consecutive scenes alternate streams so that one scene's\n                    loader/lift kernels overlap the previous scene's pooling tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step rate (extra object `training_step`)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -74,6 +75,34 @@ def conv_roofline(timer):
             "achieved": round(issued, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / MFMA_F16_PEAK_TFLOPS, 4),
             "algorithmic_tflops": round(flop / (ms * 1e-3) / 1e12, 1), "algorithmic_flop_per_layer": flop,
             "avg_layer_ms": round(ms, 4)}
+
+
+def training_step_rate(batch, dev, sd, steps=3):
+    """SURVEY 8f-1 (BASELINE config 5 shape): optimisation steps per second of the student on the bench scene --
+    4096 anchors x (1 + 63) samples, teacher features [N, 1088] synthetic, lifted features random unit rows
+    (the lift itself is timed by the headline metric), sampler + forward + backward + AdamW inside the timed region."""
+    from geopurify_amd import training
+    N = batch.scene_coords.shape[0]
+    g = torch.Generator(device=dev).manual_seed(1)
+    F_lift = torch.nn.functional.normalize(torch.randn(N, 512, device=dev, generator=g), dim=1)
+    F_teacher = torch.randn(N, 1088, device=dev, generator=g)
+    tr = training.StudentTrainer(sd, dev, base_lr=1e-4, weight_decay=1e-5, warmup_iters=10, main_iters=1000)
+    xyz = batch.scene_coords.float().contiguous()
+
+    def one():
+        anchors = torch.randperm(N, device=dev)[:4096]
+        o = tr.scene_step(F_lift, batch.scene_gauss_features, batch.scene_inds_reconstruct, batch.scene_coords_3d, xyz, F_teacher,
+                          anchors, num_negatives=63, K=96, optimize=True)
+        return o
+    o = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(1.0 / dt, 3), "unit": "optimizer steps/s (1 scene per step)", "ms_per_step": round(dt * 1e3, 2),
+            "sampled_voxels": int(o["num_voxels"]), "loss": round(float(o["loss"]), 4), "data": "synthetic teacher + lifted features"}
 
 
 def pmc_traffic(kernel, nv):
@@ -344,6 +373,11 @@ def main():
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
         }
         log(f"gpu: {out['value']} scenes/s, {out['ms_per_step']} ms/scene; pooling {pool_ms:.3f} ms/launch")
+        if not args.no_train and world == 1 and cfg.feat_dim == 512:
+            try:                                  # an extra; never lose the headline line over it
+                out["training_step"] = training_step_rate(last, dev, sd)
+            except Exception as e:
+                out["training_step"] = {"value": None, "error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (bounded sample of the oracle on the host cores)")
             try:

@@ -89,6 +89,9 @@ SIGNATURES = {
     "gp_infonce_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "gp_infonce_fwd_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, c_int64, c_int32, c_float, _P, _P, c_int64,
                                      _P, c_size_t, _P]),
+    "gp_conv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "gp_conv_wgrad_f16x3": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
+                                      _P, _P, _P, c_size_t, _P]),
     "gp_adamw_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "gp_knn_points_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "gp_iou_hist_i64": (c_int32, [_P, _P, c_int64, c_int32, POINTER(c_int64), c_int32, _P, _P]),

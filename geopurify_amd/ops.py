@@ -666,3 +666,52 @@ def knn_points(xyz, queries, k):
     check(lib.gp_knn_points_f32(_ptr(xyz), xyz.shape[0], _ptr(queries), queries.shape[0], int(k), _ptr(out), _ptr(flag),
                                 _stream()), "gp_knn_points_f32")
     return out, flag
+
+
+class WgradPlan:
+    """Pair lists of one voxel set in the layout of gp_conv_wgrad_f16x3 (shared by every 3x3x3 layer of a step)."""
+
+    def __init__(self, pair_in, pair_out, segs, seg_off, num_segments, nv):
+        self.pair_in, self.pair_out, self.segs, self.seg_off, self.num_segments, self.nv = pair_in, pair_out, segs, seg_off, num_segments, nv
+        self.workspace = None
+
+
+def wgrad_plan_build(offset_pairs, nv, steps_per_segment=128):
+    """offset_pairs: list over the kernel offsets of (out_rows i64, in_rows i64) device tensors (host knows the sizes)."""
+    dev = offset_pairs[0][0].device
+    pin, pout, segs, seg_off = [], [], [], [0]
+    step0 = 0
+    for k, (out_rows, in_rows) in enumerate(offset_pairs):
+        n = int(out_rows.numel())
+        pad = (-n) % 32
+        pin.append(in_rows.to(torch.int32))
+        pout.append(out_rows.to(torch.int32))
+        if pad:
+            pin.append(torch.zeros(pad, dtype=torch.int32, device=dev))
+            pout.append(torch.full((pad,), nv, dtype=torch.int32, device=dev))
+        steps = (n + pad) // 32
+        for s in range(0, steps, steps_per_segment):
+            segs.append((k, step0 + s, min(steps_per_segment, steps - s), 0))
+        seg_off.append(len(segs))
+        step0 += steps
+    return WgradPlan(torch.cat(pin).contiguous(), torch.cat(pout).contiguous(),
+                     torch.tensor(segs, dtype=torch.int32, device=dev).contiguous(),
+                     torch.tensor(seg_off, dtype=torch.int32, device=dev), len(segs), nv)
+
+
+def conv_wgrad_f16x3(x_split, y_split, plan, cin_pad, cin_out, cout, inv_scale=None):
+    """x_split (hi, lo) f16 [nv, >=cin_pad]; y_split (hi, lo) f16 [nv+1, >=cout] whose last row is zero."""
+    lib = _lib.load()
+    xh, xl = x_split
+    yh, yl = y_split
+    assert yh.shape[0] == plan.nv + 1 and xh.shape[0] >= plan.nv
+    need = lib.gp_conv_wgrad_workspace_bytes(plan.num_segments, int(cin_pad), int(cout))
+    if plan.workspace is None or plan.workspace.numel() < need:
+        plan.workspace = _ws(need, xh.device)
+    kv = plan.seg_off.shape[0] - 1
+    dw = torch.empty((kv, cin_out, cout), dtype=torch.float32, device=xh.device)
+    check(lib.gp_conv_wgrad_f16x3(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(yh), _ptr(yl), yh.stride(0), _ptr(plan.pair_in),
+                                  _ptr(plan.pair_out), _ptr(plan.segs), plan.num_segments, _ptr(plan.seg_off), kv, int(cin_pad),
+                                  int(cin_out), int(cout), _ptr(inv_scale), _ptr(dw), _ptr(plan.workspace), plan.workspace.numel(),
+                                  _stream()), "gp_conv_wgrad_f16x3")
+    return dw

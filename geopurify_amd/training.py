@@ -111,22 +111,36 @@ class StudentTrainer:
             return ops.sparse_conv_f16x3(x, ctx["pairs"], hi, lo, scale, None, relu=False, x_split=x_split)
         return ops.sparse_conv(x, ctx["nbr_map"], w)
 
-    def _dgrad(self, dy, w, ctx):
+    def _grad_split(self, dy):
+        """dY scaled by a power of two (device scalar, no host sync) so that 1e-6-sized gradients are normal f16
+        numbers, split into hi/lo with one extra all-zero row (the target of the padded pairs of the weight gradient).
+        Returns (scaled fp32 rows, (hi, lo) [nv+1, c], 1/scale as a 1-element device tensor)."""
+        nv, c = dy.shape
+        amax = dy.abs().amax().clamp_min(1e-30)
+        s = torch.exp2(torch.floor(torch.log2(1.0 / amax)))
+        dys = torch.zeros((nv + 1, c), dtype=torch.float32, device=dy.device)
+        dys[:nv] = dy * s
+        return dys, ops.split_f16(dys), (1.0 / s).reshape(1).contiguous()
+
+    def _dgrad(self, dy, w, ctx, gs=None):
         """dx = sum_k dy[nbr_k] @ w[26-k]^T."""
         v = w.flip(0).transpose(1, 2).contiguous()
         if self.fast and v.shape[2] % 256 == 0:
-            amax = dy.abs().amax().clamp_min(1e-30)
-            s = torch.exp2(torch.floor(torch.log2(1.0 / amax)))          # device scalar, no host sync
-            dys = dy * s
+            dys, (hi_y, lo_y), inv_s = gs if gs is not None else self._grad_split(dy)
+            nv = dy.shape[0]
             hi, lo = ops.conv_weights_split(v, W_POW2)
-            scale = ctx["inv_pow2"][v.shape[2]] / s
-            return ops.sparse_conv_f16x3(dys, ctx["pairs"], hi, lo, scale.contiguous(), None, relu=False, x_split=ops.split_f16(dys))
+            scale = (ctx["inv_pow2"][v.shape[2]] * inv_s).contiguous()
+            return ops.sparse_conv_f16x3(dys[:nv], ctx["pairs"], hi, lo, scale, None, relu=False, x_split=(hi_y[:nv], lo_y[:nv]))
         return ops.sparse_conv(dy, ctx["nbr_map"], v)
 
-    @staticmethod
-    def _wgrad(x, dy, ctx, cin):
-        """dW[k] = x[in_k]^T @ dy[out_k] (library GEMMs on gathered rows)."""
-        dw = torch.zeros((27, cin, dy.shape[1]), dtype=torch.float32, device=dy.device)
+    def _wgrad(self, x, x_split, dy, ctx, cin, gs=None):
+        """dW[k] = x[in_k]^T @ dy[out_k]: matrix-core kernel (gp_conv_wgrad_f16x3) when the shapes allow (cin >= 256,
+        cout a multiple of 256), else library GEMMs on gathered rows."""
+        cout = dy.shape[1]
+        if self.fast and x_split is not None and cin >= 256 and cout % 256 == 0:
+            _, ysplit, inv_s = gs if gs is not None else self._grad_split(dy)
+            return ops.conv_wgrad_f16x3(x_split, ysplit, ctx["wgrad_plan"], cin, cin, cout, inv_scale=inv_s)
+        dw = torch.zeros((27, cin, cout), dtype=torch.float32, device=dy.device)
         for k, (out_rows, in_rows) in enumerate(ctx["offset_pairs"]):
             if out_rows.numel():
                 dw[k] = x[in_rows, :cin].t() @ dy[out_rows]
@@ -146,6 +160,7 @@ class StudentTrainer:
             m = nbr_map[k]
             out_rows = torch.nonzero(m >= 0).squeeze(1)
             ctx["offset_pairs"].append((out_rows, m[out_rows].long()))
+        ctx["wgrad_plan"] = ops.wgrad_plan_build(ctx["offset_pairs"], Nv) if self.fast else None
         mom = self.bn_momentum
 
         def bn_fwd(y, prefix, residual=None, want_split=True):
@@ -166,7 +181,7 @@ class StudentTrainer:
             a1, a1s, st1 = bn_fwd(y1, f"res_blocks.{i}.norm1")
             y2 = self._conv(a1, a1s, P[f"res_blocks.{i}.conv2.kernel"], ctx)
             h2, h2s, st2 = bn_fwd(y2, f"res_blocks.{i}.norm2", residual=h)
-            blocks.append((h, y1, a1, st1, y2, st2, h2))
+            blocks.append((h, y1, a1, st1, y2, st2, h2, hs, a1s))
             h, hs = h2, h2s
         E = h @ P["output_layer.kernel"]
         loss, dE = ops.infonce_fwd_bwd(E, sample_to_voxel, point_to_batch, num_anchors, num_negatives, self.temperature)
@@ -176,20 +191,22 @@ class StudentTrainer:
         g["output_layer.kernel"] = h.t() @ dE
         dh = dE @ P["output_layer.kernel"].t()
         for i in reversed(range(self.num_blocks)):
-            h_in, y1, a1, st1, y2, st2, h_out = blocks[i]
+            h_in, y1, a1, st1, y2, st2, h_out, h_in_s, a1_s = blocks[i]
             dy2, dg2, db2, dz = ops.bn_train_backward(dh, h_out, y2, st2[0], st2[1], self.bn_eps, P[f"res_blocks.{i}.norm2.bn.weight"],
                                                       want_dz=True)
             g[f"res_blocks.{i}.norm2.bn.weight"], g[f"res_blocks.{i}.norm2.bn.bias"] = dg2, db2
-            g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, dy2, ctx, self.hidden)
-            da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx)
+            gs2 = self._grad_split(dy2) if self.fast else None
+            g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, a1_s, dy2, ctx, self.hidden, gs2)
+            da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx, gs2)
             dy1, dg1, db1 = ops.bn_train_backward(da1, a1, y1, st1[0], st1[1], self.bn_eps, P[f"res_blocks.{i}.norm1.bn.weight"])
             g[f"res_blocks.{i}.norm1.bn.weight"], g[f"res_blocks.{i}.norm1.bn.bias"] = dg1, db1
-            g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, dy1, ctx, self.hidden)
-            dh = dz + self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx)
+            gs1 = self._grad_split(dy1) if self.fast else None
+            g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1)
+            dh = dz + self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1)
         h0 = blocks[0][0] if self.num_blocks else h
         dy0, dg0, db0 = ops.bn_train_backward(dh, h0, y0, st0[0], st0[1], self.bn_eps, P["input_layer.1.bn.weight"])
         g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
-        g["input_layer.0.kernel"] = self._wgrad(X, dy0, ctx, self.cin_pad)
+        g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad)
         return loss, g, E
 
     # ---- optimizer ---------------------------------------------------------------------------------------

@@ -324,6 +324,17 @@ int gp_infonce_fwd_bwd(const float *e, int64_t ld_e, int64_t nv, int32_t d, cons
                        int64_t num_samples, const int64_t *point_to_batch, int64_t num_anchors,
                        int32_t num_negatives, float temperature, float *loss, float *de, int64_t ld_de,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* Weight gradient of a 3x3x3 layer on the matrix cores: dW[k] = X[in_k]^T dY[out_k] (f16 hi/lo operands, fp32    */
+/* accumulate).  x_hi/x_lo f16 [nv, ld_x >= cin_pad]; y_hi/y_lo f16 [nv+1, ld_y >= cout] with row nv all zero;       */
+/* pair_in/pair_out i32: per offset its (input row, output row) pairs padded to a multiple of 32 with (0, nv);      */
+/* segs i32 [num_segments,4] = {offset, first step (32 pairs), steps, 0} ordered by offset; seg_off i32 [kv+1].     */
+/* dw f32 [kv, cin_out, cout] = inv_scale[0] * gradient (inv_scale: device scalar, nullable).                       */
+size_t gp_conv_wgrad_workspace_bytes(int64_t num_segments, int32_t cin_pad, int32_t cout);
+int gp_conv_wgrad_f16x3(const void *x_hi, const void *x_lo, int64_t ld_x, const void *y_hi, const void *y_lo,
+                        int64_t ld_y, const int32_t *pair_in, const int32_t *pair_out, const int32_t *segs,
+                        int64_t num_segments, const int32_t *seg_off, int32_t kv, int32_t cin_pad, int32_t cin_out,
+                        int32_t cout, const float *inv_scale, float *dw, void *workspace, size_t workspace_bytes,
+                        void *stream);
 /* torch.optim.AdamW update of one flat fp32 tensor (run/train.py:198), step >= 1.                      */
 int gp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step, void *stream);

@@ -98,6 +98,39 @@ def test_knn_points_exact(ops):
     assert np.array_equal(out.cpu().numpy(), o_train.knn_points_bruteforce(xyz, q, 96))
 
 
+@pytest.mark.parametrize("cin_pad", [256, 544])
+def test_conv_weight_gradient_kernel(ops, cin_pad):
+    """dW[k] = X[in_k]^T dY[out_k] on the matrix cores against an fp64 gather-GEMM; cin_pad = 544 exercises the
+    slid-back last row tile (rows 288..543 computed, 512..543 stored), several segments per offset and padded pairs."""
+    rng = np.random.default_rng(21)
+    coords = surface_voxels(rng, 3000)
+    nv, cout = len(coords), 256
+    cs_ref = dev(coords.astype(np.int32))
+    perm, rank = ops.morton_order(cs_ref)
+    cs = cs_ref[perm.long()].contiguous()
+    nbr_map = ops.kernel_map_build(ops.grid_build(cs), cs)
+    X = torch.randn(nv, cin_pad, device="cuda")
+    dY = torch.randn(nv, cout, device="cuda") * 3e-5                     # gradient-sized values (need the power-of-two scaling)
+    pairs = []
+    for k in range(27):
+        m = nbr_map[k]
+        out_rows = torch.nonzero(m >= 0).squeeze(1)
+        pairs.append((out_rows, m[out_rows].long()))
+    plan = ops.wgrad_plan_build(pairs, nv, steps_per_segment=8)          # many segments
+    s = 2.0 ** 14
+    dys = torch.zeros((nv + 1, cout), device="cuda")
+    dys[:nv] = dY * s
+    inv_s = torch.tensor([1.0 / s], device="cuda")
+    dw = ops.conv_wgrad_f16x3(ops.split_f16(X), ops.split_f16(dys), plan, cin_pad, cin_pad, cout, inv_scale=inv_s)
+    Xd, Yd = X.double(), dY.double()
+    worst = 0.0
+    for k, (o, i) in enumerate(pairs):
+        ref = Xd[i].t() @ Yd[o] if o.numel() else torch.zeros(cin_pad, cout, dtype=torch.float64, device="cuda")
+        err = float((dw[k].double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+        worst = max(worst, err)
+    assert worst < 2e-6, worst                                           # fp32-class: 2^-22 split error, fp32 accumulation
+
+
 # ------------------------------------------------------------------------------------------ student forward/backward
 def _setup_student(hidden, num_blocks, seed, cin=38, nvox=1500, S=1200, A=64, Nn=63):
     from geopurify_amd import pipeline as pl
