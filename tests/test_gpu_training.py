@@ -268,3 +268,42 @@ def test_reference_training_loop_surface(ops):
     assert not torch.equal(model.affinity_student.output_layer.kernel.detach(), w_before)
     assert not torch.equal(model.affinity_student.input_layer[1].bn.running_mean, rm_before)
     assert int(model.affinity_student.input_layer[1].bn.num_batches_tracked) == 3
+
+
+def test_train_driver_loop_and_checkpoints(ops, tmp_path):
+    """geopurify_amd.train_driver.train: two epochs over two tiny scenes, log scalars, checkpoints, resume."""
+    from geopurify_amd import config as gp_config
+    from geopurify_amd import pipeline as pl
+    from geopurify_amd import synthetic as syn
+    from geopurify_amd import train_driver as td
+    from geopurify_amd.affinity_module import SonataXAffinityTrainer
+    cfg = syn.CONFIGS["T"]
+    args = gp_config.CfgNode({"mask_shape": list(cfg.mask_shape), "epochs": 2, "save_path": str(tmp_path), "save_freq": 1, "print_freq": 1})
+    (tmp_path / "model").mkdir()
+    model = SonataXAffinityTrainer(args, device="cuda", use_lseg=False, feature_dim=cfg.feat_dim, hidden_dim=128).to("cuda")
+    model.num_anchors_per_scene = 128
+    batches = []
+    for i in range(2):
+        scene = syn.make_scene(cfg, 90 + i)
+        batches.append((pl.build_scene_batch(pl.upload_scene(scene, "cuda"), pl.scene_rigid_transform(cfg.voxel_size, 90 + i), "cuda"),
+                        pl.SyntheticVLM(syn.make_vlm_outputs(cfg, cfg.num_views, 90 + i), "cuda"),
+                        torch.randn(cfg.num_points, 24, device="cuda")))
+
+    class Loader:
+        def __len__(self):
+            return len(batches)
+
+        def __iter__(self):
+            for b, vlm, feats in batches:
+                model.vlm, model.teacher = vlm, (lambda _b, f=feats: f)
+                yield b
+
+    opt = td.build_optimizer(model.affinity_student, 1e-3, 1e-5)
+    sched = td.build_scheduler(opt, 1e-3, 1, 2, 2)
+    scalars = td.train(model, opt, sched, Loader(), args)
+    assert set(scalars) == {"lr", "loss_train"} and set(scalars["loss_train"]) == {1, 2}
+    assert all(np.isfinite(v) for v in scalars["loss_train"].values())
+    assert (tmp_path / "model" / "affinity_predictor_last.pth").exists() and (tmp_path / "model" / "affinity_predictor_epoch_1.pth").exists()
+    opt2 = td.build_optimizer(model.affinity_student, 1e-3, 1e-5)
+    start, sc = td.load_resume(model.affinity_student, opt2, str(tmp_path / "model" / "affinity_predictor_epoch_1.pth"), "cuda")
+    assert start == 2 and sc["loss_train"] == scalars["loss_train"]

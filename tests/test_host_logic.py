@@ -142,3 +142,40 @@ def test_oracle_adamw_is_torch_adamw():
         cur = o_train.adamw_step(cur, grads, state, step, 1e-3, 1e-2)
     for k in ref:
         assert (cur[k] - ref[k].detach()).abs().max() < 1e-6
+
+
+def test_train_driver_checkpoint_resume_and_scheduler(tmp_path):
+    """run/train.py:215-263,320-334,371-391: checkpoint keys, resume (epoch from the dict or from the file name, bare
+    state_dict accepted), optimizer state restored, scheduler fast-forwarded by start_epoch * len(loader) steps."""
+    import warnings
+    from geopurify_amd import train_driver as td
+    from geopurify_amd.affinity_module import AffinityPredictor
+    torch.manual_seed(0)
+    st = AffinityPredictor(38, 16, 32)
+    opt = td.build_optimizer(st, 1e-3, 1e-5)
+    assert [g["name"] for g in opt.param_groups] == ["input_group", "middle_group", "output_group"]
+    assert np.allclose([g["lr"] for g in opt.param_groups], [1e-4, 1e-3, 5e-3])
+    for p in st.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    path = str(tmp_path / "affinity_predictor_epoch_3.pth")
+    td.save_checkpoint(path, 3, st, opt, {"loss_train": {4: 1.25}})
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "tensorboard_scalars"}
+    assert "input_layer.0.kernel" in ck["model_state_dict"] and "res_blocks.3.norm2.bn.running_var" in ck["model_state_dict"]
+    st2 = AffinityPredictor(38, 16, 32)
+    opt2 = td.build_optimizer(st2, 1e-3, 1e-5)
+    start, scalars = td.load_resume(st2, opt2, path, "cpu")
+    assert start == 4 and scalars == {"loss_train": {4: 1.25}}
+    assert all(torch.equal(a, b) for a, b in zip(st.state_dict().values(), st2.state_dict().values()))
+    assert opt2.state_dict()["state"][0]["step"] == opt.state_dict()["state"][0]["step"]
+    bare = str(tmp_path / "weights_epoch_7.pth")
+    torch.save(st.state_dict(), bare)                                   # bare state_dict: epoch parsed from the file name
+    assert td.load_resume(AffinityPredictor(38, 16, 32), td.build_optimizer(AffinityPredictor(38, 16, 32), 1e-3, 1e-5), bare, "cpu")[0] == 8
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = td.build_scheduler(opt, 1e-3, 2, 10, 5)
+        for _ in range(4 * 5):
+            a.step()
+        from geopurify_amd.training import lr_schedule
+        assert np.allclose(a.get_last_lr(), [lr_schedule(20, 1e-3, g, 10, 40) for g in ("input", "middle", "output")], rtol=1e-6)
