@@ -289,7 +289,57 @@ int nn1_splits(int64_t n_ref, int64_t n_q) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// classify: one wave per point.  logits_c = scale * <f/|f|, t_c>; first maximum wins.
+// classify: 16 lanes per point (4 points per wave); a lane keeps its share of the row (every 16th float4) in
+// registers, normalised once.  logits_c = scale * <f/|f|, t_c>; first maximum wins.  Rows wider than 16*4*CL_MAXJ
+// floats or not a multiple of 4 take the generic one-wave-per-point kernel below.
+constexpr int CL_MAXJ = 8;                    // float4 per lane -> d <= 512
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ void classify16_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t n, const float *__restrict__ text, int C,
+                                  float scale, int64_t *__restrict__ pred, uint8_t *__restrict__ zero_row) {
+    const int64_t p = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4);
+    const int l = threadIdx.x & 15;
+    const bool live = p < n;
+    const int nj = d / 64;                                 // float4 per lane (d % 64 == 0)
+    float4 v[CL_MAXJ];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CL_MAXJ; ++j) {
+        v[j] = (live && j < nj) ? *reinterpret_cast<const float4 *>(feat + p * ld + (j * 16 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    ss = sum16(ss);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float sa = 0.f;
+#pragma unroll
+    for (int j = 0; j < CL_MAXJ; ++j) {
+        v[j].x /= nrm; v[j].y /= nrm; v[j].z /= nrm; v[j].w /= nrm;
+        sa += fabsf(v[j].x) + fabsf(v[j].y) + fabsf(v[j].z) + fabsf(v[j].w);
+    }
+    sa = sum16(sa);
+    float bestv = -INFINITY;
+    int bestc = 0;
+    for (int k = 0; k < C; ++k) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < CL_MAXJ; ++j)
+            if (j < nj) {
+                const float4 t = *reinterpret_cast<const float4 *>(text + (int64_t)k * d + (j * 16 + l) * 4);
+                dot += v[j].x * t.x + v[j].y * t.y + v[j].z * t.z + v[j].w * t.w;
+            }
+        dot = sum16(dot) * scale;
+        if (dot > bestv) { bestv = dot; bestc = k; }
+    }
+    if (live && l == 0) {
+        pred[p] = bestc;
+        if (zero_row) zero_row[p] = (sa == 0.f) ? 1 : 0;
+    }
+}
+
+// generic shape: one wave per point
 __global__ void classify_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t n,
                                 const float *__restrict__ text, int C, float scale, int64_t *__restrict__ pred,
                                 uint8_t *__restrict__ zero_row) {
@@ -497,8 +547,11 @@ extern "C" int gp_visible_lists(const int64_t *mapping, int64_t n, int64_t *pt, 
 extern "C" int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int64_t n, const float *text_norm, int32_t c,
                                   float logit_scale, int64_t *pred, uint8_t *zero_row, void *stream_) {
     GP_CHECK_ARG(feat && text_norm && pred && n > 0 && d > 0 && c > 0, "gp_classify_argmax: null/empty argument");
-    classify_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
-                                                                               pred, zero_row);
+    if (d % 64 == 0 && d <= 64 * CL_MAXJ && ld % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)text_norm % 16 == 0)
+        classify16_kernel<<<(int)((n * 16 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale, pred, zero_row);
+    else
+        classify_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
+                                                                                   pred, zero_row);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
