@@ -343,45 +343,6 @@ def pool_tiles_apply(x, tiles, d, out):
     return out
 
 
-class PoolBlocks:
-    """Block-shared pooling operator (64-row blocks over the r=8 tiles)."""
-
-    def __init__(self, tiles, bu_off, bu_row, we_pos, we_w, ok):
-        self.tiles, self.bu_off, self.bu_row, self.we_pos, self.we_w, self.ok = tiles, bu_off, bu_row, we_pos, we_w, ok
-
-
-def pool_blocks_build(tiles):
-    """tiles: PoolTiles with r == 8.  One host sync (total block-union rows + overflow flag)."""
-    lib = _lib.load()
-    assert tiles.r == 8
-    nv = tiles.nv
-    dev = tiles.u_row.device
-    nb = (nv + 63) // 64
-    ws = _ws(lib.gp_pool_blocks_workspace_bytes(nv), dev)
-    bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib.gp_pool_blocks_count(_ptr(tiles.tile_off), _ptr(tiles.u_row), nv, _ptr(bu_off), _ptr(flag), _ptr(ws),
-                                   ws.numel(), _stream()), "gp_pool_blocks_count")
-    total, bad = int(bu_off[nb].item()), int(flag.item())
-    if bad:
-        return PoolBlocks(tiles, None, None, None, None, False)
-    bu_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
-    we_pos = torch.empty(max(tiles.total, 1), dtype=torch.int32, device=dev)
-    we_w = torch.empty((max(tiles.total, 1), 8), dtype=torch.float32, device=dev)
-    check(lib.gp_pool_blocks_fill(_ptr(tiles.tile_off), _ptr(tiles.u_row), _ptr(tiles.u_w), nv, _ptr(bu_off),
-                                  _ptr(bu_row), _ptr(we_pos), _ptr(we_w), _ptr(flag), _stream()), "gp_pool_blocks_fill")
-    return PoolBlocks(tiles, bu_off, bu_row, we_pos, we_w, True)
-
-
-def pool_blocks_apply(x, blocks, d, out):
-    lib = _lib.load()
-    t = blocks.tiles
-    check(lib.gp_pool_blocks_apply(_ptr(x), x.stride(0), _ptr(blocks.bu_off), _ptr(blocks.bu_row), _ptr(t.tile_off),
-                                   _ptr(blocks.we_pos), _ptr(blocks.we_w), t.nv, int(d), _ptr(out), out.stride(0),
-                                   _stream()), "gp_pool_blocks_apply")
-    return out
-
-
 class PoolMfma:
     """Affinity operator in matrix-core form: per block of block_rows rows the padded neighbour union and the
     dense [block_rows x union] weight block, pre-split to f16 hi/lo in MFMA A-fragment order."""

@@ -391,7 +391,7 @@ class HotPath:
 
     def _pool(self, X, nbr, w, Nv, D):
         """Row 12: num_iters applications of the row-stochastic affinity operator (affinity_module.py:1575-1587).
-        pool_mode: "auto" (matrix cores when the shape allows, else tiles, else ELL), "mfma", "tiles", "blocks", "ell"."""
+        pool_mode: "auto" (matrix cores when the shape allows, else tiles, else ELL), "mfma", "tiles", "ell"."""
         dev = X.device
         mode = self.pool_mode
         mfma_ok = D == 512 and self.pool_block_rows * self.K <= 16384 and self.num_iters >= 1
@@ -416,23 +416,16 @@ class HotPath:
                                     out_f32=bufs[0] if last else None)
             self._pool_kernel = "pool_mfma_kernel"
             return bufs[0]
-        use_tiles = mode in ("tiles", "blocks") and tiles_ok
+        use_tiles = mode == "tiles" and tiles_ok
         tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
-        blocks = None
-        if use_tiles and mode == "blocks" and R == 8 and D == 512:
-            blocks = ops.pool_blocks_build(tiles)
-            if not blocks.ok:
-                blocks = None
         cur = X
         for t in range(self.num_iters):
-            if blocks is not None:
-                ops.pool_blocks_apply(cur, blocks, D, bufs[t % 2])
-            elif use_tiles:
+            if use_tiles:
                 ops.pool_tiles_apply(cur, tiles, D, bufs[t % 2])
             else:
                 ops.pool_ell(cur, nbr, w, D, bufs[t % 2])
             cur = bufs[t % 2]
-        self._pool_kernel = "pool_blocks_kernel" if blocks is not None else ("pool_tiles_kernel" if use_tiles else "pool_ell_kernel")
+        self._pool_kernel = "pool_tiles_kernel" if use_tiles else "pool_ell_kernel"
         return cur
 
     def evaluate_scene(self, batch: SceneBatch, vlm):

@@ -182,21 +182,6 @@ int gp_pool_tiles_apply(const float *x, int64_t ld_x, const int64_t *tile_off, c
                         const float *u_w, int32_t r, int64_t nv, int32_t d, float *y, int64_t ld_y,
                         void *stream);
 
-/* Block-shared variant (d = 512, r = 8): 8 adjacent tiles share one LDS copy of their union rows.   */
-/* Built from the r=8 tile arrays: bu_off i64 [nblocks+1] (nblocks = ceil(nv/64)), bu_row i32 [total]  */
-/* (sorted union per block), we_pos i32 [entries] (position of each tile entry in its block union),    */
-/* we_w f32 [entries,8] (tile entries re-ordered by position).  *flag_dev != 0: a block union exceeded  */
-/* the builder's capacity -> use gp_pool_tiles_apply instead.                                          */
-size_t gp_pool_blocks_workspace_bytes(int64_t nv);
-int gp_pool_blocks_count(const int64_t *tile_off, const int32_t *u_row, int64_t nv, int64_t *bu_off,
-                         int32_t *flag_dev, void *workspace, size_t workspace_bytes, void *stream);
-int gp_pool_blocks_fill(const int64_t *tile_off, const int32_t *u_row, const float *u_w, int64_t nv,
-                        const int64_t *bu_off, int32_t *bu_row, int32_t *we_pos, float *we_w,
-                        int32_t *flag_dev, void *stream);
-int gp_pool_blocks_apply(const float *x, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
-                         const int64_t *tile_off, const int32_t *we_pos, const float *we_w, int64_t nv,
-                         int32_t d, float *y, int64_t ld_y, void *stream);
-
 /* Matrix-core variant (d = 512): blocks of block_rows (64 or 128) rows, the block's neighbour union    */
 /* swept in steps of 32 rows on v_mfma_f32_16x16x32_f16 with split operands (x = hi + lo in f16;        */
 /* hi*hi + hi*lo + lo*hi accumulated in fp32).  nblocks = ceil(nv / block_rows), nw = block_rows / 16.   */

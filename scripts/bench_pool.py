@@ -51,9 +51,7 @@ for R in (4, 8, 16):
             if (R, nf4, un) in ((16, 2, 8), (4, 1, 4), (4, 1, 8)):
                 continue
             variants.append((f"tiles R={R} nf4={nf4} unroll={un}", (R, nf4, un)))
-blocks = ops.pool_blocks_build(tiles[8])
-print("blocks ok", blocks.ok, "block union rows/row", (int(blocks.bu_off[-1]) / Nv) if blocks.ok else None, flush=True)
-variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4] + [("blocks (64 rows share LDS x)", "blocks")]
+variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4]
 mf = {}
 for BR in (64, 128):
     mf[BR] = ops.pool_mfma_build(nbr, w, BR); torch.cuda.synchronize()
@@ -82,8 +80,6 @@ for rnd in range(3):
         elif v[0] == "mfma32":
             lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_f32=Y))
-        elif v == "blocks":
-            t = timeit(lambda: ops.pool_blocks_apply(X, blocks, D, Y))
         else:
             R, nf4, un = v
             lib.gp_debug_set(1, nf4); lib.gp_debug_set(2, un)

@@ -83,12 +83,15 @@ def test_affinity_rows_are_stochastic(big):
 
 
 def test_pooling_properties_full_size(big):
+    """size-independent properties of the row-stochastic operator through every pooling kernel at full size:
+    A 1 = 1, linearity, convexity (outputs inside the column range), and agreement between independent kernels."""
     ops, nbr, w = big["ops"], big["nbr"], big["w"]
     Nv, D = nbr.shape[0], 512
     tiles = ops.pool_tiles_build(nbr, w, 8)
-    blocks = ops.pool_blocks_build(tiles)
+    mfma = {br: ops.pool_mfma_build(nbr, w, br) for br in (64, 128)}
     X = torch.randn(Nv, 544, device="cuda")
     Y = torch.randn(Nv, 544, device="cuda")
+
     def P(z, mode):
         out = torch.empty(Nv, D, device="cuda")
         if mode == "ell":
@@ -96,18 +99,18 @@ def test_pooling_properties_full_size(big):
         elif mode == "tiles":
             ops.pool_tiles_apply(z, tiles, D, out)
         else:
-            ops.pool_blocks_apply(z, blocks, D, out)
+            ops.pool_mfma_apply(ops.split_f16(z, D), mfma[mode], D, out_f32=out)
         return out
     ones = torch.ones(Nv, 544, device="cuda")
-    for mode in ("ell", "tiles") + (("blocks",) if blocks.ok else ()):
+    for mode in ("ell", "tiles", 64, 128):
         assert (P(ones, mode) - 1).abs().max() < 1e-5                                # A 1 = 1
         lin = P((2.0 * X - 0.5 * Y).contiguous(), mode) - (2.0 * P(X, mode) - 0.5 * P(Y, mode))
         assert lin.abs().max() < 1e-4                                                 # linearity
         px = P(X, mode)
         assert (px.amax(0) <= X[:, :D].amax(0) + 1e-5).all() and (px.amin(0) >= X[:, :D].amin(0) - 1e-5).all()   # convexity
-    assert (P(X, "tiles") - P(X, "ell")).abs().max() < 1e-5                          # independent kernels agree
-    if blocks.ok:
-        assert (P(X, "blocks") - P(X, "ell")).abs().max() < 1e-5
+    ref = P(X, "ell")
+    for mode in ("tiles", 64, 128):
+        assert (P(X, mode) - ref).abs().max() < 1e-5                                  # independent kernels agree
 
 
 def test_conv_paths_agree_full_size(big):

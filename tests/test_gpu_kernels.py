@@ -620,45 +620,6 @@ def test_pool_mfma_matches_ell_and_oracle(ops, n_vox, BR):
     assert ((y2[0].float() + y2[1].float()) - o2).abs().max() < 1e-6
 
 
-def test_pool_blocks_matches_tiles_and_oracle(ops):
-    rng = np.random.default_rng(13)
-    c = surface_voxels(rng, 2500)
-    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
-    Nv, K, D = len(c), 96, 512
-    nbr = ops.knn_lattice(grid, cs, perm, K)
-    E = F.normalize(torch.randn(Nv, 128), dim=1)
-    w = ops.affinity_softmax(dev(E), nbr, 20.0)
-    tiles = ops.pool_tiles_build(nbr, w, 8)
-    blocks = ops.pool_blocks_build(tiles)
-    assert blocks.ok
-    bo, br = blocks.bu_off.cpu().numpy(), blocks.bu_row.cpu().numpy()
-    to, ur = tiles.tile_off.cpu().numpy(), tiles.u_row.cpu().numpy()
-    wp, ww, uw = blocks.we_pos.cpu().numpy(), blocks.we_w.cpu().numpy(), tiles.u_w.cpu().numpy()
-    for b in (0, len(bo) // 2, len(bo) - 2):
-        u = br[bo[b]:bo[b + 1]]
-        t0, t1 = b * 8, min(b * 8 + 8, len(to) - 1)
-        assert (np.diff(u) > 0).all() and set(u) == set(ur[to[t0]:to[t1]])
-        for t in range(t0, t1):
-            pos = wp[to[t]:to[t + 1]]
-            assert (np.diff(pos) > 0).all()                              # sorted by position, distinct
-            ids = u[pos]
-            order = {v: i for i, v in enumerate(ur[to[t]:to[t + 1]])}
-            src = np.array([order[v] for v in ids])
-            assert np.array_equal(ww[to[t]:to[t + 1]], uw[to[t]:to[t + 1]][src])
-    X = torch.randn(Nv, 544)
-    Xd = dev(X)
-    a = [torch.empty((Nv, D), device="cuda") for _ in range(2)]
-    b_ = [torch.empty((Nv, D), device="cuda") for _ in range(2)]
-    ca, cb = Xd, Xd
-    T = 5
-    for t in range(T):
-        ops.pool_blocks_apply(ca, blocks, D, a[t % 2]); ca = a[t % 2]
-        ops.pool_tiles_apply(cb, tiles, D, b_[t % 2]); cb = b_[t % 2]
-    assert (ca - cb).abs().max() < 1e-5
-    ref = o_aff.pool_gather(X[:, :D], nbr.cpu().long(), w.cpu(), T)
-    assert (ca.cpu().double() - ref).abs().max() < 1e-5
-
-
 def test_nn1_masked_grid_path_equals_bruteforce(ops):
     """>= 32768 points take the grid-accelerated search; must equal the brute force (incl. far queries)."""
     from geopurify_amd import _lib
