@@ -105,6 +105,10 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; it must be the one already in the process when this library (linked
+    # against libamdhip64 by soname) is loaded, otherwise two runtimes coexist and kernel launches report
+    # "no ROCm-capable device" (seen when the library was loaded before the first `import torch`).
+    import torch  # noqa: F401
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise GeoPurifyHipError(
