@@ -58,7 +58,7 @@ t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True
 print(f"{'LDS-DMA path (pre-split in/out)':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
 t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs))
 print(f"{'LDS-DMA path (no split output)':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
-for name, v in (("DMA: no MFMA", 2), ("DMA: no MFMA, no epilogue", 10), ("DMA: no epilogue", 8)):
+for name, v in (("DMA: LDS-staged epilogue (old)", 32), ("DMA: no MFMA", 2), ("DMA: no MFMA, no epilogue", 10), ("DMA: no epilogue", 8)):
     lib.gp_debug_set(3, v)
     t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs))
     print(f"{name:36s} {t:7.3f} ms", flush=True)
