@@ -14,7 +14,11 @@ extern "C" void gp_set_error(const char *fmt, ...) {
 extern "C" const char *gp_last_error(void) { return g_err; }
 extern "C" int gp_version(void) { return 100; }
 
-// tuning knobs for experiments: 1 = pooling float4 per lane (0 auto), 2 = pooling unroll, 3 = conv phase-1 ablation mask
+// tuning knobs for experiments (gp_debug_set): 1 = tiled pooling float4 per lane (0 auto), 2 = tiled pooling unroll,
+// 3 = conv phase-1 ablation mask (1 no loads after step 0, 2 no MFMA, 8 no partial stores, 16 register-staged path,
+// 32 LDS-staged epilogue), 4 = matrix-core pooling ablation mask (1 no reads/MFMA, 2 no row gather, 4 no epilogue,
+// 8 no weight fragments, 16 no output stores), 5 = force brute-force 1-NN, 6 = 1-NN grid cells per axis,
+// 9 = matrix-core pooling: force one workgroup per CU
 int g_gp_knobs[16] = {0, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int gp_debug_set(int32_t key, int32_t value) {
     if (key < 1 || key > 15) return GP_EINVAL;
