@@ -281,7 +281,7 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         int row = wv * 32 + t * 16 + lrow;
-        int in_row = row < cnt ? pair_in[base + row] : 0;
+        int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];              // clamped, unconditional: both loads overlap
         ga_hi[t] = x_hi + (int64_t)in_row * ld_xh + q;
         ga_lo[t] = x_lo + (int64_t)in_row * ld_xh + q;
         int64_t wrow = ((int64_t)k * cout + n0 + row) * cin + q;
