@@ -564,6 +564,23 @@ def test_pool_tiles_matches_ell_and_oracle(ops, R):
     assert (ca.cpu().double() - ref).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("n_vox,K,BR", [(130, 96, 64), (70, 32, 64), (130, 32, 128), (65, 8, 64)])
+def test_pool_mfma_tiny_voxel_sets(ops, n_vox, K, BR):
+    """edge shapes: a single (partial) row block, unions of exactly K+1..Nv rows, K far from 96, 1-step applications."""
+    rng = np.random.default_rng(15)
+    c = surface_voxels(rng, n_vox)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, D = len(c), 512
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    w = ops.affinity_softmax(dev(F.normalize(torch.randn(Nv, 128), dim=1)), nbr, 20.0)
+    op = ops.pool_mfma_build(nbr, w, BR)
+    X = torch.randn(Nv, D)
+    out = torch.empty((Nv, D), device="cuda")
+    ops.pool_mfma_apply(ops.split_f16(dev(X)), op, D, out_f32=out)
+    ref = o_aff.pool_gather(X, nbr.cpu().long(), w.cpu(), 1)
+    assert (out.cpu().double() - ref).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize("n_vox,BR", [(2500, 64), (2531, 64), (2500, 128), (2531, 128)])
 def test_pool_mfma_matches_ell_and_oracle(ops, n_vox, BR):
     """Matrix-core pooling (split f16 operands, fp32 accumulation) against the ELL gather and the oracle
