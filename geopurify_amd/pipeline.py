@@ -290,10 +290,15 @@ class HotPath:
         cnt = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         segs = []
         ws_m = ws_n = None
+        # segment scores (:544) of all source views in one softmax + max when the logits are stacked (rows are independent)
+        scores_all = None
+        if batched and getattr(vlm, "pred_logits", None) is not None and vlm.pred_logits.dim() == 3:
+            scores_all = torch.softmax(vlm.pred_logits, dim=-1)[..., :-1].max(-1).values.contiguous()
         for i, v in enumerate(batch.views):
             out = vlm(v.src_view)
             pm = out["pred_masks"]
-            scores = torch.softmax(out["pred_logits"], dim=-1)[..., :-1].max(-1).values.contiguous()
+            scores = scores_all[v.src_view] if scores_all is not None else \
+                torch.softmax(out["pred_logits"], dim=-1)[..., :-1].max(-1).values.contiguous()
             if ws_m is None:
                 lib = ops._lib.load()
                 ws_m = torch.empty(lib.gp_lift_masks_workspace_bytes(*pm.shape), dtype=torch.uint8, device=dev)
