@@ -175,3 +175,38 @@ def test_view_drop_and_edge_cases(big):
     huge = torch.tensor([[0, 0, 0], [40000, 0, 0]], dtype=torch.int32, device="cuda")
     with pytest.raises(GeoPurifyHipError):
         ops.grid_build(huge)                                                              # extent beyond 32768 -> GP_ERANGE
+
+
+def test_conv_gradients_adjoint_identities_full_size(big):
+    """Training kernels at full size through identities that hold for any linear map y = conv_W(x):
+    <conv_W(x), g> = <x, dgrad_W(g)> = <W, wgrad(x, g)>  (data gradient = the same operator with mirrored, transposed
+    weights; weight gradient = the matrix-core kernel).  Sums in fp64 on the device."""
+    ops = big["ops"]
+    nm = ops.kernel_map_build(big["grid"], big["cs"])
+    pairs = ops.conv_pairs_build(nm)
+    Nv, C = big["cs"].shape[0], 256
+    torch.manual_seed(2)
+    X = torch.randn(Nv, C, device="cuda")
+    G = torch.randn(Nv, C, device="cuda")
+    W = torch.randn(27, C, C, device="cuda") * 0.02
+    sc = torch.full((C,), 1 / 32.0, device="cuda")
+    hi, lo = ops.conv_weights_split(W, 32.0)
+    xs = ops.split_f16(X)
+    Y = ops.sparse_conv_f16x3(X, pairs, hi, lo, sc, None, x_split=xs)
+    V = W.flip(0).transpose(1, 2).contiguous()
+    vhi, vlo = ops.conv_weights_split(V, 32.0)
+    Gp = torch.zeros((Nv + 1, C), device="cuda")
+    Gp[:Nv] = G
+    gs = ops.split_f16(Gp)
+    dX = ops.sparse_conv_f16x3(G, pairs, vhi, vlo, sc, None, x_split=(gs[0][:Nv], gs[1][:Nv]))
+    offset_pairs = []
+    for k in range(27):
+        out_rows = torch.nonzero(nm[k] >= 0).squeeze(1)
+        offset_pairs.append((out_rows, nm[k][out_rows].long()))
+    plan = ops.wgrad_plan_build(offset_pairs, Nv)
+    dW = ops.conv_wgrad_f16x3(xs, gs, plan, C, C, C)
+    a = float((Y.double() * G.double()).sum())
+    b = float((X.double() * dX.double()).sum())
+    c = float((W.double() * dW.double()).sum())
+    scale = float(Y.double().norm() * G.double().norm())
+    assert abs(a - b) < 1e-6 * scale and abs(a - c) < 1e-6 * scale, (a, b, c, scale)
