@@ -49,10 +49,8 @@ def sample_contrastive_pairs_hybrid(F_teacher, neighbor_indices, anchor_indices,
     sim = Fn[anchor_indices] @ Fn.t()
     A, N = sim.shape
     rows = torch.arange(A, device=sim.device)
-    pos_sim = sim.clone()
-    pos_sim[rows, anchor_indices] = float("-inf")
-    positive = torch.argmax(pos_sim, dim=1)
-    del pos_sim
+    sim[rows, anchor_indices] = float("-inf")         # the reference clones the [A,N] matrix for this; marking in place is the same
+    positive = torch.argmax(sim, dim=1)
     sim[rows, anchor_indices] = float("inf")          # in place, as the reference (sim_matrix_neg aliases the matrix)
     sim[rows, positive] = float("inf")
     _, macro = torch.topk(sim, k=N_MACRO, largest=False, dim=1)
