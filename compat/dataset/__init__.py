@@ -1,0 +1,1 @@
+"""compat shim package (see compat/README.md)."""

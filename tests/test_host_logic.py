@@ -179,3 +179,23 @@ def test_train_driver_checkpoint_resume_and_scheduler(tmp_path):
             a.step()
         from geopurify_amd.training import lr_schedule
         assert np.allclose(a.get_last_lr(), [lr_schedule(20, 1e-3, g, 10, 40) for g in ("input", "middle", "output")], rtol=1e-6)
+
+
+def test_compat_shims_resolve_reference_module_names():
+    """compat/: the reference drivers' import names (`models.affinity_module`, `dataset.voxelizer`, `util.config`,
+    `MinkowskiEngine` ...) resolve to the mirrors."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import models.affinity_module as m, dataset.voxelizer as v, dataset.voxelization_utils as vu, dataset.feature_loader as fl;"
+        "import models.utils.fusion_util as fu, util.config as c, util.util as u, MinkowskiEngine as ME;"
+        "import geopurify_amd.affinity_module as g;"
+        "assert m.SonataXAffinityTrainer is g.SonataXAffinityTrainer and m.AffinityPredictor is g.AffinityPredictor;"
+        "assert hasattr(v, 'Voxelizer') and hasattr(vu, 'sparse_quantize') and hasattr(fl, 'FusedFeatureLoader');"
+        "assert hasattr(fu, 'PointCloudToImageMapper') and hasattr(fu, 'PointCloudToImageMappermatterport');"
+        "assert hasattr(c, 'load_cfg_from_cfg_file') and hasattr(u, 'intersectionAndUnionGPU');"
+        "mod = object(); assert ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(mod) is mod; print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "compat"), root]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
