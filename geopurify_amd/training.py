@@ -7,8 +7,9 @@ What runs where:
   * 3x3x3 convolutions, forward and data-gradient: gp_sparse_conv_f16x3 (dgrad = the same operator with weights
     V[k] = W[26-k]^T; gradients are scaled by a power of two before the f16 hi/lo split so that they stay normal);
   * BatchNorm(training), ReLU masks, InfoNCE forward+backward, AdamW, anchors' K nearest points: train.hip;
-  * weight gradients dW[k] = X[in_k]^T dY[out_k], the 512->128 output layer and the anchors x points similarity:
-    plain dense GEMMs through torch.matmul (rocBLAS) -- library GEMMs on gathered rows, not hand-written kernels;
+  * weight gradients dW[k] = X[in_k]^T dY[out_k]: gp_conv_wgrad_f16x3 (wgrad.hip); the anchors x points similarity:
+    the convolution operator with one offset (_anchor_similarities); the 512->128 output layer (plain dense GEMMs,
+    forward and backward) and unsupported shapes: torch.matmul (rocBLAS);
   * set logic (unique / argmax / topk of the sampler): torch device ops, as in the reference.
 The teacher (Sonata) is not available offline: its per-point features are an input tensor.
 Deviation: the voxel input is [mean lifted feature | mean geometry] (518 channels) as in
@@ -41,12 +42,31 @@ def lr_schedule(step_index, base_lr, group, warmup_iters, main_iters):
     return eta_min + (lr0 - eta_min) * 0.5 * (1.0 + math.cos(math.pi * t / max(main_iters, 1)))
 
 
+def _anchor_similarities(Fn, anchor_indices):
+    """sim[a, p] = <Fn[anchor_a], Fn[p]> (einsum('ad,pd->ap'), affinity_module.py:1115).  On the device with a feature
+    width that is a multiple of 32 this is the gather-GEMM of the convolution operator with ONE offset: the anchors are
+    the gathered rows, the points play the output channels (weights are stored [cout][cin] = [point][feature]), f16
+    hi/lo operands with fp32 accumulation (fp32-class, 2.5x the rate of the library fp32 GEMM).  Otherwise torch.matmul."""
+    N, Dt = Fn.shape
+    if not (Fn.is_cuda and Dt % 32 == 0 and N >= 256):
+        return Fn[anchor_indices] @ Fn.t()
+    Np = (N + 255) // 256 * 256
+    Fp = Fn
+    if Np != N:
+        Fp = torch.zeros((Np, Dt), dtype=torch.float32, device=Fn.device)
+        Fp[:N] = Fn
+    hi, lo = ops.split_f16(Fp)
+    pairs = ops.conv_pairs_build(anchor_indices.to(torch.int32).view(1, -1).contiguous())
+    sim = ops.sparse_conv_f16x3(None, pairs, hi.view(1, Np, Dt), lo.view(1, Np, Dt), None, None, relu=False, x_split=(hi, lo))
+    return sim[:, :N]
+
+
 # --------------------------------------------------------------------------------------------------
 def sample_contrastive_pairs_hybrid(F_teacher, neighbor_indices, anchor_indices, num_negatives):
     """affinity_module.py:1113-1136 after the randperm (anchors are the caller's draw).  neighbor_indices i64 [A,K]
     are the anchors' rows of the point kNN.  Returns positive [A], negative [A, num_negatives]."""
     Fn = torch.nn.functional.normalize(F_teacher, p=2, dim=1)
-    sim = Fn[anchor_indices] @ Fn.t()
+    sim = _anchor_similarities(Fn, anchor_indices)
     A, N = sim.shape
     rows = torch.arange(A, device=sim.device)
     sim[rows, anchor_indices] = float("-inf")         # the reference clones the [A,N] matrix for this; marking in place is the same

@@ -197,7 +197,7 @@ def test_scene_training_step_end_to_end(ops):
     batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
     N = batch.scene_coords.shape[0]
     g = torch.Generator().manual_seed(9)
-    D, Dt, A, Nn, K = 32, 48, 128, 63, 96
+    D, Dt, A, Nn, K = 32, 64, 128, 63, 96                 # Dt % 32 == 0: anchor similarities on the matrix cores
     F_lift = torch.randn(N, D, generator=g)
     F_teacher = torch.randn(N, Dt, generator=g)
     anchors = torch.randperm(N, generator=g)[:A]
