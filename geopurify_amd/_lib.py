@@ -6,8 +6,7 @@ pointers, sizes and a hipStream_t.
 """
 import ctypes
 import os
-from ctypes import (POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint8,
-                    c_uint64, c_void_p)
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgeopurify_hip.so")

@@ -16,7 +16,6 @@ import argparse
 import logging
 import os
 import random
-import sys
 
 import numpy as np
 import torch
