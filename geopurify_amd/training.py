@@ -318,3 +318,34 @@ def training_forward(student_module, F_lift, gauss, inds_reconstruct, coords_3d,
             elif k.endswith("num_batches_tracked"):
                 b += 1
     return _LossWithGradients.apply(out["loss"], grads, *[named[n] for n in names])
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW with the update done by gp_adamw_step (one HIP launch per parameter tensor).  Same constructor
+    arguments, param_groups and state_dict layout ('step', 'exp_avg', 'exp_avg_sq'), so it can replace the optimizer of
+    run/train.py:198 and load / save its checkpoints.  amsgrad / maximize are not supported."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32):
+                    raise ValueError("FusedAdamW needs contiguous fp32 parameters on the device")
+                ops.adamw_step_(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], int(st["step"]),
+                                weight_decay=group["weight_decay"], betas=group["betas"], eps=group["eps"])
+        return loss

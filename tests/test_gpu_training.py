@@ -88,6 +88,26 @@ def test_adamw_matches_torch(ops):
     assert (p.cpu() - p_ref.detach()).abs().max() < 1e-6
 
 
+def test_fused_adamw_optimizer_is_torch_adamw(ops):
+    from geopurify_amd.training import FusedAdamW
+    torch.manual_seed(3)
+    shapes = [(27, 6, 8), (8,), (8, 4)]
+    ref = [torch.randn(*s, device="cuda").requires_grad_(True) for s in shapes]
+    mine = [r.detach().clone().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.AdamW([{"params": ref[:1], "lr": 1e-3}, {"params": ref[1:], "lr": 5e-3}], weight_decay=1e-2)
+    o_mine = FusedAdamW([{"params": mine[:1], "lr": 1e-3}, {"params": mine[1:], "lr": 5e-3}], weight_decay=1e-2)
+    for _ in range(4):
+        for a, b in zip(ref, mine):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        o_ref.step()
+        o_mine.step()
+    for a, b in zip(ref, mine):
+        assert (a - b).abs().max() < 1e-6
+    sd = o_mine.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+
+
 def test_knn_points_exact(ops):
     rng = np.random.default_rng(3)
     xyz = (rng.random((20000, 3)) * np.array([7, 5, 2.6])).astype(np.float32)
