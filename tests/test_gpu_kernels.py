@@ -661,3 +661,19 @@ def test_nn1_masked_grid_path_equals_bruteforce(ops):
     sub = np.where(qry)[0][:400]
     exp = np.where(ref)[0][o_lift.nn1_indices_bruteforce(xyz[ref], xyz[sub])]
     assert np.array_equal(nn_grid[sub], exp)
+
+
+def test_c_abi_example_runs_without_python_or_torch(ops, tmp_path):
+    """examples/c_abi_pooling.c: a plain C99 program (gcc, no torch, no C++) builds the matrix-core pooling operator
+    and applies it through include/geopurify_hip.h, checks itself against a double-precision loop and the error path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_pooling")
+    libdir = os.path.join(root, "geopurify_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "c_abi_pooling.c"), "-I" + os.path.join(root, "include"),
+                         "-I/opt/rocm/include", "-L" + libdir, "-lgeopurify_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
