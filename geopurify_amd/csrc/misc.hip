@@ -77,21 +77,27 @@ __global__ void mask_compact_kernel(const float *__restrict__ xyz, const uint8_t
     if (qm[i]) qidx[qs[i]] = i;
     if (i == n - 1) { counts[0] = rs[i] + (rm[i] ? 1 : 0); counts[1] = qs[i] + (qm[i] ? 1 : 0); }
 }
-// one query per thread, the whole compacted reference set streamed through LDS tiles
+// brute force for small sets: one query per thread; the compacted reference set is cut into NN_CHUNKS ranges that
+// different workgroups stream through LDS tiles (a view has a few thousand queries = a handful of workgroups: one
+// range per workgroup would leave the chip idle), then a second kernel takes the lexicographic (d2, index) minimum
+// over the ranges in ascending order -- the same winner as a single sequential scan.
+constexpr int NN_CHUNKS = 16;
 __global__ void __launch_bounds__(256)
-nn1_masked_kernel(const float *__restrict__ xyz, const float *__restrict__ rxyz, const int64_t *__restrict__ ridx,
-                  const int64_t *__restrict__ qidx, const int32_t *__restrict__ counts, int64_t *__restrict__ nn) {
+nn1_masked_part_kernel(const float *__restrict__ xyz, const float *__restrict__ rxyz, const int64_t *__restrict__ qidx,
+                       const int32_t *__restrict__ counts, double *__restrict__ part_d, int32_t *__restrict__ part_i, int64_t stride) {
     __shared__ double sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
     const int n_ref = counts[0], n_q = counts[1];
     if ((int64_t)blockIdx.x * 256 >= n_q || n_ref == 0) return;
+    const int per = (n_ref + NN_CHUNKS - 1) / NN_CHUNKS;
+    const int r0 = blockIdx.y * per, r1 = r0 + per < n_ref ? r0 + per : n_ref;
     int64_t qi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int64_t q = qi < n_q ? qidx[qi] : -1;
     double qx = 0, qy = 0, qz = 0;
     if (q >= 0) { qx = xyz[q * 3]; qy = xyz[q * 3 + 1]; qz = xyz[q * 3 + 2]; }
     double best = INFINITY;
     int bi = -1;
-    for (int t0 = 0; t0 < n_ref; t0 += NN_TILE) {
-        int cnt = n_ref - t0 < NN_TILE ? n_ref - t0 : NN_TILE;
+    for (int t0 = r0; t0 < r1; t0 += NN_TILE) {
+        int cnt = r1 - t0 < NN_TILE ? r1 - t0 : NN_TILE;
         __syncthreads();
         for (int j = threadIdx.x; j < cnt; j += 256) {
             sx[j] = rxyz[(int64_t)(t0 + j) * 3]; sy[j] = rxyz[(int64_t)(t0 + j) * 3 + 1]; sz[j] = rxyz[(int64_t)(t0 + j) * 3 + 2];
@@ -103,7 +109,22 @@ nn1_masked_kernel(const float *__restrict__ xyz, const float *__restrict__ rxyz,
             if (d2 < best) { best = d2; bi = t0 + j; }
         }
     }
-    if (q >= 0) nn[q] = ridx[bi];
+    if (qi < n_q) { part_d[(int64_t)blockIdx.y * stride + qi] = best; part_i[(int64_t)blockIdx.y * stride + qi] = bi; }
+}
+__global__ void nn1_masked_reduce_kernel(const double *__restrict__ part_d, const int32_t *__restrict__ part_i, int64_t stride,
+                                         const int64_t *__restrict__ ridx, const int64_t *__restrict__ qidx,
+                                         const int32_t *__restrict__ counts, int64_t *__restrict__ nn) {
+    const int n_ref = counts[0], n_q = counts[1];
+    int64_t qi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (qi >= n_q || n_ref == 0) return;
+    double best = INFINITY;
+    int bi = -1;
+    for (int c = 0; c < NN_CHUNKS; ++c) {
+        double d = part_d[(int64_t)c * stride + qi];
+        int i = part_i[(int64_t)c * stride + qi];
+        if (i >= 0 && d < best) { best = d; bi = i; }
+    }
+    nn[qidx[qi]] = ridx[bi];
 }
 
 
@@ -514,7 +535,12 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
         nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
         nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, NG2);
     } else {
-        nn1_masked_kernel<<<blocks, 256, 0, st>>>(xyz, rxyz, ridx, qidx, counts, nn);
+        // the cell arrays of the grid path are idle here: partial results of the reference ranges live in them
+        double *part_d = reinterpret_cast<double *>(cell_cnt);
+        int32_t *part_i = reinterpret_cast<int32_t *>(cell_cnt) + 2 * (int64_t)NN_CHUNKS * n;
+        static_assert((size_t)NN_CHUNKS * 32768 * 12 <= ((size_t)NGMAX * NGMAX * NGMAX + 1) * 4 * 2, "partials must fit the cell arrays");
+        nn1_masked_part_kernel<<<dim3((unsigned)blocks, NN_CHUNKS), 256, 0, st>>>(xyz, rxyz, qidx, counts, part_d, part_i, n);
+        nn1_masked_reduce_kernel<<<blocks, 256, 0, st>>>(part_d, part_i, n, ridx, qidx, counts, nn);
     }
     GP_CHECK_LAUNCH();
     return GP_OK;
