@@ -165,12 +165,13 @@ def _setup_student(hidden, num_blocks, seed, cin=38, nvox=1500, S=1200, A=64, Nn
     return coords, sd, X, s2v, p2b, A, Nn
 
 
-@pytest.mark.parametrize("hidden,num_blocks", [(128, 1), (256, 2)])
-def test_student_training_step_matches_autograd(ops, hidden, num_blocks):
+@pytest.mark.parametrize("hidden,num_blocks,cin", [(128, 1, 38), (256, 2, 38), (256, 1, 518)])
+def test_student_training_step_matches_autograd(ops, hidden, num_blocks, cin):
     """loss, every gradient, the AdamW-updated weights and the BatchNorm running statistics of one step.
-    hidden=128: exact fp32 MFMA convolutions; hidden=256: the f16x3 matrix-core path (forward and dgrad)."""
+    hidden=128: exact fp32 MFMA convolutions; hidden=256: the f16x3 matrix-core path (forward, dgrad, weight gradient);
+    cin=518 (= 512 + 6, padded to 544): the input layer's weight gradient through the slid-back last row tile."""
     from geopurify_amd.training import StudentTrainer
-    coords, sd, X, s2v, p2b, A, Nn = _setup_student(hidden, num_blocks, seed=5)
+    coords, sd, X, s2v, p2b, A, Nn = _setup_student(hidden, num_blocks, seed=5, cin=cin)
     ref = o_train.train_step_oracle(sd, X, coords, s2v, p2b, A, Nn, 0.07, num_blocks, base_lr=1e-3, weight_decay=1e-2)
     tr = StudentTrainer(sd, "cuda", base_lr=1e-3, weight_decay=1e-2)
     cs_ref = dev(coords.astype(np.int32))
