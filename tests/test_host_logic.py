@@ -220,3 +220,19 @@ def test_bench_line_contract_on_the_committed_run():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] / c["value"] > 50                                           # BASELINE target: >= 50x the CPU path
+
+
+def test_bench_helpers_traffic_and_schedule():
+    """bench.py helpers that do not need a GPU: the PMC-derived traffic figure (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes,
+    scaled to the scene's voxel count) and the bounded host-thread count."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(root, "profiles", "pool_pmc.json")))["pool_mfma_kernel"]
+    t = bench.pmc_traffic("pool_mfma_kernel", rec["nv"])
+    assert t["traffic"] == int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024) and "pool_pmc.json" in t["traffic_source"]
+    assert bench.pmc_traffic("pool_mfma_kernel", rec["nv"] // 2)["traffic"] == int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024 * (rec["nv"] // 2) / rec["nv"])
+    assert bench.pmc_traffic("no_such_kernel", 1000) == {"traffic": None}
+    assert 1 <= bench.host_threads() <= 16
