@@ -327,7 +327,8 @@ class HotPath:
         nn = ops.nn1_masked(batch.scene_coords, seen, 1 - seen)
         src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
         F = ops.gather_rows(F, D, src)
-        return F, vlm.text_embed, vlm.logit_scale
+        # the reference returns the NORMALISED text embeddings (affinity_module.py:628 rebinds the name returned at :711)
+        return F, (text_norm if V else vlm.text_embed), vlm.logit_scale
 
     # ---- row 5 ----------------------------------------------------------------------------------
     def lift_dense(self, batch: SceneBatch, vlm: DenseFeatureVLM):

@@ -82,6 +82,8 @@ def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=1
                                          xyz32[v["pt"]], cfg.mask_shape)
             fs.append(f), lgs.append(lg)
         tick("lift per view")
+        if len(ld["views"]):
+            text = F.normalize(text, dim=-1)          # :628 rebinds text_features to the normalised copy that :711 returns
         Fp = lift.fuse_views_top3(N, [v["pt"] for v in ld["views"]], fs, lgs, xyz32, faithful_loops=not vectorised)
     tick("fuse+fill")
     inv = ld["inv"]
