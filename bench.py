@@ -33,9 +33,16 @@ FP32_MFMA_PEAK_TF = 157.3        # dense fp32-input MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 6; config V: every scene of this rank once)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="S", choices=["P", "S", "M", "T"])
+    ap.add_argument("--config", default="S", choices=["P", "S", "M", "T", "V"],
+                    help="S = BASELINE configs[1] (default); V = configs[2]: ScanNet-val scene SIZES (tests/golden/"
+                         "scannet_val_point_counts.txt), a fixed subset of --val-scenes per GPU, sharded over the ranks")
+    ap.add_argument("--val-scenes", type=int, default=16, help="config V: scenes per GPU")
+    ap.add_argument("--shard-policy", default="lpt", choices=["lpt", "contiguous"], help="config V: scene -> rank assignment")
+    ap.add_argument("--cpu-sample", default="full", choices=["full", "bounded"],
+                    help="cpu_baseline: one whole scene of the workload through the oracle (measured, ~1 min at S) or the "
+                         "bounded sub-sampled scene extrapolated per stage")
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
     ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma", "tiles", "ell"])
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
@@ -43,7 +50,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step rate (extra object `training_step`)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 0 if a.config == "V" else 6            # 0 = resolved to the rank's scene count below
+    return a
 
 
 def log(*a):
@@ -106,15 +116,20 @@ def training_step_rate(batch, dev, sd, steps=3):
 
 
 def pmc_traffic(kernel, nv):
-    """HBM-side bytes per launch of the pooling kernel from the committed rocprofv3 PMC passes
-    (profiles/pool_pmc.json: FETCH_SIZE / WRITE_SIZE in KiB on an S-shaped voxel set, separate passes;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950), scaled to this
-    scene's voxel count.  null when no counters were collected for this kernel."""
+    """HBM-side bytes per launch of the pooling kernel.  Hardware counters cannot be read from inside this process:
+    they come from the committed rocprofv3 PMC passes over THIS script (scripts/pmc_pool.sh -> profiles/pool_pmc.json:
+    FETCH_SIZE / WRITE_SIZE in KiB per launch, separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    16-B-per-lane reads on gfx950; the record names the voxel count and the commit it was collected at).  Used as is
+    when the record's voxel count is this run's (same seeded scene), scaled by the voxel ratio otherwise (and said so);
+    null when no counters were collected for this kernel."""
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pool_pmc.json")) as f:
             rec = json.load(f)[kernel]
-        b = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024 * nv / rec["nv"]
-        return {"traffic": int(b), "traffic_source": f"profiles/pool_pmc.json ({rec['profile']})"}
+        b = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024
+        src = f"profiles/pool_pmc.json ({rec['profile']}, Nv={rec['nv']}, commit {rec.get('commit', '?')})"
+        if abs(rec["nv"] - nv) > 0.005 * nv:
+            b, src = b * nv / rec["nv"], src + f", scaled to Nv={nv}"
+        return {"traffic": int(b), "traffic_source": src}
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
 
@@ -199,37 +214,58 @@ class StageTimer:
         return out
 
 
-def cpu_baseline(scene, vlm_np, sd, rigid, cfg, pool_iters, budget_s):
-    """The oracle ("port") timed on the host cores, on a BOUNDED sample of the same workload: the same
-    scene geometry sub-sampled to fewer points / views so that it finishes in ~budget_s, scaled to
-    scenes/sec by its measured per-stage costs (linear in points x views for the lift, in voxels for
-    the refine stages)."""
+def cpu_baseline(scene, vlm_np, sd, rigid, cfg, pool_iters, budget_s, mode="full"):
+    """The oracle ("port": torch-CPU / numpy / sklearn restatement of the reference path, vectorised variant -- the
+    reference's two per-point Python loops replaced by tensor ops, i.e. the STRONGER CPU baseline -- with the kNN by
+    scipy cKDTree on all cores instead of the oracle's quadratic exact search) timed on the host cores.
+    mode "full": ONE whole scene of the benchmarked workload, measured end to end (no extrapolation).
+    mode "bounded": the same scene generator sub-sampled to 20 % of the points and 1/6 of the views (~budget_s),
+    extrapolated per stage (linear in points x views for loader + lift, in points for the rest)."""
     import dataclasses
     from geopurify_amd import synthetic as syn
     from oracle import pipeline as o_pipe
     threads = host_threads()
     torch.set_num_threads(threads)
+    kw = {}
+    if cfg.dense_features:
+        kw["dense_feat"] = vlm_np["dense"]
+    if mode == "full":
+        timings = {}
+        t0 = time.perf_counter()
+        o_pipe.evaluate_scene_oracle(scene, vlm_np, sd, rigid, K=96, num_iters=pool_iters, timings=timings, knn_impl="kdtree", **kw)
+        wall = time.perf_counter() - t0
+        return {"value": round(1.0 / wall, 6), "unit": "scenes/s", "cores": threads, "kind": "port",
+                "sample": f"oracle (torch-CPU/numpy/sklearn, vectorised variant, kNN by scipy cKDTree), ONE whole {cfg.name} scene "
+                          f"({scene.coords.shape[0]} pts x {len(scene.views)} views, T={pool_iters}) measured end to end: {wall:.1f} s",
+                "stages_s": {k: round(v, 3) for k, v in timings.items()}}
     frac_pts, n_views = 0.2, max(2, cfg.num_views // 6)
     small_cfg = dataclasses.replace(cfg, num_points=int(cfg.num_points * frac_pts), num_views=n_views)
     small = syn.make_scene(small_cfg, 5557)
     vlm_small = {k: (v[:n_views] if isinstance(v, np.ndarray) and v.ndim >= 3 and v.shape[0] == cfg.num_views else v)
                  for k, v in vlm_np.items()}
+    if cfg.dense_features:
+        kw["dense_feat"] = vlm_small["dense"]
     timings = {}
     t0 = time.perf_counter()
-    o_pipe.evaluate_scene_oracle(small, vlm_small, sd, rigid, K=96, num_iters=pool_iters, timings=timings,
-                                 knn_impl="kdtree")
+    o_pipe.evaluate_scene_oracle(small, vlm_small, sd, rigid, K=96, num_iters=pool_iters, timings=timings, knn_impl="kdtree", **kw)
     wall = time.perf_counter() - t0
-    # scale: loader+lift ~ points x views ; fuse ~ points ; refine stages ~ voxels (~points)
     pv = (cfg.num_points * cfg.num_views) / (small_cfg.num_points * small_cfg.num_views)
     pn = cfg.num_points / small_cfg.num_points
-    est = 0.0
-    for k, v in timings.items():
-        est += v * (pv if k in ("loader(project+voxelize)", "lift per view") else pn)
+    est = sum(v * (pv if k in ("loader(project+voxelize)", "lift per view") else pn) for k, v in timings.items())
     return {"value": round(1.0 / est, 6), "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch-CPU/numpy/sklearn, vectorised variant, kNN by scipy cKDTree) on {small_cfg.num_points} pts x {n_views} views "
-                      f"of the same scene generator, T={pool_iters}: {wall:.1f}s measured; extrapolated per stage to "
-                      f"{cfg.num_points} pts x {cfg.num_views} views = {est:.1f} s/scene",
+            "sample": f"oracle (vectorised variant, cKDTree kNN) on {small_cfg.num_points} pts x {n_views} views of the same scene "
+                      f"generator, T={pool_iters}: {wall:.1f}s measured; EXTRAPOLATED per stage to {cfg.num_points} pts x "
+                      f"{cfg.num_views} views = {est:.1f} s/scene",
             "stages_s_sample": {k: round(v, 3) for k, v in timings.items()}}
+
+
+def val_scene_sizes(per_gpu, world):
+    """BASELINE configs[2]: a fixed subset of the 312 ScanNet-val scene sizes (labelled-point counts of
+    dataset/scannet_val_metrics.tsv, committed as tests/golden/scannet_val_point_counts.txt): per_gpu * world sizes taken at
+    a constant stride through the list in file order, so the subset keeps the list's spread (28k .. 302k points)."""
+    sizes = [int(float(v)) for v in open(os.path.join(ROOT, "tests", "golden", "scannet_val_point_counts.txt")).read().split()]
+    n = min(per_gpu * world, len(sizes))
+    return [sizes[(i * len(sizes)) // n] for i in range(n)]
 
 
 def main():
@@ -240,34 +276,59 @@ def main():
     if args.gpus != world and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
+    local = local % torch.cuda.device_count()         # more ranks than GPUs only happens in the gloo test (two ranks, one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GP_BENCH_BACKEND", "nccl")      # nccl = RCCL; "gloo" lets a test run two ranks on ONE GPU
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
-    from geopurify_amd import ops, pipeline as pl, synthetic as syn
-    cfg = syn.CONFIGS[args.config]
+    import dataclasses
+    from geopurify_amd import ops, pipeline as pl, sharding, synthetic as syn
+    val_mode = args.config == "V"
+    cfg = syn.CONFIGS["S" if val_mode else args.config]
     # ---- synthetic inputs, resident in HBM before timing ------------------------------------------
-    scenes, vlms, rigids = [], [], []
+    scenes, vlms, rigids, scene_cfgs = [], [], [], []
     vlm_np0 = None
     torch.set_num_threads(host_threads())
-    for s in range(args.scenes):
-        log(f"rank {rank}: generating synthetic scene {s + 1}/{args.scenes} ({cfg.name})")
-        seed = 5557 + 1000 * rank + s
-        sc = syn.make_scene(cfg, seed)
+    shard = None
+    if val_mode:
+        sizes = val_scene_sizes(args.val_scenes, world)
+        ids = list(range(len(sizes)))
+        parts = sharding.assign_scenes_lpt(sizes, world) if args.shard_policy == "lpt" else \
+            [sharding.get_batch_scenes(ids, r, world) for r in range(world)]
+        mine = parts[rank]
+        shard = {"policy": args.shard_policy, "scenes_total": len(sizes), "points_per_rank": [int(sum(sizes[i] for i in p)) for p in parts],
+                 "scenes_per_rank": [len(p) for p in parts]}
+        todo = [(5557 + gi, sizes[gi]) for gi in mine]
+        args.scenes = len(todo)
+    else:
+        todo = [(5557 + 1000 * rank + s, cfg.num_points) for s in range(args.scenes)]
+    shared_vlm = None
+    for s, (seed, npts) in enumerate(todo):
+        log(f"rank {rank}: generating synthetic scene {s + 1}/{len(todo)} ({cfg.name}, {npts} points)")
+        c = dataclasses.replace(cfg, num_points=npts) if npts != cfg.num_points else cfg
+        sc = syn.make_scene(c, seed)
         if cfg.dense_features:
             feat = syn.make_dense_feature_maps(cfg, cfg.num_views, seed)
             text = np.random.default_rng(seed).normal(size=(cfg.num_classes, cfg.feat_dim)).astype(np.float32)
             vlm_np = {"text_embed": text, "logit_scale": np.float32(1 / 0.07), "dense": feat}
             vlms.append(pl.DenseFeatureVLM(feat, text, 1 / 0.07, dev))
+        elif val_mode and shared_vlm is not None:
+            vlms.append(shared_vlm)                       # config V: one set of synthetic 2D outputs serves every scene (the
+            vlm_np = vlm_np0                              # geometry, hence every kernel's work, differs per scene)
         else:
             vlm_np = syn.make_vlm_outputs(cfg, cfg.num_views, seed)
             vlms.append(pl.SyntheticVLM(vlm_np, dev))
+            shared_vlm = vlms[-1]
         if s == 0:
             vlm_np0 = vlm_np
         scenes.append(pl.upload_scene(sc, dev))
+        scene_cfgs.append(c)
         rigids.append(pl.scene_rigid_transform(cfg.voxel_size, seed))
+    if args.steps <= 0:
+        args.steps = max(len(todo), 1)
     sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
     student = pl.StudentWeights(sd, dev)
     hp = pl.HotPath(student, cfg.mask_shape, K=96, sharpen=20.0, num_iters=args.pool_iters, device=dev, pool_mode=args.pool_mode)
@@ -279,12 +340,12 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
-    def step(i, stage=None):
-        with torch.cuda.stream(streams[i % len(streams)]):
-            return _step(i, stage if len(streams) == 1 else None)
+    def step(i, stage=None, stream=None):
+        with torch.cuda.stream(stream if stream is not None else streams[i % len(streams)]):
+            return _step(i, stage)
 
     def _step(i, stage=None):
-        j = i % args.scenes
+        j = i % max(args.scenes, 1)
         if stage:
             stage.mark("start")
         batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
@@ -305,6 +366,17 @@ def main():
             stage.mark("classify+iou")
         return batch
 
+    def join_streams():
+        """Order the default stream (on which the collective is issued) after every side stream, and back."""
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            cur.wait_stream(st)
+
+    def fork_streams():
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -313,28 +385,46 @@ def main():
             torch.cuda.synchronize()
 
     log("inputs resident; warm-up")
-    for i in range(args.warmup):
-        step(i)
+    if args.scenes:
+        for i in range(args.warmup):
+            step(i)
     barrier()
     log("timing")
     counts.zero_()
+    fork_streams()                                    # the side streams start after the zeroing (default stream)
     pool_timer.enabled = conv_timer.enabled = True
-    stage = StageTimer()
     t0 = time.perf_counter()
     last = None
-    for i in range(args.steps):
-        last = step(i, stage)
+    n_local = args.steps if args.scenes else 0
+    for i in range(n_local):
+        last = step(i)
+    join_streams()                                    # every scene's histogram atomics precede the collective
+    busy_ev = torch.cuda.Event(enable_timing=False)
+    busy_ev.record()
     if world > 1:
         import torch.distributed as dist
+        busy_ev.synchronize()
+        busy = time.perf_counter() - t0               # this rank's own work, before it waits for the others
         dist.all_reduce(counts)                       # the one collective: int64 [3,C] IoU counts
     barrier()
     dt = time.perf_counter() - t0
+    if world == 1:
+        busy = dt
     pool_timer.enabled = conv_timer.enabled = False
+    total_steps = n_local
+    busy_all = [busy]
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        ns = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(ns)
+        total_steps = int(ns.item())
+        bt = torch.zeros(world, dtype=torch.float64, device=dev)
+        bt[rank] = busy
+        dist.all_reduce(bt)
+        busy_all = bt.cpu().tolist()
 
     if rank == 0:
         Nv = hp.stats["Nv"]
@@ -349,31 +439,52 @@ def main():
         pool_ms_alone = pool_timer.mean_ms()
         pool_bytes = Nv * (2 * D * 4 + 96 * 8)           # algorithmic bytes per application of A
         achieved = pool_bytes / (pool_ms * 1e-3) / 1e9
+        # per-stage breakdown from a ONE-stream side pass (stage marks are meaningless while two scenes interleave)
+        stage = StageTimer()
+        side = min(2, max(args.scenes, 1))
+        for i in range(side):
+            step(i, stage, stream=streams[0])
+        torch.cuda.synchronize()
         stages = stage.table()
         pairs = int((hp.stats["nbr_map"] >= 0).sum().item())
         flops = student.flops(pairs, Nv)
+        if val_mode:
+            workload = (f"V: {shard['scenes_total']} ScanNet-val-SIZED synthetic scenes ({args.val_scenes} per GPU, sizes "
+                        f"{min(val_scene_sizes(args.val_scenes, world))}..{max(val_scene_sizes(args.val_scenes, world))} points from "
+                        f"scannet_val_point_counts.txt), 25 views, D={D}, K=96, pool_iters={args.pool_iters}, student 518->512x9->128")
+        else:
+            workload = (f"{cfg.name}: ScanNetV2-shaped scene, N={cfg.num_points} pts, Nv={Nv}, {len(last.views)}/{cfg.num_views} views kept, "
+                        f"D={D}, K=96, pool_iters={args.pool_iters}, student 518->512x9->128 random-init")
         out = {
             "metric": "scenes/sec (ScanNet-val shape) + pooled-feature GB/s vs HBM peak",
-            "value": round(world * args.steps / dt, 4), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg.name}: ScanNetV2-shaped scene, N={cfg.num_points} pts, Nv={Nv}, "
-                                   f"{len(last.views)}/{cfg.num_views} views kept, D={D}, K=96, "
-                                   f"pool_iters={args.pool_iters}, student 518->512x9->128 random-init",
-                       "sharding": f"1 scene per GPU x {world}, one int64 all-reduce of IoU counts",
+            "value": round(total_steps / dt, 4), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (student convolutions and pooling: f16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": workload,
+                       "sharding": (f"{shard['policy']} assignment of {shard['scenes_total']} scenes to {world} rank(s), " if val_mode else
+                                    f"1 scene per GPU x {world}, ") + "one int64 all-reduce of IoU counts",
                        "streams": len(streams)},
             "roofline": {"kernel": hp.stats["pool_kernel"] + " (affinity pooling, one application of A)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], Nv),
                          "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4),
                          "avg_launch_ms_isolated": round(pool_ms_alone, 4),
-                         "frac_isolated": round(pool_bytes / (pool_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "frac_isolated": round(pool_bytes / (pool_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "achieved/frac: HIP events around every launch INSIDE the timed region (the last scene's Nv); "
+                                 "_isolated: the same launches with nothing else on the GPU"},
             "roofline_conv": conv_roofline(conv_timer),
-            "stages_ms_per_scene": {k: round(v / args.steps, 3) for k, v in stages.items()},
+            "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
+            "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
+            "iou_target_points": int(counts[2].sum().item()),      # labelled points counted over ALL ranks (after the all-reduce)
         }
+        if val_mode:
+            out["shard"] = dict(shard, busy_s_per_rank=[round(b, 4) for b in busy_all],
+                                imbalance_max_over_mean=round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4))
         log(f"gpu: {out['value']} scenes/s, {out['ms_per_step']} ms/scene; pooling {pool_ms:.3f} ms/launch")
-        if world == 1 and args.pool_iters != 3:
+        if world == 1 and args.pool_iters != 3 and not val_mode:
             # BASELINE.json words config 1 as "affinity pooling 3 iters"; the reference code applies A 19 times
             # (affinity_module.py:1584-1587), which is what `value` is measured on.  Same scenes with 3 applications:
             try:
@@ -391,16 +502,16 @@ def main():
                 out["variant_pool_iters_3"] = {"value": None, "error": repr(e)}
             finally:
                 hp.num_iters = args.pool_iters
-        if not args.no_train and world == 1 and cfg.feat_dim == 512:
+        if not args.no_train and world == 1 and cfg.feat_dim == 512 and not val_mode:
             try:                                  # an extra; never lose the headline line over it
                 out["training_step"] = training_step_rate(last, dev, sd)
             except Exception as e:
                 out["training_step"] = {"value": None, "error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
-            log("cpu baseline (bounded sample of the oracle on the host cores)")
+            log("cpu baseline (the oracle on the host cores)")
             try:
-                import dataclasses
-                out["cpu_baseline"] = cpu_baseline(scenes[0], vlm_np0, sd, rigids[0], cfg, args.pool_iters, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(scenes[0], vlm_np0, sd, rigids[0], scene_cfgs[0], args.pool_iters, args.cpu_seconds,
+                                                   mode=args.cpu_sample)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))

@@ -57,6 +57,7 @@ class AffinityPredictor(nn.Module):
         self.res_blocks = nn.Sequential(*[MinkowskiResBlock(hidden_dim) for _ in range(4)])
         self.output_layer = _SparseConvParams(hidden_dim, embed_dim, 1)
         self._dev_weights = None
+        self._dev_key = None
 
     def get_param_groups(self):
         return {"input": list(self.input_layer.parameters()),
@@ -68,15 +69,60 @@ class AffinityPredictor(nn.Module):
         self._dev_weights = None
         return out
 
+    def train(self, mode=True):
+        if mode:
+            self._dev_weights = None             # parameters are about to change: drop the folded / split device copy
+        return super().train(mode)
+
+    def _weights_key(self, device):
+        """Identity + in-place version of every parameter and buffer: optimizer.step(), FusedAdamW, .to(), load_state_dict
+        and manual edits all change it, so a stale folded copy can never be served."""
+        return (str(device),) + tuple((id(t), t._version, t.device.type) for t in list(self.parameters()) + list(self.buffers()))
+
     def device_weights(self, device):
-        if self._dev_weights is None or self.training:
+        key = self._weights_key(device)
+        if self._dev_weights is None or self.training or self._dev_key != key:
             self._dev_weights = StudentWeights(self.state_dict(), device)
+            self._dev_key = key
         return self._dev_weights
 
     def forward(self, features, nbr_map):
         """features fp32 [Nv, cin_pad] in Morton order + its 27-offset kernel map -> unnormalised is
         not exposed: returns the L2-normalised embeddings the caller applies next (:1546-1547)."""
         return self.device_weights(features.device).forward(features, nbr_map)
+
+
+_VLM_FACTORY = None
+
+
+def register_vlm_factory(factory):
+    """Install the builder of the 2D VLM that the reference constructs inside SonataXAffinityTrainer.__init__
+    (models/affinity_module.py:224-249: build X-Decoder from `xdecoder_cfg`, load its weights, set the text prompts).
+    `factory(cfg, xdecoder_cfg, device, use_lseg)` -> a callable `vlm(view_index, image=img [H,W,3] 0..255)` returning
+    dict(pred_masks [Q,h,w], pred_logits [Q,C+1], mask_embed [Q,D], text_embed [C,D], logit_scale), e.g. a
+    ForwardSegAllVLM around the real model.  With a factory registered the reference's own constructor call
+    `SonataXAffinityTrainer(args, xdecoder_cfg, scene_config, device, False)` (run/validation.py:166) works unchanged.
+    Pass None to clear.  Returns the previous factory."""
+    global _VLM_FACTORY
+    old, _VLM_FACTORY = _VLM_FACTORY, factory
+    return old
+
+
+class ForwardSegAllVLM:
+    """Adapter of an X-Decoder-style model to the lift's VLM hook: what the reference does with each view's image
+    (models/affinity_module.py:496,518-519): img [H,W,3] -> [1,3,H,W] on the device ->
+    `model.forward_seg_all([{'image': img, 'height': mask_shape[0], 'width': mask_shape[1]}])` -> (_, outputs)."""
+
+    def __init__(self, model, mask_shape, device="cuda"):
+        self.model, self.mask_shape, self.device = model, tuple(mask_shape), device
+
+    def __call__(self, view_index, image=None):
+        if image is None:
+            raise ValueError("ForwardSegAllVLM needs the view's image (slot 11 of the batch tuple)")
+        img = image.unsqueeze(0).permute(0, 3, 1, 2).contiguous().to(self.device)
+        _, out = self.model.forward_seg_all([{"image": img, "height": self.mask_shape[0], "width": self.mask_shape[1]}])
+        return {"pred_masks": out["pred_masks"][0], "pred_logits": out["pred_logits"][0], "mask_embed": out["mask_embed"][0],
+                "text_embed": out["text_embed"], "logit_scale": out["logit_scale"]}
 
 
 class SonataXAffinityTrainer(nn.Module):
@@ -89,14 +135,22 @@ class SonataXAffinityTrainer(nn.Module):
     use_lseg=True (dense-feature lift)."""
 
     def __init__(self, cfg, xdecoder_cfg=None, scene_config=None, device="cuda", use_lseg=True, vlm=None,
-                 feature_dim=512, embed_dim=128, hidden_dim=512, teacher=None):
+                 feature_dim=512, embed_dim=128, hidden_dim=512, teacher=None, allow_deferred_vlm=False):
         super().__init__()
         self.cfg = cfg
         self.device = device
         self.use_lseg = use_lseg
+        self.scene_config = scene_config
         self.use_ape = bool(getattr(cfg, "use_ape", False)) if not isinstance(cfg, dict) else bool(cfg.get("use_ape", False))
         if self.use_ape:
             raise NotImplementedError("lift_ape_features needs the absent xdecoder_test package (SURVEY.md section 2 #1)")
+        if vlm is None and _VLM_FACTORY is not None:
+            vlm = _VLM_FACTORY(cfg, xdecoder_cfg, device, use_lseg)          # the reference builds its VLM here (:224-249)
+        if vlm is None and not allow_deferred_vlm:
+            raise RuntimeError(
+                "SonataXAffinityTrainer: no 2D VLM.  The X-Decoder / LSeg model itself is outside this library: register a "
+                "builder with geopurify_amd.affinity_module.register_vlm_factory(factory) (then the reference's constructor "
+                "call works unchanged), pass vlm=..., or pass allow_deferred_vlm=True and set .vlm before the first scene")
         self.vlm = vlm
         self.feature_dim = feature_dim
         self.affinity_student = AffinityPredictor(input_dim=feature_dim + GEO_DIM, embed_dim=embed_dim,
@@ -124,6 +178,7 @@ class SonataXAffinityTrainer(nn.Module):
         N = scene_coords.shape[0]
         mask_2ds = mask_2ds.to(dev)
         V = int(mask_2ds.shape[0] // N)
+        imgs = imgs if torch.is_tensor(imgs) and imgs.dim() == 4 and imgs.shape[0] == V else None   # slot 11: what the VLM sees
         vis = mask_2ds[:, 1].view(V, N).bool()
         view_of = ori_coords_3ds[:, 0].to(dev).long()
         x_labels, y_labels = x_labels.to(dev), y_labels.to(dev)
@@ -133,7 +188,7 @@ class SonataXAffinityTrainer(nn.Module):
             views.append(ViewLists(torch.where(vis[i])[0], x_labels[sel].contiguous(), y_labels[sel].contiguous(), i))
         return SceneBatch(scene_coords.to(dev).float().contiguous(), scene_coords_3d.to(dev).float().contiguous(),
                           scene_inds_reconstruct.to(dev).long().contiguous(), scene_label.to(dev).long(),
-                          scene_gauss_features[:, :6].to(dev).float().contiguous(), views)
+                          scene_gauss_features[:, :6].to(dev).float().contiguous(), views, imgs=imgs)
 
     @torch.no_grad()
     def evaluate_scene(self, batch_data, vis_prefix="scene0695_00"):

@@ -131,6 +131,7 @@ class SceneBatch:
     order: Optional[torch.Tensor] = None       # CSR of each voxel's points (from the voxelizer sort)
     seg_start: Optional[torch.Tensor] = None
     extent: Optional[list] = None              # host ints: max voxel coord + 1 per axis (min is 0)
+    imgs: Optional[torch.Tensor] = None        # f32 [V,H,W,3] slot 11 of the tuple: what the 2D VLM is run on (:496)
 
     def as_tuple(self):
         """The reference's positional 20-tuple (unused per-view voxelization slots are empty)."""
@@ -147,8 +148,9 @@ class SceneBatch:
         mask_2ds = torch.stack([vid, mask.reshape(-1)], 1)
         xl = torch.cat([v.x for v in self.views]) if V else e.long()
         yl = torch.cat([v.y for v in self.views]) if V else e.long()
+        imgs = self.imgs if self.imgs is not None else e
         return (self.scene_coords, self.scene_coords_3d, self.scene_inds_reconstruct, self.scene_label, ori,
-                e, e, e, e, e, e, e, xl, yl, mask_2ds, e, e, e, (None,) * V, self.scene_gauss_features)
+                e, e, e, e, e, e, imgs, xl, yl, mask_2ds, e, e, e, (None,) * V, self.scene_gauss_features)
 
 
 def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000):
@@ -210,15 +212,18 @@ class SyntheticVLM:
     """Stand-in for the frozen X-Decoder (out of scope, weights unavailable offline): returns the five
     outputs the lift consumes (SURVEY.md 8a'), pre-generated per view and resident on the device."""
 
-    def __init__(self, outputs, device="cuda"):
+    def __init__(self, outputs, device="cuda", index_from_image=False):
         dev = torch.device(device)
+        self.index_from_image = index_from_image       # the generator's view index is read from pixel (0,0) of the image
         self.pred_masks = torch.as_tensor(outputs["pred_masks"]).to(dev)
         self.pred_logits = torch.as_tensor(outputs["pred_logits"]).to(dev)
         self.mask_embed = torch.as_tensor(outputs["mask_embed"]).to(dev)
         self.text_embed = torch.as_tensor(outputs["text_embed"]).to(dev)
         self.logit_scale = float(outputs["logit_scale"])
 
-    def __call__(self, view_index):
+    def __call__(self, view_index, image=None):
+        if self.index_from_image and image is not None:
+            view_index = int(image[0, 0, 0].item())
         return {"pred_masks": self.pred_masks[view_index], "pred_logits": self.pred_logits[view_index],
                 "mask_embed": self.mask_embed[view_index], "text_embed": self.text_embed,
                 "logit_scale": self.logit_scale}
@@ -272,20 +277,38 @@ class HotPath:
         return self._taps[key]
 
     # ---- rows 6-7 -------------------------------------------------------------------------------
-    def lift_masks(self, batch: SceneBatch, vlm: SyntheticVLM):
+    def lift_masks(self, batch: SceneBatch, vlm):
+        """lift_xdecoder_features (affinity_module.py:455-714).  `vlm(view_index, image=...)` -> dict(pred_masks [Q,h,w],
+        pred_logits [Q,C+1], mask_embed [Q,D], text_embed [C,D], logit_scale): the synthetic stand-in, or any adapter of a
+        real 2D model (affinity_module.ForwardSegAllVLM)."""
         dev = self.device
         N = batch.scene_coords.shape[0]
         V = len(batch.views)
-        text_norm = torch.nn.functional.normalize(vlm.text_embed, dim=-1).contiguous()
-        Q, D = vlm.mask_embed.shape[1:]
+        # per-(view, segment) tables for ALL source views in one launch when the VLM outputs are batched and indexed by
+        # src_view (the synthetic stand-in on device-built batches); a batch that carries images (the reference's tuple,
+        # slot 11) runs the VLM on imgs[view_idx] view by view, as affinity_module.py:496,518-519 does
+        has_img = batch.imgs is not None and batch.imgs.numel() > 0
+        batched = (not has_img and torch.is_tensor(getattr(vlm, "mask_embed", None)) and vlm.mask_embed.dim() == 3
+                   and vlm.mask_embed.is_contiguous())
+        outs = None
+        if batched:
+            text_embed, logit_scale = vlm.text_embed, float(vlm.logit_scale)
+            Q, D = vlm.mask_embed.shape[1:]
+        else:
+            outs = [vlm(v.src_view, image=batch.imgs[v.src_view]) if has_img else vlm(v.src_view) for v in batch.views]
+            if V:
+                text_embed, logit_scale = outs[0]["text_embed"].to(dev), float(outs[0]["logit_scale"])
+                Q, D = outs[0]["mask_embed"].shape
+            else:
+                text_embed, logit_scale = vlm.text_embed, float(vlm.logit_scale)
+                Q, D = 1, text_embed.shape[1]
+        text_norm = torch.nn.functional.normalize(text_embed, dim=-1).contiguous()
         C = text_norm.shape[0]
-        # per-(view, segment) tables for ALL source views in one launch when the VLM outputs are batched
-        batched = hasattr(vlm, "mask_embed") and vlm.mask_embed.dim() == 3 and vlm.mask_embed.is_contiguous()
         n_tab = vlm.mask_embed.shape[0] if batched else max(V, 1)
         f_seg = torch.empty((n_tab, Q, D), dtype=torch.float32, device=dev)
         l_seg = torch.empty((n_tab, Q, C), dtype=torch.float32, device=dev)
         if batched:
-            ops.segment_tables(vlm.mask_embed.view(n_tab * Q, D), text_norm, vlm.logit_scale,
+            ops.segment_tables(vlm.mask_embed.view(n_tab * Q, D), text_norm, logit_scale,
                                f_seg.view(n_tab * Q, D), l_seg.view(n_tab * Q, C))
         cnt = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         segs = []
@@ -295,10 +318,10 @@ class HotPath:
         if batched and getattr(vlm, "pred_logits", None) is not None and vlm.pred_logits.dim() == 3:
             scores_all = torch.softmax(vlm.pred_logits, dim=-1)[..., :-1].max(-1).values.contiguous()
         for i, v in enumerate(batch.views):
-            out = vlm(v.src_view)
-            pm = out["pred_masks"]
+            out = vlm(v.src_view) if batched else outs[i]
+            pm = out["pred_masks"].to(dev).contiguous()
             scores = scores_all[v.src_view] if scores_all is not None else \
-                torch.softmax(out["pred_logits"], dim=-1)[..., :-1].max(-1).values.contiguous()
+                torch.softmax(out["pred_logits"].to(dev), dim=-1)[..., :-1].max(-1).values.contiguous()
             if ws_m is None:
                 lib = ops._lib.load()
                 ws_m = torch.empty(lib.gp_lift_masks_workspace_bytes(*pm.shape), dtype=torch.uint8, device=dev)
@@ -311,7 +334,7 @@ class HotPath:
             nn = ops.nn1_masked(xyz, covered, 1 - covered, workspace=ws_n)
             seg = torch.where(nn >= 0, seg[nn.clamp(min=0)], seg)
             if not batched:
-                ops.segment_tables(out["mask_embed"].contiguous(), text_norm, out["logit_scale"], f_seg[i], l_seg[i])
+                ops.segment_tables(out["mask_embed"].to(dev).contiguous(), text_norm, logit_scale, f_seg[i], l_seg[i])
             ops.pv_count(v.pt, cnt)
             segs.append(seg)
         start = ops.exclusive_scan_i64(cnt)
@@ -328,7 +351,7 @@ class HotPath:
         src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
         F = ops.gather_rows(F, D, src)
         # the reference returns the NORMALISED text embeddings (affinity_module.py:628 rebinds the name returned at :711)
-        return F, (text_norm if V else vlm.text_embed), vlm.logit_scale
+        return F, (text_norm if V else text_embed), logit_scale
 
     # ---- row 5 ----------------------------------------------------------------------------------
     def lift_dense(self, batch: SceneBatch, vlm: DenseFeatureVLM):

@@ -20,6 +20,17 @@ def get_batch_scenes(scene_ids, batch_idx, total_batches=4):
     return scene_ids[start:start + size + (1 if batch_idx < rem else 0)]
 
 
+def equal_steps_scene_ids(num_scenes, rank, world_size):
+    """Training shards: every rank gets the SAME number of steps, ceil(n / world) -- one gradient all-reduce per step
+    needs every rank in every collective.  The id list is padded by wrapping around (what torch's DistributedSampler does,
+    the sampler the reference's DDP path would use), then dealt contiguously.  Deterministic, rank-independent length."""
+    if num_scenes <= 0:
+        return []
+    per = -(-num_scenes // world_size)
+    ids = [i % num_scenes for i in range(per * world_size)]
+    return ids[rank * per:(rank + 1) * per]
+
+
 def assign_scenes_lpt(costs, world_size):
     """Greedy longest-processing-time assignment (scene sizes span 28k..302k points):
     scenes sorted by cost descending, each to the currently lightest rank.  Deterministic.
@@ -77,16 +88,18 @@ def evaluate_sharded(num_scenes, scene_counts_fn, num_classes, device, rank=0, w
 
 
 def summarize(counts, category_split=None):
-    """mIoU / mAcc / allAcc for Base / Novel / All exactly as run/validation.py:490-523
-    (I/(U+1e-10) averaged over the index lists of category_split)."""
-    c = counts.detach().cpu().numpy().astype(np.float64)
+    """mIoU / mAcc / allAcc for Base / Novel / All exactly as run/validation.py:490-523: the reference keeps the
+    per-class counts as fp32 numpy vectors (histc output summed by AverageMeter) and evaluates I/(U+1e-10) on them, so the
+    exact int64 counts are converted to fp32 here -- identical numbers (and identical log strings) while a class holds
+    fewer than 2^24 points, where the reference's own fp32 sums stop being exact."""
+    c = counts.detach().cpu().numpy().astype(np.float32)
     inter, out, tgt = c[0], c[1], c[2]
     union = out + tgt - inter
 
     def block(idx):
         i, u, t = inter[idx], union[idx], tgt[idx]
         iou, acc = i / (u + 1e-10), i / (t + 1e-10)
-        return {"mIoU": float(np.mean(iou)), "mAcc": float(np.mean(acc)), "allAcc": float(i.sum() / (t.sum() + 1e-10)),
+        return {"mIoU": np.mean(iou), "mAcc": np.mean(acc), "allAcc": sum(i) / (sum(t) + 1e-10),
                 "iou_class": iou, "intersection": i, "union": u, "target": t}
 
     res = {"All": block(np.arange(len(inter)))}

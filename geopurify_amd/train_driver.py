@@ -10,8 +10,11 @@ checkpoints `model/affinity_predictor_last.pth` every save_freq epochs and `..._
 end, holding {'epoch', 'model_state_dict', 'optimizer_state_dict', 'tensorboard_scalars'} (:371-391).
 
 Differences, on purpose: scenes, 2D-VLM outputs and the teacher's per-point features are synthetic (no datasets, X-Decoder
-or Sonata offline); with torch.distributed initialised every rank trains on its own scenes and the student gradients are
-averaged by ONE bucketed all-reduce per step (sharding.allreduce_mean_gradients) instead of DistributedDataParallel hooks.
+or Sonata offline); with torch.distributed initialised every rank trains on its own scenes (the same number of steps per
+rank) and the student gradients are averaged by ONE bucketed all-reduce per step (sharding.allreduce_mean_gradients)
+instead of DistributedDataParallel hooks.  DEVIATION from the reference's multi-GPU recipe: run/train.py:212-213 converts
+the student to MinkowskiSyncBatchNorm (batch statistics over all ranks); here BatchNorm statistics are per rank (one scene
+each) and rank 0's running statistics are the ones checkpointed.  Single-GPU training (every shipped config) is unaffected.
 """
 import argparse
 import os
@@ -147,10 +150,12 @@ def main(argv=None):
     teacher_dim = int(args.get("teacher_dim", 1088))
 
     class Scenes:
-        """one synthetic scene per step, this rank's share (scene index = global index % num_scenes)."""
+        """one synthetic scene per step, this rank's share: the same number of steps on every rank (ids wrap around when
+        num_scenes is not a multiple of the world size), so that every rank takes part in every gradient all-reduce and
+        len(loader) -- hence the LR schedule and the resume fast-forward -- is rank-independent."""
 
         def __init__(self, n):
-            self.ids = sharding.get_batch_scenes(list(range(n)), rank, world)
+            self.ids = sharding.equal_steps_scene_ids(n, rank, world)
 
         def __len__(self):
             return len(self.ids)
@@ -165,7 +170,7 @@ def main(argv=None):
                 yield pl.build_scene_batch(pl.upload_scene(scene, "cuda"), pl.scene_rigid_transform(cfg_s.voxel_size, seed0 + i), "cuda")
 
     model = SonataXAffinityTrainer(args, None, None, device="cuda", use_lseg=False, feature_dim=cfg_s.feat_dim,
-                                   hidden_dim=int(args.get("hidden_dim", 512))).to("cuda")
+                                   hidden_dim=int(args.get("hidden_dim", 512)), allow_deferred_vlm=True).to("cuda")
     loader = Scenes(int(args.get("num_scenes", 4)))
     base_lr = float(args.get("lr_3d", 1e-4))
     optimizer = build_optimizer(model.affinity_student, base_lr, float(args.get("weight_decay", 1e-5)))

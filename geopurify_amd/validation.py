@@ -141,17 +141,27 @@ def main(argv=None):
     cfg_s = syn.CONFIGS[args.get("synthetic_config", "S")]
     if dataset_name == "matterport" and cfg_s.dataset != "matterport":
         cfg_s = syn.CONFIGS["M"]
-    scene_ids = [f"{dataset_name}_synthetic_{i:04d}" for i in range(int(args.get("num_scenes", 4)))]
+    n_scenes = int(args.get("num_scenes", 4))
+    scene_ids = [f"{dataset_name}_synthetic_{i:04d}" for i in range(n_scenes)]
+    # scene sizes: the config's point count, or -- `synthetic_sizes scannet_val` -- the 312 ScanNet-val scene sizes in file
+    # order (labelled-point counts of dataset/scannet_val_metrics.tsv; BASELINE configs[2])
+    if args.get("synthetic_sizes") == "scannet_val":
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scannet_val_point_counts.txt")
+        table = [int(float(v)) for v in open(path).read().split()]
+        sizes = {sid: table[i % len(table)] for i, sid in enumerate(scene_ids)}
+    else:
+        sizes = {sid: cfg_s.num_points for sid in scene_ids}
     scene_ids = sharding.get_batch_scenes(scene_ids, args.split_idx, args.split_total)      # the reference's manual split
     if rank == 0:
         logger.info(f"=> Validation split: {args.split_idx + 1}/{args.split_total}, num scenes: {len(scene_ids)}")
     if world > 1:
         policy = args.get("shard_policy", "contiguous")
         idx = list(range(len(scene_ids)))
-        mine = sharding.assign_scenes_lpt([cfg_s.num_points] * len(idx), world)[rank] if policy == "lpt" \
+        mine = sharding.assign_scenes_lpt([sizes[s] for s in scene_ids], world)[rank] if policy == "lpt" \
             else sharding.get_batch_scenes(idx, rank, world)
         scene_ids = [scene_ids[i] for i in mine]
-    model = SonataXAffinityTrainer(args, None, None, device="cuda", use_lseg=False, feature_dim=cfg_s.feat_dim)
+    model = SonataXAffinityTrainer(args, None, None, device="cuda", use_lseg=False, feature_dim=cfg_s.feat_dim,
+                                   allow_deferred_vlm=True)           # the synthetic VLM is attached per scene below
     model.num_pool_iters = int(args.get("pool_iters", 19))
     if args.get("resume"):
         load_student_checkpoint(model.affinity_student, args.resume, logger)
@@ -162,7 +172,8 @@ def main(argv=None):
     def provider_for(sid):
         def make():
             seed = int(args.get("manual_seed") or 0) + int(sid.rsplit("_", 1)[1])
-            scene = syn.make_scene(cfg_s, seed)
+            import dataclasses
+            scene = syn.make_scene(dataclasses.replace(cfg_s, num_points=sizes[sid]) if sizes[sid] != cfg_s.num_points else cfg_s, seed)
             state["vlm"] = pl.SyntheticVLM(syn.make_vlm_outputs(cfg_s, cfg_s.num_views, seed), "cuda")
             rigid = pl.scene_rigid_transform(cfg_s.voxel_size, seed)
             return pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda", val_keep=int(args.get("val_keep", 10 ** 7)))

@@ -87,3 +87,85 @@ def test_lseg_path_low_resolution_feature_maps():
     assert (F.cpu() - ref["lifted"]).abs().max() <= 1e-6
     res = hp.evaluate_scene(batch, vlm)
     assert (res["scene_features"].cpu() - ref["scene_features"]).abs().max() < 1e-4
+
+
+def test_config_v_three_scannet_val_scene_sizes(golden_dir):
+    """BASELINE configs[2] as a workload: scenes of the smallest, a typical and the largest ScanNet-val size (28k / ~115k /
+    302k points, tests/golden/scannet_val_point_counts.txt) through the whole device path at the benchmark's shape
+    (25 views, D=512, K=96, 19 applications, f16x3 student 518->512x9->128).  The oracle cannot run at these sizes in
+    seconds: size-independent properties + exact IoU bookkeeping."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    from geopurify_amd import pipeline as pl
+    from geopurify_amd import synthetic as syn
+    sizes = sorted(int(float(v)) for v in open(os.path.join(golden_dir, "scannet_val_point_counts.txt")).read().split())
+    pick = [sizes[0], sizes[len(sizes) // 2 + 20], sizes[-1]]
+    assert pick[0] == 28231 and pick[2] == 301855 and 100_000 < pick[1] < 130_000
+    base = syn.CONFIGS["S"]
+    vlm_np = syn.make_vlm_outputs(base, base.num_views, 1)
+    vlm = pl.SyntheticVLM(vlm_np, "cuda")
+    sd = pl.random_student_state_dict(base.feat_dim + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
+    hp = pl.HotPath(pl.StudentWeights(sd, "cuda"), base.mask_shape, K=96, num_iters=19, device="cuda")
+    counts = torch.zeros((3, base.num_classes), dtype=torch.int64, device="cuda")
+    labelled = 0
+    for i, n in enumerate(pick):
+        cfg = dataclasses.replace(base, num_points=n)
+        scene = syn.make_scene(cfg, 900 + i)
+        batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), pl.scene_rigid_transform(cfg.voxel_size, 900 + i), "cuda")
+        assert batch.scene_coords.shape[0] == n and len(batch.views) >= 10
+        F, text, scale = hp.lift_masks(batch, vlm)
+        out = hp.refine(batch, F)
+        assert hp.stats["pool_kernel"] == "pool_mfma_kernel" and 0.6 * n < hp.stats["Nv"] <= n
+        assert out.shape == (n, 512) and torch.isfinite(out).all()
+        # pooling is a convex combination of voxel means of the lifted rows: every column stays inside the lifted range
+        assert (out.amax(0) <= F.amax(0) + 1e-5).all() and (out.amin(0) >= F.amin(0) - 1e-5).all()
+        # points of one voxel get the same pooled row
+        inv = batch.scene_inds_reconstruct
+        first = torch.zeros(hp.stats["Nv"], dtype=torch.int64, device="cuda").scatter_(0, inv, torch.arange(n, device="cuda"))
+        assert torch.equal(out, out[first[inv]])
+        before = counts.clone()
+        pred, zero = hp.classify_and_count({"scene_features": out, "text_features": text, "logit_scale": scale}, batch.scene_label,
+                                           base.num_classes, base.ignore_ids, counts)
+        d = (counts - before).cpu()
+        lab = torch.from_numpy(scene.labels)
+        valid = lab < base.num_classes
+        assert torch.equal(d[2], torch.bincount(lab[valid], minlength=base.num_classes))           # target histogram exact
+        assert int(d[1].sum()) == int(valid.sum()) and (d[0] <= d[2]).all() and (d[0] <= d[1]).all()
+        assert torch.equal(d[0], torch.bincount(lab[valid & (pred.cpu() == lab)], minlength=base.num_classes))
+        labelled += int(valid.sum())
+    assert int(counts[2].sum()) == labelled
+
+
+def test_bench_two_ranks_share_one_gpu_counts_are_the_sum(tmp_path):
+    """with --streams 2 every scene's histogram atomics run on side streams; the one collective must be ordered
+    after them.  Two ranks (gloo, both on this box's single GPU) run bench.py; the all-reduced target counts must equal the
+    labelled points of every scene both ranks evaluated."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from geopurify_amd import synthetic as syn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    steps, nscn = 6, 2
+    env = dict(os.environ, GP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1",
+           "--config", "T", "--scenes", str(nscn), "--streams", "2", "--no-cpu-baseline", "--no-train"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    cfg = syn.CONFIGS["T"]
+    want = 0
+    for rank in range(2):
+        per_scene = [int((syn.make_scene(cfg, 5557 + 1000 * rank + s).labels < cfg.num_classes).sum()) for s in range(nscn)]
+        want += sum(per_scene[i % nscn] for i in range(steps))
+    assert rec["n_gpus"] == 2 and rec["iou_target_points"] == want, (rec["iou_target_points"], want)
+    assert rec["value"] > 0 and rec["stages_ms_per_scene"]

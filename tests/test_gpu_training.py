@@ -301,7 +301,8 @@ def test_train_driver_loop_and_checkpoints(ops, tmp_path):
     cfg = syn.CONFIGS["T"]
     args = gp_config.CfgNode({"mask_shape": list(cfg.mask_shape), "epochs": 2, "save_path": str(tmp_path), "save_freq": 1, "print_freq": 1})
     (tmp_path / "model").mkdir()
-    model = SonataXAffinityTrainer(args, device="cuda", use_lseg=False, feature_dim=cfg.feat_dim, hidden_dim=128).to("cuda")
+    model = SonataXAffinityTrainer(args, device="cuda", use_lseg=False, feature_dim=cfg.feat_dim, hidden_dim=128,
+                                   allow_deferred_vlm=True).to("cuda")
     model.num_anchors_per_scene = 128
     batches = []
     for i in range(2):

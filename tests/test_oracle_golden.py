@@ -212,3 +212,36 @@ def test_sampler_matches_reference(golden_dir):
     # the faiss stand-in rows really are the anchors' nearest neighbours
     nn = o_train.knn_points_bruteforce(g["xyz"], anchor.numpy()[:8], g["nbr_anchor"].shape[1])
     assert np.array_equal(nn, g["nbr_anchor"][:8].astype(np.int64))
+
+
+def test_validate_tail_matches_reference(golden_dir):
+    """8f-2: oracle.validate reproduces the reference's validate() (run/validation.py:413-553) on three scenes, two of them
+    with all-zero feature rows: predictions after the (y,z)-only nearest fill, per-class counts, running Base/Novel/All
+    numbers and the log strings, line for line."""
+    import torch
+    from oracle import validate as o_val
+    g = np.load(os.path.join(golden_dir, "ref_validate.npz"))
+    C = int(g["test_classes"])
+    ign = [int(v) for v in g["test_ignore_label"]]
+    meters = o_val.Meters(C, g["base_category"], g["novel_category"])
+    lines = []
+    n = int(g["num_scenes"])
+    for i in range(n):
+        pred, (I, U, T) = o_val.scene_tail(torch.from_numpy(g[f"s{i}_features"]), torch.from_numpy(g[f"s{i}_text"]),
+                                           float(g["logit_scale"]), torch.from_numpy(g[f"s{i}_coords"]), g[f"s{i}_label"], C, ign)
+        ref_pred = g[f"s{i}_pred"].copy()
+        # the fixture holds `output` as intersectionAndUnionGPU received it, i.e. before its in-place ignore overwrite
+        assert np.array_equal(pred.numpy(), ref_pred)
+        zero = g[f"s{i}_zero"]
+        if zero.any():                                       # the fill really used (y, z): a full-xyz fill gives other sources
+            c = g[f"s{i}_coords"].astype(np.float64)
+            seen = np.where(~zero)[0]
+            d_yz = ((c[zero][:, None, 1:3] - c[seen][None, :, 1:3]) ** 2).sum(-1).argmin(1)
+            d_xyz = ((c[zero][:, None, :] - c[seen][None, :, :]) ** 2).sum(-1).argmin(1)
+            assert (d_yz != d_xyz).mean() > 0.5
+            assert np.array_equal(ref_pred[zero], ref_pred[seen[d_yz]])
+        meters.update(I, U, T)
+        lines += o_val.log_lines(i, n, meters.summary())
+    assert lines == [str(s) for s in g["log_lines"]]
+    s = meters.summary()
+    assert np.float32(s["Base"]["mIoU"]) == np.float32(g["result"][0]) and np.float32(s["Novel"]["mIoU"]) == np.float32(g["result"][1])

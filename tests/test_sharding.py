@@ -110,3 +110,95 @@ def test_two_rank_gradient_allreduce_is_the_mean():
     for r in range(2):
         for k in want:
             assert np.allclose(res[r][k], want[k], atol=1e-6)
+
+
+def test_summary_and_log_lines_match_reference_validate(golden_dir):
+    """The running Base/Novel/All numbers and the log strings of the product (sharding.summarize / log_lines on exact
+    int64 counts) equal what the reference's validate() logged (tests/golden/ref_validate.npz), line for line."""
+    import os
+    from oracle import metric
+    g = np.load(os.path.join(golden_dir, "ref_validate.npz"))
+    C = int(g["test_classes"])
+    ign = [int(v) for v in g["test_ignore_label"]]
+    split = {"base_category": g["base_category"].tolist(), "novel_category": g["novel_category"].tolist()}
+    counts = torch.zeros((3, C), dtype=torch.int64)
+    ref = [str(s) for s in g["log_lines"]]
+    n = int(g["num_scenes"])
+    per = len(ref) // n
+    for i in range(n):
+        I, U, T = metric.intersection_and_union(g[f"s{i}_pred"], g[f"s{i}_label"], C, ign)
+        counts += torch.from_numpy(np.stack([I, U - T + I, T]))
+        lines = ["Process: [{}/{}]".format(i, n)] + sharding.log_lines(sharding.summarize(counts, split))
+        assert lines == ref[i * per:(i + 1) * per]
+    s = sharding.summarize(counts, split)
+    assert np.float32(s["Base"]["mIoU"]) == np.float32(g["result"][0])
+    assert np.float32(s["Novel"]["mIoU"]) == np.float32(g["result"][1])
+
+
+def test_equal_steps_scene_ids():
+    for n, w in ((4, 8), (5, 2), (7, 3), (8, 8), (1, 4), (312, 8)):
+        parts = [sharding.equal_steps_scene_ids(n, r, w) for r in range(w)]
+        assert len({len(p) for p in parts}) == 1 and len(parts[0]) == -(-n // w)
+        assert set(sum(parts, [])) == set(range(n))              # every scene is used; surplus slots wrap around
+    assert sharding.equal_steps_scene_ids(0, 0, 2) == []
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _train_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geopurify_amd import train_driver as td
+        torch.manual_seed(0)
+
+        class Student(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.a, self.b, self.c = (torch.nn.Linear(3, 3) for _ in range(3))
+
+            def get_param_groups(self):
+                return {"input": list(self.a.parameters()), "middle": list(self.b.parameters()), "output": list(self.c.parameters())}
+
+        class Model(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.affinity_student = Student()
+
+            def forward(self, batch):
+                s = self.affinity_student
+                return s.c(s.b(s.a(batch))).pow(2).mean()
+
+        model = Model()
+        ids = sharding.equal_steps_scene_ids(3, rank, world)       # odd scene count on two ranks
+        loader = [torch.full((4, 3), float(i + 1)) for i in ids]
+        opt = td.build_optimizer(model.affinity_student, 1e-2, 0.0)
+        sch = td.build_scheduler(opt, 1e-2, 0, 2, len(loader))
+        args = td.gp_config.CfgNode({"epochs": 2, "print_freq": 1})
+        td.train(model, opt, sch, loader, args, rank=rank, world=world)
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        q.put((rank, len(loader), sch.get_last_lr(), flat.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_loop_two_ranks_odd_scene_count(tmp_path):
+    """with num_scenes % world != 0 every rank must still run the same number of steps (one gradient
+    all-reduce each), end with identical weights and identical learning rates -- and not hang."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 2
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][3], res[1][3])                   # same averaged gradients -> same weights on both ranks
