@@ -408,6 +408,7 @@ def main():
         dist.all_reduce(counts)                       # the one collective: int64 [3,C] IoU counts
     barrier()
     dt = time.perf_counter() - t0
+    iou_target_points = int(counts[2].sum().item())   # labelled points counted over ALL ranks (before any untimed side pass)
     if world == 1:
         busy = dt
     pool_timer.enabled = conv_timer.enabled = False
@@ -478,7 +479,7 @@ def main():
             "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
-            "iou_target_points": int(counts[2].sum().item()),      # labelled points counted over ALL ranks (after the all-reduce)
+            "iou_target_points": iou_target_points,
         }
         if val_mode:
             out["shard"] = dict(shard, busy_s_per_rank=[round(b, 4) for b in busy_all],
