@@ -44,7 +44,7 @@ def parse():
                     help="cpu_baseline: one whole scene of the workload through the oracle (measured, ~1 min at S) or the "
                          "bounded sub-sampled scene extrapolated per stage")
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
-    ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma", "tiles", "ell"])
+    ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma", "mfma_persist", "tiles", "ell"])
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams: consecutive scenes alternate streams so that one scene's\n                    loader/lift kernels overlap the previous scene's pooling tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,7 +144,7 @@ class PoolTimer:
 
     def wrap(self, ops):
         timer = self
-        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply"):
+        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply", "pool_mfma_apply_persistent"):
             orig = getattr(ops, name)
 
             def timed(*a, _orig=orig, _name=name, **k):
@@ -155,13 +155,19 @@ class PoolTimer:
                 e0.record(s)
                 r = _orig(*a, **k)
                 e1.record(s)
-                timer.events.append((e0, e1))
+                nv = int(a[1].nv) if hasattr(a[1], "nv") else int(a[1].shape[0])               # voxel rows of this launch
+                timer.events.append((e0, e1, nv))
                 timer.kernel = _name
                 return r
             setattr(ops, name, timed)
 
     def mean_ms(self):
-        return float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else float("nan")
+        return float(np.mean([a.elapsed_time(b) for a, b, _ in self.events])) if self.events else float("nan")
+
+    def totals(self):
+        """(sum of launch times in ms, sum of voxel rows) over the recorded launches: scenes of different sizes (config V)
+        are priced by their own voxel counts."""
+        return float(sum(a.elapsed_time(b) for a, b, _ in self.events)), int(sum(nv for _, _, nv in self.events))
 
 
 class ConvTimer:
@@ -431,6 +437,8 @@ def main():
         Nv = hp.stats["Nv"]
         D = cfg.feat_dim
         pool_ms = pool_timer.mean_ms()
+        per_row = 2 * D * 4 + 96 * 8                      # algorithmic bytes per voxel row and application of A
+        tot_ms, tot_rows = pool_timer.totals()
         # the same launches with nothing else on the GPU (with --streams 2 the timed region overlaps the pooling
         # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth)
         pool_timer.events, pool_timer.enabled = [], True
@@ -438,8 +446,8 @@ def main():
         torch.cuda.synchronize()
         pool_timer.enabled = False
         pool_ms_alone = pool_timer.mean_ms()
-        pool_bytes = Nv * (2 * D * 4 + 96 * 8)           # algorithmic bytes per application of A
-        achieved = pool_bytes / (pool_ms * 1e-3) / 1e9
+        pool_bytes = Nv * per_row
+        achieved = tot_rows * per_row / (tot_ms * 1e-3) / 1e9      # all timed launches, each priced by its own voxel count
         # per-stage breakdown from a ONE-stream side pass (stage marks are meaningless while two scenes interleave)
         stage = StageTimer()
         side = min(2, max(args.scenes, 1))

@@ -18,7 +18,9 @@ extern "C" int gp_version(void) { return 100; }
 // 3 = conv phase-1 ablation mask (1 no loads after step 0, 2 no MFMA, 8 no partial stores, 16 register-staged path,
 // 32 LDS-staged epilogue), 4 = matrix-core pooling ablation mask (1 no reads/MFMA, 2 no row gather, 4 no epilogue,
 // 8 no weight fragments, 16 no output stores), 5 = force brute-force 1-NN, 6 = 1-NN grid cells per axis,
-// 9 = matrix-core pooling: force one workgroup per CU
+// 8 no weight fragments, 16 no output stores; persistent kernel: 32 waves 4-7 issue DMA after the sweep, 64 nt weight loads),
+// 9 = matrix-core pooling: force one workgroup per CU, 10 = persistent pooling: workgroups per XCD label (0 = CUs/8),
+// 11 = persistent pooling: 3 forces the 3-deep X ring
 int g_gp_knobs[16] = {0, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int gp_debug_set(int32_t key, int32_t value) {
     if (key < 1 || key > 15) return GP_EINVAL;

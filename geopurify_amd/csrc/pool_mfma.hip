@@ -170,7 +170,6 @@ struct PqGeo {
     static constexpr int EP = WC + 4;                    // epilogue staging pitch (floats)
     static constexpr int ROWB = (RPW == 8 ? 2 : 4) * RB; // LDS distance row 8g+q -> row 8g+q+4
     static constexpr size_t SMEM = (size_t)NST * STAGE;
-    static_assert(BR / 16 == NW, "one weight fragment group per wave to stage");
     static_assert(RPW / RPI == 2, "two row instructions per plane and wave");
     static_assert((size_t)NW * MT * 16 * EP * sizeof(float) <= SMEM, "epilogue staging must fit in the ring");
     static_assert(OFF_W + 2 * NW * 1024 < 65536, "intra-stage LDS offsets are 16-bit immediates");
@@ -261,6 +260,333 @@ __device__ __forceinline__ void pq_sweep(f32x4 *acc, s16x4 (&fa)[2][2][2], s16x4
     }
 }
 
+// ---- persistent variant: operands swapped (A = staged X columns, B = weights), so that the accumulator holds
+//      4 CONSECUTIVE OUTPUT COLUMNS per lane (D[m = column 4(l>>4)+r][n = row l&15]) and the epilogue stores straight
+//      from registers -- no LDS staging, the ring is never drained
+template <typename G, int MT>
+__device__ __forceinline__ void pg_mma_group(f32x4 *acc, const s16x4 (&f)[2][2][2], const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
+    f16x8 bh[2], bl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { bh[u] = pq_cat(f[u][0][0], f[u][0][1]); bl[u] = pq_cat(f[u][1][0], f[u][1][1]); }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc[mt * G::NCB + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[u], ah[mt], acc[mt * G::NCB + u], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc[mt * G::NCB + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[u], ah[mt], acc[mt * G::NCB + u], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc[mt * G::NCB + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[u], al[mt], acc[mt * G::NCB + u], 0, 0, 0);
+}
+template <typename G, int MT, int CB>
+__device__ __forceinline__ void pg_sweep(f32x4 *acc, s16x4 (&fa)[2][2][2], s16x4 (&fb)[2][2][2], const uint32_t (&addr)[8],
+                                         const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
+    if constexpr (CB + 2 < G::NCB) {
+        pq_read_group<G, CB + 2>(fb, addr);
+        pq_wait_lgkm<8>(fa);
+        pg_mma_group<G, MT>(acc + CB, fa, ah, al);
+        pg_sweep<G, MT, CB + 2>(acc, fb, fa, addr, ah, al);
+    } else {
+        pq_wait_lgkm<0>(fa);
+        pg_mma_group<G, MT>(acc + CB, fa, ah, al);
+    }
+}
+
+// Persistent matrix-core pooling: ONE 512-thread workgroup per CU owns 16*MT*4 rows x 256 columns at a time (4 row
+// groups x 2 column groups of waves: the two column groups share every staged weight fragment, which halves the
+// weight traffic of the 128-column kernel above) and walks a strided list of (row block, column half) tiles: workgroup
+// i of XCD label q = blockIdx & 7 takes tiles lo_q + i, lo_q + i + 32, ... of the label's contiguous tile range, so
+// the 32 workgroups of an XCD work on 32 adjacent tiles at any time (the halo rows they share meet in that XCD's L2).
+//
+// The gather is latency-bound by the bytes a CU keeps in flight (Little: ~2 us issue->landed under load), and LDS is
+// both the buffer and the in-flight space, so the two operand streams get rings of their own depth:
+//   X ring  XD stages of 32 union rows x 256 columns x {hi, lo} (32 KiB), issued XD-1 steps ahead;
+//   W ring  3 stages of the step's weight fragments (+ row ids), issued 2 steps ahead; W-stage g carries the row ids
+//           of X-stage g + (XD-1), read back from LDS at step g when that X stage is issued.
+// Both rings run THROUGH tile boundaries (the next tile's first stages are issued during the last steps of the
+// current one) and the epilogue stores go out with the rings full: the accumulators hold 4 consecutive output columns
+// per lane (operands swapped, see pg_mma_group), so they are stored straight from registers.  All waits are
+// hand-counted (vector-memory operations complete in issue order): per step every wave issues [W (MT), ids (1),
+// X (4)] = DPS operations, and at the end of step g it needs W(g+1), its ids and X(g+1) => at most
+// 4 (XD-3) + DPS (+ the stores of an epilogue issued since) younger operations may be outstanding.
+// Needs >= XD + 1 steps per tile (host-checked) and output buffers padded to whole row blocks (no store predicate =>
+// a fixed number of vector-memory operations per wave).  Waves 4-7 issue their DMA after the sweep, so that the two
+// waves of a SIMD alternate DMA issue and matrix work (knob bit 5 turns that off: 4-8 % slower).  Measured and left out:
+// non-temporal weight loads, sc1 / nt output stores (all within run-to-run noise), a 4-deep X ring (no gain while the
+// weight ring stays 2 steps ahead), G consecutive tiles per workgroup handed out by the dispatcher (slower: the 32
+// workgroups of an XCD then work 32 G tiles apart and the halo rows no longer meet in L2).
+// The epilogue goes through a wave-private LDS area (inline-asm LDS operations with their own lgkmcnt waits: a
+// compiler-visible LDS access would wait for every outstanding LDS-DMA) so that each store instruction writes 4 rows x
+// 256 contiguous bytes: the 32-byte pieces of a store straight from the accumulators cost 4x the L2 write requests,
+// and the kernel runs at the L2 request rate.
+template <int MT, int XD>
+struct PgGeo {
+    using Q = PqGeo<8, 256, MT, 2>;
+    static constexpr int NWF = 4 * MT;                       // 16-row weight fragments per stage and plane
+    static constexpr int XSTAGE = 2 * Q::PLANE;              // 32 KiB
+    static constexpr int WD = 3;
+    static constexpr int OFF_ID = 2 * NWF * 1024;            // inside a W stage
+    static constexpr int WSTAGE = OFF_ID + 8 * 256;
+    static constexpr int WRING = XD * XSTAGE;
+    static constexpr int AHX = XD - 1;
+    static constexpr int DPS = 5 + MT;                       // DMA instructions per wave and step: MT weights, 1 ids, 4 rows
+    static constexpr int BASE_WAIT = 4 * (AHX - 2) + DPS;
+    // epilogue staging: per wave 16 rows x 256 B (+16 B pitch skew) -- one f16 plane of its 16 x 128 tile, or half of the
+    // fp32 tile -- so that the tile leaves in 256-byte row runs (2 full lines per request instead of 32-byte pieces)
+    static constexpr int STG_PITCH = 272, STG_WAVE = 16 * STG_PITCH;
+    static constexpr int OFF_STG = XD * XSTAGE + WD * WSTAGE;
+    static constexpr size_t SMEM = (size_t)OFF_STG + 8 * STG_WAVE;
+    static_assert(WSTAGE < 65536, "intra-stage LDS offsets are 16-bit immediates");
+    static_assert(SMEM <= 160 * 1024, "rings + epilogue staging must fit the CU's LDS");
+};
+
+struct PgTile { int64_t b; int col0; int64_t ub0; int n; };
+
+template <int OFF>
+__device__ __forceinline__ void pg_wr64(uint32_t addr, f16x4 v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void pg_wr128(uint32_t addr, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void pg_rd128(f32x4 &d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void pg_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pg_lgkm0(f32x4 (&r)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
+}
+
+template <int MT, int XD, bool F32OUT>
+__global__ void __launch_bounds__(512)
+pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
+                         const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
+                         const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nblocks,
+                         _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
+                         int64_t ld_yf, const float *__restrict__ out_scale, int knobs, int chunk) {
+    using P = PgGeo<MT, XD>;
+    using G = typename P::Q;
+    static_assert(MT == 1, "the staged epilogue is written for 16 rows x 128 columns per wave");
+    constexpr int NWF = P::NWF, AHX = P::AHX, NSTORE = 8;      // per wave and tile: 2 passes x 4 row-run stores
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- this workgroup's tile list
+    const int64_t T = nblocks * 2;
+    // chunk == 0: persistent, workgroup wi of the label walks tiles lo+wi, lo+wi+32, ...; chunk = G > 0: workgroup wi takes the G
+    // consecutive tiles lo + G wi .. (the grid then has T/G workgroups, handed out in order by the dispatcher)
+    const int label = blockIdx.x & 7, wi = blockIdx.x >> 3, stride = chunk > 0 ? 1 : (int)(gridDim.x >> 3);
+    const int64_t lo = label * T / 8, hi_label = (label + 1) * T / 8;
+    int64_t t = chunk > 0 ? lo + (int64_t)wi * chunk : lo + wi;
+    const int64_t hi = chunk > 0 ? (t + chunk < hi_label ? t + chunk : hi_label) : hi_label;
+    if (t >= hi) return;
+    auto load_tile = [&](int64_t tt) {
+        PgTile r;
+        r.b = tt >> 1;
+        r.col0 = (int)(tt & 1) * 256;
+        r.ub0 = bu_off[r.b];
+        r.n = (int)((bu_off[r.b + 1] - r.ub0) / PM_KS);
+        return r;
+    };
+    PgTile cur = load_tile(t);
+    bool has1 = t + stride < hi, has2 = t + 2 * (int64_t)stride < hi;
+    PgTile nx1 = has1 ? load_tile(t + stride) : cur;
+    PgTile nx2 = has2 ? load_tile(t + 2 * (int64_t)stride) : cur;
+    const bool late_issue = !(knobs & 32) && wv >= 4;
+
+    // ---- DMA roles (same staging geometry as PqGeo<8,256,..>: 4 rows per wave, two 1-KiB instructions per plane)
+    const int du = lane / (64 / G::RPI), dc = lane % (G::RB / 16);
+    const int row_i0 = G::RPW * wv + 2 * du;
+    const int t0 = (row_i0 & 3) | (((row_i0 >> 3) & 1) << 2), t1 = ((row_i0 + 1) & 3) | ((((row_i0 + 1) >> 3) & 1) << 2);
+    const int dcol0 = (dc ^ (2 * t0)) * 8, dcol1 = (dc ^ (2 * t1)) * 8;
+    auto issue_x = [&](const PgTile &TT, int2 id, int xslot) {
+        unsigned char *dst = smem_raw + xslot * P::XSTAGE;
+        const int64_t s0 = (int64_t)id.x * ld_x + TT.col0 + dcol0, s1 = (int64_t)id.y * ld_x + TT.col0 + dcol1;
+        glds16(x_hi + s0, dst + (G::RPW * wv) * G::RB);
+        glds16(x_lo + s0, dst + G::PLANE + (G::RPW * wv) * G::RB);
+        glds16(x_hi + s1, dst + (G::RPW * wv) * G::RB + 1024);
+        glds16(x_lo + s1, dst + G::PLANE + (G::RPW * wv) * G::RB + 1024);
+    };
+    // W stage (TT, k) -> W-ring slot, with the row ids of (IT, kid)
+    auto issue_w = [&](const PgTile &TT, int k, const PgTile &IT, int kid, int wslot) {
+        unsigned char *dst = smem_raw + P::WRING + wslot * P::WSTAGE;
+        const int64_t ks = TT.ub0 / PM_KS + k;
+        const int32_t *ids = bu_row + IT.ub0 + G::RPW * wv + (int64_t)kid * PM_KS + (lane & (G::RPW - 1));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int L = wv + 8 * i, plane = L / NWF, frag = L % NWF;
+            const _Float16 *src = (plane ? wa_lo : wa_hi) + ((ks * NWF + frag) * 64 + lane) * 8;
+            glds16(src, dst + L * 1024);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ids,
+                                         (__attribute__((address_space(3))) void *)(dst + P::OFF_ID + wv * 256), 4, 0, 0);
+    };
+
+    // ---- read roles
+    const int rg = wv % G::RGN, cg = wv / G::RGN;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+    uint32_t addr[8];
+    {
+        const int r = 8 * g + q, r_w = r % G::RPW;
+        const int slot = (r / G::RPW) * G::RPW + G::RPI * (r_w & 1) + (r_w >> 1);
+        const uint32_t rowb = (uint32_t)slot * G::RB + (uint32_t)(cg * G::WC * 2) + (uint32_t)((p >> 1) * 16 + (p & 1) * 8);
+        const uint32_t tt = (uint32_t)(q | ((g & 1) << 2));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) addr[k] = lds0 + ((rowb + 32u * k) ^ (tt << 5));
+    }
+    const uint32_t addr_w = lds0 + P::WRING + (MT * rg) * 1024 + lane * 16;
+    const uint32_t addr_id = lds0 + P::WRING + P::OFF_ID + wv * 256 + du * 8;
+    const uint32_t stg = lds0 + P::OFF_STG + wv * P::STG_WAVE;                          // epilogue staging, wave-private
+    const uint32_t rd = stg + (lane >> 4) * P::STG_PITCH + (lane & 15) * 16;
+
+    f32x4 acc[MT * G::NCB];
+#pragma unroll
+    for (int i = 0; i < MT * G::NCB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: X stages 0 .. AHX-1 and W stages 0, 1 of the first tile (every tile has >= AHX + 2 steps)
+    {
+        const int32_t *idg = bu_row + cur.ub0 + G::RPW * wv;
+        int2 ip[AHX];
+#pragma unroll
+        for (int j = 0; j < AHX; ++j) ip[j] = *reinterpret_cast<const int2 *>(idg + j * PM_KS + 2 * du);
+#pragma unroll
+        for (int j = 0; j < AHX; ++j) asm volatile("" ::"v"(ip[j].x), "v"(ip[j].y));   // the id loads land before the first DMA
+        issue_w(cur, 0, cur, AHX, 0);
+        issue_x(cur, ip[0], 0);
+        issue_w(cur, 1, cur, AHX + 1, 1);
+        issue_x(cur, ip[1], 1);
+        if constexpr (AHX == 3) issue_x(cur, ip[2], 2);
+        pq_handover<P::BASE_WAIT>();
+    }
+    const float inv = (1.f / PM_WSCALE) * (out_scale ? out_scale[0] : 1.f);
+    const int fl = lane & 15, fq = lane >> 4;
+    s16x4 f0[2][2][2], f1[2][2][2];
+    f16x8 ah[MT], al[MT];
+    int2 idn;
+    int xs = 0, ws = 0;
+    bool first_tile = true;
+    for (;;) {
+        const int n = cur.n;
+        for (int s = 0; s < n; ++s) {
+            const uint32_t xoff = (uint32_t)xs * P::XSTAGE, woff = (uint32_t)ws * P::WSTAGE;
+            uint32_t a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = addr[k] + xoff;
+            pq_rd64(idn, addr_id + woff);
+            pq_rd128<0>(ah[0], addr_w + woff);
+            pq_rd128<NWF * 1024>(al[0], addr_w + woff);
+            if constexpr (MT == 2) {
+                pq_rd128<1024>(ah[1], addr_w + woff);
+                pq_rd128<NWF * 1024 + 1024>(al[1], addr_w + woff);
+            }
+            pq_read_group<G, 0>(f0, a);
+            pq_wait_lgkm3<8>(idn, ah, al);
+            const int xs2 = xs + AHX >= XD ? xs + AHX - XD : xs + AHX;
+            const int ws2 = ws + 2 >= P::WD ? ws + 2 - P::WD : ws + 2;
+            const int kx = s + AHX, kw = s + 2;
+            const bool x_any = kx < n || has1, w_any = kw < n || has1;
+            auto do_issue = [&]() {
+                // W stage two steps ahead (this tile's, or step 0 / 1 of the next tile) with the row ids of the X stage that
+                // will be issued when it is read; X stage AHX steps ahead.  Wave-uniform selects instead of code copies.
+                const bool wc = kw < n;
+                const PgTile &TW = wc ? cur : nx1;
+                const int kwl = wc ? kw : kw - n;
+                int ki = kwl + AHX;
+                const bool id_next = wc && ki >= n && has1;            // ids of the next tile's first stages ride in this tile's last ones
+                const PgTile &TI = id_next ? nx1 : TW;
+                ki = id_next ? ki - n : (ki < TW.n ? ki : TW.n - 1);
+                if (wc || has1) issue_w(TW, kwl, TI, ki, ws2);
+                const bool xc = kx < n;
+                if (xc || has1) issue_x(xc ? cur : nx1, idn, xs2);
+            };
+            if (!late_issue) do_issue();
+            pg_sweep<G, MT, 0>(acc, f0, f1, a, ah, al);
+            if (late_issue) do_issue();
+            const bool last = s == n - 1;
+            if (last) {
+                // epilogue: lane (fl, fq) holds columns 16 cb + 4 fq .. +3 of row fl.  The wave's 16 x 128 tile is transposed
+                // through its private LDS area one plane (or half an fp32 tile) at a time and leaves in 256-byte row runs:
+                // lane l stores 16 bytes of row (l >> 4) + 4 pass, 16-byte chunk l & 15.
+                const int64_t row0 = cur.b * G::BR + rg * 16 + (lane >> 4);
+                const int colw = cur.col0 + cg * G::WC;
+                f32x4 r[4];
+                if constexpr (F32OUT) {
+                    const uint32_t wr = stg + fl * P::STG_PITCH + fq * 16;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        pg_wr128<0>(wr, acc[half * 4 + 0] * inv);
+                        pg_wr128<64>(wr, acc[half * 4 + 1] * inv);
+                        pg_wr128<128>(wr, acc[half * 4 + 2] * inv);
+                        pg_wr128<192>(wr, acc[half * 4 + 3] * inv);
+                        pg_lgkm0();
+                        pg_rd128<0>(r[0], rd);
+                        pg_rd128<4 * P::STG_PITCH>(r[1], rd);
+                        pg_rd128<8 * P::STG_PITCH>(r[2], rd);
+                        pg_rd128<12 * P::STG_PITCH>(r[3], rd);
+                        pg_lgkm0(r);
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps)
+                            *reinterpret_cast<f32x4 *>(y_f32 + (row0 + 4 * ps) * ld_yf + colw + half * 64 + (lane & 15) * 4) = r[ps];
+                    }
+                } else {
+                    const uint32_t wr = stg + fl * P::STG_PITCH + fq * 8;
+                    f16x4 h[G::NCB], l[G::NCB];
+#pragma unroll
+                    for (int cb = 0; cb < G::NCB; ++cb) {
+                        const f32x4 v = acc[cb] * inv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { h[cb][i] = (_Float16)v[i]; l[cb][i] = (_Float16)(v[i] - (float)h[cb][i]); }
+                    }
+#pragma unroll
+                    for (int plane = 0; plane < 2; ++plane) {
+                        const f16x4 *src = plane ? l : h;
+                        pg_wr64<0>(wr, src[0]);   pg_wr64<32>(wr, src[1]);  pg_wr64<64>(wr, src[2]);  pg_wr64<96>(wr, src[3]);
+                        pg_wr64<128>(wr, src[4]); pg_wr64<160>(wr, src[5]); pg_wr64<192>(wr, src[6]); pg_wr64<224>(wr, src[7]);
+                        pg_lgkm0();
+                        pg_rd128<0>(r[0], rd);
+                        pg_rd128<4 * P::STG_PITCH>(r[1], rd);
+                        pg_rd128<8 * P::STG_PITCH>(r[2], rd);
+                        pg_rd128<12 * P::STG_PITCH>(r[3], rd);
+                        pg_lgkm0(r);
+                        _Float16 *yp = plane ? y_lo : y_hi;
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps)
+                            *reinterpret_cast<f32x4 *>(yp + (row0 + 4 * ps) * ld_y + colw + (lane & 15) * 8) = r[ps];
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < G::NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // hand-over.  Steady state: [W, ids, X] of this step are the youngest DPS operations, before them the X stage of
+            // the previous step (AHX = 3) and the stores of an epilogue issued since the stage being waited for.
+            if (x_any && w_any) {
+                const bool stores_since = last || (s == 0 && !first_tile);
+                if (stores_since) pq_handover<P::BASE_WAIT + NSTORE>(); else pq_handover<P::BASE_WAIT>();
+            } else {
+                pq_handover<0>();                  // the last steps of the workgroup's last tile: nothing left to overlap
+            }
+            xs = xs + 1 >= XD ? 0 : xs + 1;
+            ws = ws + 1 >= P::WD ? 0 : ws + 1;
+        }
+        if (!has1) break;
+        first_tile = false;
+        t += stride;
+        cur = nx1;
+        nx1 = nx2;
+        has1 = has2;
+        has2 = t + 2 * (int64_t)stride < hi;
+        if (has2) nx2 = load_tile(t + 2 * (int64_t)stride);
+    }
+}
+
 template <int NW, int NC, int MT, int CGN>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1)
 pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
@@ -269,6 +595,7 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
                  _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
                  int64_t ld_yf, int64_t per_xcd, int ablate) {
     using G = PqGeo<NW, NC, MT, CGN>;
+    static_assert(G::BR / 16 == NW, "one weight fragment group per wave to stage");
     constexpr int NQ = PM_D / NC;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -447,7 +774,60 @@ int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
     return GP_OK;
 }
 
+template <int MT, int XD, bool F32OUT>
+int pg_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row, const void *wa_hi,
+              const void *wa_lo, int64_t nblocks, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
+              const float *out_scale, hipStream_t s) {
+    using P = PgGeo<MT, XD>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_persist_kernel<MT, XD, F32OUT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::SMEM));
+        int dev = 0;
+        GP_CHECK_HIP(hipGetDevice(&dev));
+        GP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set = true;
+    }
+    int per_label = g_gp_knobs[10] > 0 ? g_gp_knobs[10] : (n_cu >= 8 ? n_cu / 8 : 1);      // workgroups per XCD label
+    const int chunk = g_gp_knobs[12];                                                      // tuning aid: G consecutive tiles per workgroup
+    if (chunk > 0) per_label = (int)(((nblocks * 2 + 7) / 8 + chunk - 1) / chunk) + 1;
+    pool_mfma_persist_kernel<MT, XD, F32OUT><<<(unsigned)(per_label * 8), 512, P::SMEM, s>>>(
+        static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
+        static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nblocks, static_cast<_Float16 *>(y_hi),
+        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, out_scale, g_gp_knobs[4], chunk);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
 }  // namespace
+
+// Persistent variant (one 512-thread workgroup per CU, 256 columns per workgroup, ring kept full across row blocks).
+// Requirements beyond gp_pool_mfma_apply: every row block has at least 4 steps (5 for the deep X ring) (min_steps, from the builder's bu_off:
+// min over blocks of (bu_off[b+1]-bu_off[b])/32 -- true whenever k >= 97 per block union), and the OUTPUT buffers hold
+// y_rows >= ceil(nv / block_rows) * block_rows rows (rows >= nv receive zeros).  Exactly one of (y_hi, y_lo) / y_f32.
+// out_scale: optional device scalar multiplied into the fp32 output (power-of-two pre-scaling of the split operands).
+extern "C" int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
+                                             const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
+                                             int32_t block_rows, int32_t min_steps, void *y_hi, void *y_lo, int64_t ld_y,
+                                             float *y_f32, int64_t ld_yf, int64_t y_rows, const float *out_scale, void *stream_) {
+    GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && wa_hi && wa_lo && nv > 0, "gp_pool_mfma_apply_persistent: null/empty argument");
+    GP_CHECK_ARG(d == PM_D, "gp_pool_mfma_apply_persistent: d=%d (kernel specialised for %d columns)", d, PM_D);
+    GP_CHECK_ARG(block_rows == 64, "gp_pool_mfma_apply_persistent: block_rows=%d (64; 128-row blocks: gp_pool_mfma_apply)", block_rows);
+    GP_CHECK_ARG(min_steps >= 4, "gp_pool_mfma_apply_persistent: a row block with %d < 4 steps (use gp_pool_mfma_apply)", min_steps);
+    GP_CHECK_ARG(((y_hi && y_lo) != 0) != (y_f32 != nullptr), "gp_pool_mfma_apply_persistent: exactly one output form");
+    GP_CHECK_ARG(ld_x % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0, "gp_pool_mfma_apply_persistent: x rows must be 16-byte aligned");
+    GP_CHECK_ARG(!y_hi || (ld_y % 8 == 0 && (uintptr_t)y_hi % 16 == 0 && (uintptr_t)y_lo % 16 == 0 && y_hi != x_hi && y_lo != x_lo),
+                 "gp_pool_mfma_apply_persistent: y rows must be 16-byte aligned and must not alias x");
+    GP_CHECK_ARG(!y_f32 || (ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0), "gp_pool_mfma_apply_persistent: fp32 output rows must be 16-byte aligned");
+    int64_t nb = (nv + block_rows - 1) / block_rows;
+    GP_CHECK_ARG(y_rows >= nb * block_rows, "gp_pool_mfma_apply_persistent: output needs %lld rows (whole row blocks), has %lld",
+                 (long long)(nb * block_rows), (long long)y_rows);
+    hipStream_t s = gp_stream(stream_);
+#define PG_ARGS x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nb, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s
+    return y_f32 ? pg_launch<1, 3, true>(PG_ARGS) : pg_launch<1, 3, false>(PG_ARGS);
+#undef PG_ARGS
+}
 
 extern "C" size_t gp_pool_mfma_workspace_bytes(int64_t nv, int32_t block_rows) {
     if (nv <= 0 || block_rows <= 0) return 0;

@@ -347,9 +347,14 @@ class PoolMfma:
     """Affinity operator in matrix-core form: per block of block_rows rows the padded neighbour union and the
     dense [block_rows x union] weight block, pre-split to f16 hi/lo in MFMA A-fragment order."""
 
-    def __init__(self, bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows):
+    def __init__(self, bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows, min_steps=0):
         self.bu_off, self.bu_n, self.bu_row, self.wa_hi, self.wa_lo = bu_off, bu_n, bu_row, wa_hi, wa_lo
-        self.nv, self.total, self.block_rows = nv, total, block_rows
+        self.nv, self.total, self.block_rows, self.min_steps = nv, total, block_rows, min_steps
+
+    @property
+    def rows_padded(self):
+        """Rows the persistent kernel's output buffers must hold (whole row blocks)."""
+        return (self.nv + self.block_rows - 1) // self.block_rows * self.block_rows
 
 
 def pool_mfma_build(nbr, w, block_rows=64):
@@ -363,13 +368,13 @@ def pool_mfma_build(nbr, w, block_rows=64):
     bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
     check(lib.gp_pool_mfma_count(_ptr(nbr), nv, int(k), int(block_rows), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(),
                                  _stream()), "gp_pool_mfma_count")
-    total = int(bu_off[nb].item())
+    total, min_rows = torch.stack([bu_off[nb], torch.diff(bu_off).min()]).cpu().tolist()     # the one host sync
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * (block_rows // 16) * 64 * 8, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
     check(lib.gp_pool_mfma_fill(_ptr(nbr), _ptr(w), nv, int(k), int(block_rows), _ptr(bu_off), _ptr(bu_n), total,
                                 _ptr(bu_row), _ptr(wa_hi), _ptr(wa_lo), _stream()), "gp_pool_mfma_fill")
-    return PoolMfma(bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows)
+    return PoolMfma(bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows, min_steps=min_rows // 32)
 
 
 def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
@@ -382,6 +387,21 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
                                  _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows), _ptr(yh), _ptr(yl),
                                  yh.stride(0) if yh is not None else 0, _ptr(out_f32),
                                  out_f32.stride(0) if out_f32 is not None else 0, _stream()), "gp_pool_mfma_apply")
+    return out_f32 if out_f32 is not None else out_split
+
+
+def pool_mfma_apply_persistent(x_split, op, d, out_split=None, out_f32=None, out_scale=None):
+    """Persistent matrix-core pooling (one workgroup per CU).  Outputs need op.rows_padded rows; exactly one output form."""
+    lib = _lib.load()
+    xh, xl = x_split
+    assert xh.stride(0) == xl.stride(0)
+    yh, yl = out_split if out_split is not None else (None, None)
+    rows = (yh if yh is not None else out_f32).shape[0]
+    check(lib.gp_pool_mfma_apply_persistent(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.wa_hi),
+                                            _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows), int(op.min_steps), _ptr(yh), _ptr(yl),
+                                            yh.stride(0) if yh is not None else 0, _ptr(out_f32),
+                                            out_f32.stride(0) if out_f32 is not None else 0, int(rows), _ptr(out_scale), _stream()),
+          "gp_pool_mfma_apply_persistent")
     return out_f32 if out_f32 is not None else out_split
 
 

@@ -428,23 +428,35 @@ class HotPath:
         tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
         if mode == "auto":
             mode = "mfma" if (mfma_ok and self.num_iters >= 3) else ("tiles" if tiles_ok else "ell")
-        if mode == "mfma" and not mfma_ok:
+        if mode in ("mfma", "mfma_persist") and not mfma_ok:
             raise ValueError(f"pool_mode='mfma' needs D == 512 and block_rows*K <= 16384 (D={D}, K={self.K})")
         bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
         if self.num_iters == 0:
             bufs[0].copy_(X[:, :D])
             self._pool_kernel = "none"
             return bufs[0]
-        if mode == "mfma":
-            # matrix-core pooling: operands stay split (hi, lo) f16 between applications, fp32 only at the end
+        if mode in ("mfma", "mfma_persist"):
+            # matrix-core pooling: operands stay split (hi, lo) f16 between applications, fp32 only at the end.
+            # "mfma" (default): one (64 rows x 128 columns) tile per workgroup, two workgroups per CU.
+            # "mfma_persist": the persistent kernel (one workgroup per CU, 256 columns per workgroup, weight fragments shared
+            # by both column groups, rings kept full across row blocks) -- same speed within run-to-run noise on MI355X
+            # (DESIGN.md section 6); needs >= 4 steps per row block and 64-row blocks, else falls back to "mfma"
             op = ops.pool_mfma_build(nbr, w, self.pool_block_rows)
-            sp = [ops.split_f16(X, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))]
+            persistent = mode == "mfma_persist" and op.min_steps >= 4 and self.pool_block_rows == 64
+            rows = op.rows_padded if persistent else Nv
+            out = torch.empty((rows, D), dtype=torch.float32, device=dev)
+            sp = [ops.split_f16(X, D), tuple(torch.empty((rows, D), dtype=torch.float16, device=dev) for _ in range(2))]
+            if persistent and self.num_iters > 1:          # the ping-pong partner of the input planes also needs whole row blocks
+                sp.append(tuple(torch.empty((rows, D), dtype=torch.float16, device=dev) for _ in range(2)))
+            apply = ops.pool_mfma_apply_persistent if persistent else ops.pool_mfma_apply
+            src = sp[0]
             for t in range(self.num_iters):
                 last = t == self.num_iters - 1
-                ops.pool_mfma_apply(sp[t % 2], op, D, out_split=None if last else sp[(t + 1) % 2],
-                                    out_f32=bufs[0] if last else None)
-            self._pool_kernel = "pool_mfma_kernel"
-            return bufs[0]
+                dst = None if last else sp[1 + (t % 2)] if persistent else sp[(t + 1) % 2]
+                apply(src, op, D, out_split=dst, out_f32=out if last else None)
+                src = dst
+            self._pool_kernel = "pool_mfma_persist_kernel" if persistent else "pool_mfma_kernel"
+            return out[:Nv]
         use_tiles = mode == "tiles" and tiles_ok
         tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
         cur = X

@@ -63,7 +63,12 @@ for R in (8,):
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
 variants += [("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
-             ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0))]
+             ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0)),
+             ("persist64 (split out)", ("persist", 64, 0, 0)), ("persist64 (fp32 out)", ("persist32", 64, 0, 0)),
+             ("persist64 no-stagger (split out)", ("persist", 64, 32, 0))]
+ysp = {br: tuple(torch.empty((mf[br].rows_padded, D), dtype=torch.float16, device="cuda") for _ in range(2)) for br in (64,)}
+Yp = {br: torch.empty((mf[br].rows_padded, D), device="cuda") for br in (64,)}
+print("min steps per row block:", {br: mf[br].min_steps for br in (64, 128)}, flush=True)
 ABL = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # pool_mfma ablation bits (timing only, results invalid)
 lib.gp_debug_set(4, ABL)
 lib.gp_debug_set(9, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
@@ -77,6 +82,14 @@ for rnd in range(3):
         elif v[0] == "mfma":
             lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
+        elif v[0] == "persist":
+            lib.gp_debug_set(4, v[2]); lib.gp_debug_set(11, v[3]); lib.gp_debug_set(12, v[4] if len(v) > 4 else 0)
+            t = timeit(lambda: ops.pool_mfma_apply_persistent(xs, mf[v[1]], D, out_split=ysp[v[1]]))
+            lib.gp_debug_set(4, ABL); lib.gp_debug_set(11, 0); lib.gp_debug_set(12, 0)
+        elif v[0] == "persist32":
+            lib.gp_debug_set(4, v[2]); lib.gp_debug_set(11, v[3])
+            t = timeit(lambda: ops.pool_mfma_apply_persistent(xs, mf[v[1]], D, out_f32=Yp[v[1]]))
+            lib.gp_debug_set(4, ABL); lib.gp_debug_set(11, 0)
         elif v[0] == "mfma32":
             lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_f32=Y))

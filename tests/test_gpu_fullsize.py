@@ -98,19 +98,37 @@ def test_pooling_properties_full_size(big):
             ops.pool_ell(z, nbr, w, D, out)
         elif mode == "tiles":
             ops.pool_tiles_apply(z, tiles, D, out)
+        elif isinstance(mode, str):                         # "p64": the persistent kernel (outputs padded to row blocks)
+            op = mfma[int(mode[1:])]
+            assert op.min_steps >= 4
+            outp = torch.empty(op.rows_padded, D, device="cuda")
+            ops.pool_mfma_apply_persistent(ops.split_f16(z, D), op, D, out_f32=outp)
+            # two chained applications through the split (hi, lo) hand-off == two fp32 applications
+            return outp[:Nv]
         else:
             ops.pool_mfma_apply(ops.split_f16(z, D), mfma[mode], D, out_f32=out)
         return out
     ones = torch.ones(Nv, 544, device="cuda")
-    for mode in ("ell", "tiles", 64, 128):
+    for mode in ("ell", "tiles", 64, 128, "p64"):
         assert (P(ones, mode) - 1).abs().max() < 1e-5                                # A 1 = 1
         lin = P((2.0 * X - 0.5 * Y).contiguous(), mode) - (2.0 * P(X, mode) - 0.5 * P(Y, mode))
         assert lin.abs().max() < 1e-4                                                 # linearity
         px = P(X, mode)
         assert (px.amax(0) <= X[:, :D].amax(0) + 1e-5).all() and (px.amin(0) >= X[:, :D].amin(0) - 1e-5).all()   # convexity
     ref = P(X, "ell")
-    for mode in ("tiles", 64, 128):
+    for mode in ("tiles", 64, 128, "p64"):
         assert (P(X, mode) - ref).abs().max() < 1e-5                                  # independent kernels agree
+    # the persistent kernel's split (hi, lo) output feeds its next application: two chained == ELL twice
+    for br in (64,):
+        op = mfma[br]
+        mid = tuple(torch.empty((op.rows_padded, D), dtype=torch.float16, device="cuda") for _ in range(2))
+        outp = torch.empty(op.rows_padded, D, device="cuda")
+        ops.pool_mfma_apply_persistent(ops.split_f16(X, D), op, D, out_split=mid)
+        ops.pool_mfma_apply_persistent(mid, op, D, out_f32=outp)
+        ref2 = torch.empty(Nv, D, device="cuda")
+        ops.pool_ell(ref, nbr, w, D, ref2)
+        assert (outp[:Nv] - ref2).abs().max() < 2e-5
+        assert (outp[Nv:] == 0).all()                                                 # padded rows receive zeros
 
 
 def test_conv_paths_agree_full_size(big):
