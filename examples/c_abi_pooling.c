@@ -80,7 +80,7 @@ int main(void) {
     CHECK_HIP(hipMalloc(&d_wal, wa_bytes));
     CHECK_GP(gp_pool_mfma_fill(d_nbr, d_w, nv, k, br, d_bu_off, d_bu_n, total, d_bu_row, d_wah, d_wal, NULL));
     CHECK_GP(gp_split_f16(d_x, d, d, nv, d_xh, d_xl, d, NULL));
-    CHECK_GP(gp_pool_mfma_apply(d_xh, d_xl, d, d_bu_off, d_bu_row, d_wah, d_wal, nv, d, br, NULL, NULL, 0, d_y, d, NULL));
+    CHECK_GP(gp_pool_mfma_apply(d_xh, d_xl, d, d_bu_off, d_bu_row, d_wah, d_wal, nv, d, br, NULL, NULL, 0, d_y, d, NULL, NULL));
     CHECK_HIP(hipDeviceSynchronize());
 
     float *y = (float *)malloc(sizeof(float) * nv * d);
@@ -95,7 +95,7 @@ int main(void) {
         }
     printf("padded union rows per output row: %.2f, max |y - ref| = %.3g\n", (double)total / (double)nv, worst);
     /* error path: the library reports, it does not abort */
-    int rc = gp_pool_mfma_apply(d_xh, d_xl, d, d_bu_off, d_bu_row, d_wah, d_wal, nv, 300, br, NULL, NULL, 0, d_y, d, NULL);
+    int rc = gp_pool_mfma_apply(d_xh, d_xl, d, d_bu_off, d_bu_row, d_wah, d_wal, nv, 300, br, NULL, NULL, 0, d_y, d, NULL, NULL);
     printf("d = 300 is rejected: rc = %d, \"%s\"\n", rc, gp_last_error());
     if (worst > 1e-5 || rc != GP_EINVAL) { printf("FAILED\n"); return 1; }
     printf("OK\n");

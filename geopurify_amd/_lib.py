@@ -40,7 +40,9 @@ SIGNATURES = {
     "gp_split_f16": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P]),
     "gp_sparse_conv_f16x3": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, c_int32, _P, _P,
                                        c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P,
-                                       c_int64, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), _P]),
+                                       c_int64, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32), _P, _P, _P]),
+    "gp_pow2_scale": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_size_t, _P]),
+    "gp_split_f16_scaled": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P]),
     "gp_l2norm_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P]),
     "gp_knn_workspace_bytes": (c_size_t, [c_int64]),
     "gp_knn_lattice": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
@@ -53,7 +55,7 @@ SIGNATURES = {
     "gp_pool_mfma_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "gp_pool_mfma_count": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "gp_pool_mfma_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P]),
-    "gp_pool_mfma_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P]),
+    "gp_pool_mfma_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_pool_mfma_apply_persistent": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64,
                                                 _P, c_int64, c_int64, _P, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),

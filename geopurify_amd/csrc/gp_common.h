@@ -68,6 +68,17 @@ __device__ __forceinline__ float gp_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// power of two s with amax * s in [2^13, 2^14): the pre-scale of an fp32 -> (hi, lo) f16 split.  Every element within
+// 2^-18 of amax then has a NORMAL f16 lo half (|lo| >= 2^-14), i.e. x = hi + lo to 2^-22 relative; f16 max is 65504.
+// amax == 0 (or not finite) -> 1.  Exponent clamped so that s and 1/s are normal fp32 numbers.
+__device__ __forceinline__ float gp_pow2_for(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(amax, &e);                      // amax = m * 2^e, m in [0.5, 1)
+    int k = 14 - e;                        // amax * 2^k = m * 2^14 in [2^13, 2^14)
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return ldexpf(1.f, k);
+}
 __device__ __forceinline__ int gp_wave_sum_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -466,7 +466,8 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
         if constexpr (AHX == 3) issue_x(cur, ip[2], 2);
         pq_handover<P::BASE_WAIT>();
     }
-    const float inv = (1.f / PM_WSCALE) * (out_scale ? out_scale[0] : 1.f);
+    // split outputs stay in the pre-scaled domain of the planes (pooling is linear); only the fp32 output is scaled back
+    const float inv = (1.f / PM_WSCALE) * ((F32OUT && out_scale) ? out_scale[0] : 1.f);
     const int fl = lane & 15, fq = lane >> 4;
     s16x4 f0[2][2][2], f1[2][2][2];
     f16x8 ah[MT], al[MT];
@@ -593,7 +594,7 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
                  const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
                  const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
                  _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
-                 int64_t ld_yf, int64_t per_xcd, int ablate) {
+                 int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale) {
     using G = PqGeo<NW, NC, MT, CGN>;
     static_assert(G::BR / 16 == NW, "one weight fragment group per wave to stage");
     constexpr int NQ = PM_D / NC;
@@ -698,7 +699,10 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
     }
     if (ablate & 4) return;                                // tuning aid: bit 2 skips the epilogue
     // ---- epilogue through LDS (the ring is drained: the last hand-over waited for vmcnt(0))
-    constexpr float inv = 1.f / PM_WSCALE;
+    // the split planes carry x * s (s = the power of two of gp_pow2_scale, so that the lo halves stay normal f16 numbers);
+    // pooling is linear, so the planes written for the next application stay in that domain and only the fp32 output is
+    // multiplied by out_scale = 1/s
+    const float inv = 1.f / PM_WSCALE;
     float *st = reinterpret_cast<float *>(smem_raw) + wv * (MT * 16 * G::EP);
     const int fl = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -735,7 +739,10 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
                 *reinterpret_cast<f16x4 *>(y_hi + grow * ld_y + colw + c4 * 4) = h;
                 *reinterpret_cast<f16x4 *>(y_lo + grow * ld_y + colw + c4 * 4) = l;
             }
-            if (y_f32) *reinterpret_cast<float4 *>(y_f32 + grow * ld_yf + colw + c4 * 4) = v[it];
+            if (y_f32) {
+                const float so = out_scale ? out_scale[0] : 1.f;
+                *reinterpret_cast<float4 *>(y_f32 + grow * ld_yf + colw + c4 * 4) = make_float4(v[it].x * so, v[it].y * so, v[it].z * so, v[it].w * so);
+            }
         }
     }
 }
@@ -750,7 +757,8 @@ int pm_np2(int64_t n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 template <int NW, int NC, int MT, int CGN>
 int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row, const void *wa_hi,
-              const void *wa_lo, int64_t nv, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, hipStream_t s) {
+              const void *wa_lo, int64_t nv, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale,
+              hipStream_t s) {
     using G = PqGeo<NW, NC, MT, CGN>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -769,7 +777,7 @@ int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
     pool_mfma_kernel<NW, NC, MT, CGN><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
         static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
-        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4]);
+        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -888,7 +896,7 @@ extern "C" int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv,
 extern "C" int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
                                   const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                                   int32_t block_rows, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
-                                  void *stream_) {
+                                  const float *out_scale, void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && wa_hi && wa_lo && nv > 0, "gp_pool_mfma_apply: null/empty argument");
     GP_CHECK_ARG(d == PM_D, "gp_pool_mfma_apply: d=%d (kernel specialised for %d columns)", d, PM_D);
     GP_CHECK_ARG(block_rows == 64 || block_rows == 128, "gp_pool_mfma_apply: block_rows=%d (64 or 128)", block_rows);
@@ -898,6 +906,6 @@ extern "C" int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld
     GP_CHECK_ARG(!y_f32 || ld_yf % 4 == 0, "gp_pool_mfma_apply: fp32 output rows must be 16-byte aligned");
     hipStream_t s = gp_stream(stream_);
     if (block_rows == 64)
-        return pm_launch<4, 128, 1, 1>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, s);
-    return pm_launch<8, 256, 2, 2>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, s);
+        return pm_launch<4, 128, 1, 1>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s);
+    return pm_launch<8, 256, 2, 2>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s);
 }

@@ -258,7 +258,8 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
                        const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
                        const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
                        const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
-                       float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base) {
+                       float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base,
+                       const float *__restrict__ x_inv_scale) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -274,6 +275,19 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
     const int4 td = tile_desc[mt];
     const int k = td.x, base = td.y, cnt = td.z;
     const int n0 = nt * TN;
+    // per-row power-of-two scales of the pre-split operand (x_hi + x_lo = x * 2^e(row), gp_split_f16_scaled): the partial
+    // row of a pair is multiplied back by 2^-e(input row).  Loaded before the K loop (16 rows per lane), used in the epilogue.
+    float rinv[4][4];
+    {
+        const int wm_ = wv >> 1, fq_ = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = wm_ * 64 + i * 16 + fq_ * 4 + r;
+                rinv[i][r] = x_inv_scale ? x_inv_scale[pair_in[base + (grow < cnt ? grow : cnt - 1)]] : 1.f;
+            }
+    }
     // DMA roles: wave wv stages rows [wv*32, wv*32+32) of each array, two instructions of 16 rows
     const int lrow = lane >> 2, lp = lane & 3;
     const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;         // logical 8-half slot this lane fetches
@@ -334,7 +348,7 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
                     if (grow < cnt) {
                         float *prow = P + (int64_t)(base - pair_base + grow) * cout + n0 + wn * 128 + fl;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) prow[j * 16] = acc[i][j][r];
+                        for (int j = 0; j < 8; ++j) prow[j * 16] = acc[i][j][r] * rinv[i][r];
                     }
                 }
             }
@@ -350,7 +364,7 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * EP + j * 16 + fl] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * EP + j * 16 + fl] = acc[i][j][r] * rinv[i][r];
             gp_wave_sync();
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -373,13 +387,62 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
                                    const float *__restrict__ residual, int64_t ld_res, int relu,
                                    float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ y_hi,
                                    _Float16 *__restrict__ y_lo, int64_t ld_yh, int64_t row_begin, int64_t row_count,
-                                   int pair_base) {
+                                   int pair_base, float *__restrict__ y_inv_scale) {
     int64_t u = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     if (u >= row_count) return;
     u += row_begin;
     if (u >= nv) return;
     int lane = gp_lane();
     int mypos = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    if (y_inv_scale && y_hi && cout <= 1024) {
+        // pre-split output with a per-row power of two: hi + lo = y * 2^e, 2^e chosen so that the row's largest magnitude
+        // lands in [2^13, 2^14) -- every element within 2^-18 of it keeps a NORMAL f16 lo half, i.e. the full 2^-22 relative
+        // accuracy of the split; the next layer's phase 1 multiplies its partial rows by y_inv_scale[row] = 2^-e (exact)
+        float4 av[4];
+        float amax = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int c = lane * 4 + ch * 256;
+            if (c < cout) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < kv; ++k) {
+                    int pos = __shfl(mypos, k, 64);
+                    if (pos >= 0) {
+                        float4 t = *reinterpret_cast<const float4 *>(P + (int64_t)(pos - pair_base) * cout + c);
+                        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+                    }
+                }
+                float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+                float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
+                if (residual) {
+                    float4 r = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
+                    a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+                }
+                if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
+                av[ch] = a;
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+            }
+        }
+        amax = gp_wave_max(amax);
+        const float s = gp_pow2_for(amax);
+        if (lane == 0) y_inv_scale[u] = 1.f / s;
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int c = lane * 4 + ch * 256;
+            if (c < cout) {
+                float v[4] = {av[ch].x * s, av[ch].y * s, av[ch].z * s, av[ch].w * s};
+                f16x4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { h[i] = (_Float16)v[i]; l[i] = (_Float16)(v[i] - (float)h[i]); }
+                *reinterpret_cast<f16x4 *>(y_hi + u * ld_yh + c) = h;
+                *reinterpret_cast<f16x4 *>(y_lo + u * ld_yh + c) = l;
+            }
+        }
+        return;
+    }
     for (int c = lane * 4; c < cout; c += 256) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < kv; ++k) {
@@ -408,6 +471,55 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
             *reinterpret_cast<f16x4 *>(y_lo + u * ld_yh + c) = l;
         }
     }
+}
+
+// fp32 rows -> hi/lo f16 rows with a power-of-two pre-scale: global (device scalar `scale`, from gp_pow2_scale) or per row
+// (row_inv receives 2^-e(row)).  One wave per row in the per-row mode (d <= 1024... any d: two sweeps).
+__global__ void split_rows_scaled_kernel(const float *__restrict__ x, int64_t ld_x, int d, int64_t n, _Float16 *__restrict__ hi,
+                                         _Float16 *__restrict__ lo, int64_t ld_h, const float *__restrict__ scale,
+                                         float *__restrict__ row_inv) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int lane = gp_lane();
+    for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < n; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        float s = scale ? scale[0] : 1.f;
+        if (row_inv) {
+            float amax = 0.f;
+            for (int c = lane * 4; c < d; c += 256) {
+                float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+            }
+            s = gp_pow2_for(gp_wave_max(amax));
+            if (lane == 0) row_inv[r] = 1.f / s;
+        }
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+            float v[4] = {a.x * s, a.y * s, a.z * s, a.w * s};
+            f16x4 h, l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h[k] = (_Float16)v[k]; l[k] = (_Float16)(v[k] - (float)h[k]); }
+            *reinterpret_cast<f16x4 *>(hi + r * ld_h + c) = h;
+            *reinterpret_cast<f16x4 *>(lo + r * ld_h + c) = l;
+        }
+    }
+}
+
+// amax over an [n, d] block: non-negative floats order like their bit patterns -> atomicMax on the uint image
+__global__ void amax_kernel(const float *__restrict__ x, int64_t ld_x, int d, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    const int64_t total = n * (d / 4);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / (d / 4);
+        int c = (int)(i - r * (d / 4)) * 4;
+        float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    }
+    m = gp_wave_max(m);
+    if (gp_lane() == 0) atomicMax(out, __float_as_uint(m));
+}
+__global__ void pow2_scale_kernel(const unsigned *__restrict__ amax_bits, float *__restrict__ out2) {
+    const float s = gp_pow2_for(__uint_as_float(amax_bits[0]));
+    out2[0] = s;
+    out2[1] = 1.f / s;
 }
 
 // fp32 rows -> hi/lo f16 rows (input of the first layer)
@@ -504,6 +616,29 @@ extern "C" int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, 
     return GP_OK;
 }
 
+extern "C" int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n, float *scale2, void *workspace,
+                             size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(x && scale2 && workspace && workspace_bytes >= 4 && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0,
+                 "gp_pow2_scale: bad argument");
+    hipStream_t s = gp_stream(stream_);
+    GP_CHECK_HIP(hipMemsetAsync(workspace, 0, 4, s));
+    amax_kernel<<<1024, 256, 0, s>>>(x, ld_x, d, n, static_cast<unsigned *>(workspace));
+    pow2_scale_kernel<<<1, 1, 0, s>>>(static_cast<const unsigned *>(workspace), scale2);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+extern "C" int gp_split_f16_scaled(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
+                                   const float *scale, float *row_inv_scale, void *stream_) {
+    GP_CHECK_ARG(x && hi && lo && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0, "gp_split_f16_scaled: bad argument");
+    GP_CHECK_ARG(!(scale && row_inv_scale), "gp_split_f16_scaled: one global scale OR per-row scales");
+    int64_t waves = n < 16384 ? n : 16384;
+    split_rows_scaled_kernel<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(
+        x, ld_x, d, n, static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), ld_h, scale, row_inv_scale);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
 extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
                                     const int32_t *pair_in, const int32_t *pair_pos,
                                     const int32_t *pair_off, const int32_t *tile_start, const int32_t *tile_desc,
@@ -512,10 +647,13 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     const float *scale, const float *shift, const float *residual, int64_t ld_res,
                                     int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                                     int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
-                                    const int32_t *chunk_pair_off_host, void *stream_) {
+                                    const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
+                                    void *stream_) {
     GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && tile_desc && nseg > 0 && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
     GP_CHECK_ARG(!x_hi || (ld_xh % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0), "gp_sparse_conv_f16x3: pre-split rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (y_lo && ld_yh % 4 == 0), "gp_sparse_conv_f16x3: y_hi/y_lo come as a pair");
+    GP_CHECK_ARG(!x_row_inv_scale || x_hi, "gp_sparse_conv_f16x3: x_row_inv_scale belongs to pre-split operands (x_hi/x_lo)");
+    GP_CHECK_ARG(!y_row_inv_scale || (y_hi && cout <= 1024), "gp_sparse_conv_f16x3: y_row_inv_scale needs y_hi/y_lo and cout <= 1024");
     GP_CHECK_ARG(nv > 0 && num_pairs > 0 && (kv == 27 || kv == 1), "gp_sparse_conv_f16x3: bad sizes");
     GP_CHECK_ARG(cin % TK == 0, "gp_sparse_conv_f16x3: cin=%d must be a multiple of %d", cin, TK);
     GP_CHECK_ARG(x_hi || (ld_x % 4 == 0 && (uintptr_t)x % 16 == 0), "gp_sparse_conv_f16x3: x rows must be 16-byte aligned");
@@ -547,9 +685,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
                     static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv,
                     static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate,
-                    tile_begin, tile_count, pair_base);
+                    tile_begin, tile_count, pair_base, x_row_inv_scale);
             else {
                 GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
+                GP_CHECK_ARG(!x_row_inv_scale, "gp_sparse_conv_f16x3: the register-staged path splits unscaled fp32 rows");
                 conv_phase1_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
                     x, ld_x, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi),
                     static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate, tile_begin, tile_count, pair_base);
@@ -557,7 +696,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         }
         conv_phase2_kernel<<<(unsigned)((row_count * 64 + 255) / 256), 256, 0, s>>>(
             partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
-            static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base);
+            static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale);
     }
     GP_CHECK_LAUNCH();
     return GP_OK;

@@ -237,21 +237,39 @@ def conv_weights_split(w, scale_pow2):
     return hi, lo
 
 
-def split_f16(x, d=None):
-    """fp32 rows -> (hi, lo) f16 rows with x = hi + lo to 2^-22 relative."""
+def split_f16(x, d=None, scale=None, per_row=False):
+    """fp32 rows -> (hi, lo) f16 rows with x * s = hi + lo.  Unscaled (s = 1): exact to 2^-22 relative only for |x| >= 2^-3
+    (below that the lo half is a subnormal f16: absolute error 2^-25).  scale = device scalar from pow2_scale(): one power of
+    two for the whole block; per_row=True: a power of two per row, returns (hi, lo, row_inv_scale)."""
     lib = _lib.load()
     d = x.shape[1] if d is None else d
     hi = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
     lo = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
-    check(lib.gp_split_f16(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(hi), _ptr(lo), hi.stride(0), _stream()),
-          "gp_split_f16")
-    return hi, lo
+    if scale is None and not per_row:
+        check(lib.gp_split_f16(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(hi), _ptr(lo), hi.stride(0), _stream()),
+              "gp_split_f16")
+        return hi, lo
+    rinv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if per_row else None
+    check(lib.gp_split_f16_scaled(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(hi), _ptr(lo), hi.stride(0), _ptr(scale),
+                                  _ptr(rinv), _stream()), "gp_split_f16_scaled")
+    return (hi, lo, rinv) if per_row else (hi, lo)
+
+
+def pow2_scale(x, d=None):
+    """Device tensor [s, 1/s]: s = the power of two that puts max |x[:, :d]| into [2^13, 2^14).  No host sync."""
+    lib = _lib.load()
+    d = x.shape[1] if d is None else d
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    ws = _ws(256, x.device)
+    check(lib.gp_pow2_scale(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(out), _ptr(ws), ws.numel(), _stream()), "gp_pow2_scale")
+    return out
 
 
 def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=None, relu=False, out=None,
-                      x_split=None, out_split=None):
+                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None):
     """x fp32 [nv, >=cin] and/or x_split=(hi, lo) f16 (pre-split operand -> LDS-DMA path);
-    out_split=(hi, lo) f16 buffers to also receive the split output."""
+    out_split=(hi, lo) f16 buffers to also receive the split output.  x_row_inv fp32 [nv]: the per-row inverse scales of
+    a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled)."""
     lib = _lib.load()
     kv, cout, cin = w_hi.shape
     nv = pairs.nv
@@ -269,7 +287,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
                                    out.stride(0), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                    int(pairs.chunk_rows), int(pairs.num_chunks), pairs.chunk_tile_off, pairs.chunk_pair_off,
-                                   _stream()),
+                                   _ptr(x_row_inv), _ptr(out_row_inv), _stream()),
           "gp_sparse_conv_f16x3")
     return out
 
@@ -377,8 +395,9 @@ def pool_mfma_build(nbr, w, block_rows=64):
     return PoolMfma(bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows, min_steps=min_rows // 32)
 
 
-def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
-    """x_split / out_split: (hi, lo) f16 [Nv, >=d] pairs; out_f32 fp32 [Nv, >=d]; at least one output."""
+def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None):
+    """x_split / out_split: (hi, lo) f16 [Nv, >=d] pairs; out_f32 fp32 [Nv, >=d]; at least one output.
+    out_scale: device scalar multiplied into out_f32 (1/s of a pow2_scale()-scaled x_split)."""
     lib = _lib.load()
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
@@ -386,7 +405,7 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None):
     check(lib.gp_pool_mfma_apply(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.wa_hi),
                                  _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows), _ptr(yh), _ptr(yl),
                                  yh.stride(0) if yh is not None else 0, _ptr(out_f32),
-                                 out_f32.stride(0) if out_f32 is not None else 0, _stream()), "gp_pool_mfma_apply")
+                                 out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()), "gp_pool_mfma_apply")
     return out_f32 if out_f32 is not None else out_split
 
 

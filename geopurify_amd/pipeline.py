@@ -67,22 +67,30 @@ class StudentWeights:
         scale, shift = bn[0].to(device).contiguous(), bn[1].to(device).contiguous()
         use_fast = self.mode == "f16x3" and w.shape[2] % 256 == 0
         if use_fast:
+            # weights x 2^k with the largest magnitude in [2^13, 2^14): every weight within 2^-18 of it keeps a normal f16 lo
+            # half (the inverse goes into the BatchNorm scale; powers of two, exact)
             amax = float(w.abs().max().item())
-            p2 = 2.0 ** int(np.floor(np.log2(2.0 / amax))) if amax > 0 else 1.0
+            p2 = 2.0 ** int(np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
             hi, lo = ops.conv_weights_split(w, p2)
             self.layers.append(("f16x3", (hi, lo), (scale / p2).contiguous(), shift))
         else:
             self.layers.append(("f32", w, scale, shift))
 
     def _conv(self, li, x, ctx, residual=None, x_split=None, want_split=False):
+        """x_split / the returned split: (hi, lo, row_inv_scale) -- operands pre-scaled by a power of two per row."""
         kind, w, scale, shift = self.layers[li]
         if kind == "f16x3":
             out_split = None
             if want_split:
                 nv, cout = ctx["pairs"].nv, w[0].shape[1]
-                out_split = tuple(torch.empty((nv, cout), dtype=torch.float16, device=w[0].device) for _ in range(2))
+                dev = w[0].device
+                out_split = (torch.empty((nv, cout), dtype=torch.float16, device=dev), torch.empty((nv, cout), dtype=torch.float16, device=dev),
+                             torch.empty(nv, dtype=torch.float32, device=dev))
             y = ops.sparse_conv_f16x3(x, ctx["pairs"], w[0], w[1], scale, shift, residual=residual, relu=True,
-                                      x_split=x_split, out_split=out_split)
+                                      x_split=x_split[:2] if x_split is not None else None,
+                                      out_split=out_split[:2] if out_split is not None else None,
+                                      x_row_inv=x_split[2] if x_split is not None else None,
+                                      out_row_inv=out_split[2] if out_split is not None else None)
             return y, out_split
         return ops.sparse_conv(x, ctx["nbr_map"], w, scale, shift, residual=residual, relu=True), None
 
@@ -94,7 +102,7 @@ class StudentWeights:
         fast = all(l[0] == "f16x3" for l in self.layers)
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
             ctx["pairs"] = ops.conv_pairs_build(nbr_map)
-        xs = ops.split_f16(x, self.cin_pad) if fast else None
+        xs = ops.split_f16(x, self.cin_pad, per_row=True) if fast else None
         h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast)
         for b in range(self.num_blocks):
             t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast)
@@ -445,7 +453,10 @@ class HotPath:
             persistent = mode == "mfma_persist" and op.min_steps >= 4 and self.pool_block_rows == 64
             rows = op.rows_padded if persistent else Nv
             out = torch.empty((rows, D), dtype=torch.float32, device=dev)
-            sp = [ops.split_f16(X, D), tuple(torch.empty((rows, D), dtype=torch.float16, device=dev) for _ in range(2))]
+            # one power of two for the whole operand (pooling is a convex combination: magnitudes never grow), so that the lo
+            # halves of small features stay normal f16 numbers; the fp32 output of the last application is scaled back
+            sc = ops.pow2_scale(X, D)
+            sp = [ops.split_f16(X, D, scale=sc[0:1]), tuple(torch.empty((rows, D), dtype=torch.float16, device=dev) for _ in range(2))]
             if persistent and self.num_iters > 1:          # the ping-pong partner of the input planes also needs whole row blocks
                 sp.append(tuple(torch.empty((rows, D), dtype=torch.float16, device=dev) for _ in range(2)))
             apply = ops.pool_mfma_apply_persistent if persistent else ops.pool_mfma_apply
@@ -453,7 +464,7 @@ class HotPath:
             for t in range(self.num_iters):
                 last = t == self.num_iters - 1
                 dst = None if last else sp[1 + (t % 2)] if persistent else sp[(t + 1) % 2]
-                apply(src, op, D, out_split=dst, out_f32=out if last else None)
+                apply(src, op, D, out_split=dst, out_f32=out if last else None, out_scale=sc[1:2] if last else None)
                 src = dst
             self._pool_kernel = "pool_mfma_persist_kernel" if persistent else "pool_mfma_kernel"
             return out[:Nv]

@@ -132,6 +132,16 @@ int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, int32_t cout,
 /* NULL) receive the split output for the next layer.                                                */
 int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
                  void *stream);
+/* Power-of-two pre-scaling of split operands, so that the f16 lo halves stay NORMAL numbers and x = hi + lo holds to  */
+/* 2^-22 RELATIVE also for small magnitudes (unscaled, |x| < 2^-3 leaves lo subnormal: absolute error 2^-25).          */
+/* gp_pow2_scale: scale2[0] = s = 2^k with amax(|x[0:n, 0:d]|) * s in [2^13, 2^14), scale2[1] = 1/s (device scalars, */
+/* no host sync; workspace >= 4 bytes).  gp_split_f16_scaled: hi + lo = x * s with s = *scale (global, nullable) or,   */
+/* when row_inv_scale != NULL, a per-row s(row) chosen the same way, row_inv_scale[row] = 1/s(row).  Exact (powers of  */
+/* two); consumers multiply back: gp_pool_mfma_apply(out_scale), gp_sparse_conv_f16x3(x_row_inv_scale).                */
+int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n, float *scale2, void *workspace,
+                  size_t workspace_bytes, void *stream);
+int gp_split_f16_scaled(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
+                        const float *scale, float *row_inv_scale, void *stream);
 int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
                          const int32_t *pair_in, const int32_t *pair_pos,
                          const int32_t *seg_off, const int32_t *tile_start, const int32_t *tile_desc,
@@ -140,7 +150,7 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          const float *scale, const float *shift, const float *residual, int64_t ld_res,
                          int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                          int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
-                         const int32_t *chunk_pair_off_host, void *stream);
+                         const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale, void *stream);
 /* Chunked execution (num_chunks > 1, pairs built with the same chunk_rows): phase 1 / phase 2 alternate  */
 /* per chunk so that `partial` (then sized for the largest chunk) stays in the Infinity Cache;             */
 /* chunk_tile_off_host / chunk_pair_off_host = tile_start / seg_off at the chunk boundaries [num_chunks+1]. */
@@ -197,7 +207,7 @@ int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k,
 int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
                        const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                        int32_t block_rows, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
-                       int64_t ld_yf, void *stream);
+                       int64_t ld_yf, const float *out_scale, void *stream);
 /* Persistent form of the same operator (one 512-thread workgroup per CU walks (row block, 256-column half) tiles;  */
 /* both column groups of waves share every staged weight fragment; the LDS-DMA ring stays full across row blocks; */
 /* the epilogue stores straight from the accumulators).  Extra requirements: min_steps = min over row blocks of   */
