@@ -82,3 +82,74 @@ def test_f16x3_student_chain_vs_fp64_oracle(env, hidden, chunk_rows):
     Y_ref = o_aff.pool_gather(X[:, :D], nbr_o, w_ref, T)[perm.long().cpu()]
     p_err = (Y.cpu().double() - Y_ref).abs().max().item()
     assert p_err <= 1e-4, p_err                                       # north-star tolerance: pooled features 1e-4
+
+
+def test_split_relative_accuracy_small_magnitudes(env):
+    """fp32 -> (hi, lo) f16 operands with a power-of-two pre-scale: |x s - (hi + lo)| <= 2^-21 |x s| for every element within
+    2^-10 of the scale's reference magnitude, for rows spanning 1e-5 .. 1; unscaled, the lo half of a small element is a
+    subnormal f16 and the same bound fails by orders of magnitude."""
+    ops, _ = env
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((rng.normal(0, 1, size=(512, 512)) * 10.0 ** rng.uniform(-5, 0, size=(512, 1))).astype(np.float32)).cuda()
+    hi, lo, rinv = ops.split_f16(x, per_row=True)
+    s = 1.0 / rinv.double()
+    assert torch.equal(torch.log2(s), torch.log2(s).round())                        # exact powers of two
+    amax = x.abs().amax(dim=1).double() * s
+    assert (amax >= 2.0 ** 13).all() and (amax < 2.0 ** 14).all()
+    back = (hi.double() + lo.double()) * rinv.double()[:, None]
+    rel = (back - x.double()).abs() / x.double().abs().clamp(min=1e-300)
+    big = x.abs() >= x.abs().amax(dim=1, keepdim=True) * 2.0 ** -10
+    assert rel[big].max().item() <= 2.0 ** -21, rel[big].max().item()
+    h0, l0 = ops.split_f16(x)                                                         # unscaled: absolute-error class only
+    rel0 = ((h0.double() + l0.double()) - x.double()).abs() / x.double().abs().clamp(min=1e-300)
+    assert rel0[big].max().item() > 2.0 ** -16
+    sc = ops.pow2_scale(x)
+    hg, lg = ops.split_f16(x, scale=sc[0:1])
+    assert float(sc[0]) * float(sc[1]) == 1.0 and 2.0 ** 13 <= float(x.abs().max()) * float(sc[0]) < 2.0 ** 14
+    top = x.abs() >= x.abs().max() * 2.0 ** -10
+    relg = ((hg.double() + lg.double()) * float(sc[1]) - x.double()).abs() / x.double().abs().clamp(min=1e-300)
+    assert relg[top].max().item() <= 2.0 ** -21
+
+
+def test_small_magnitude_inputs_keep_relative_accuracy(env):
+    """The statement "fp32-class" for the f16 hi/lo kernels must hold in RELATIVE terms for small operands too: a 3x3x3 layer and
+    19 pooling applications on inputs of magnitude 1e-3 .. 1e-4 against fp64, relative to the result's own scale."""
+    ops, pl = env
+    from test_gpu_kernels import surface_voxels
+    rng = np.random.default_rng(77)
+    coords = surface_voxels(rng, 1500)
+    Nv, C, K, T = len(coords), 256, 96, 19
+    c = torch.from_numpy(coords).cuda().contiguous()
+    perm, rank = ops.morton_order(c)
+    cs = c[perm.long()].contiguous()
+    grid = ops.grid_build(cs)
+    nm = ops.kernel_map_build(grid, cs)
+    pairs = ops.conv_pairs_build(nm, chunk_rows=1024)
+    X = torch.from_numpy((rng.normal(0, 1, size=(Nv, C)) * 10.0 ** rng.uniform(-4, -3, size=(Nv, 1))).astype(np.float32))
+    W = torch.from_numpy((rng.normal(0, 1, size=(27, C, C)) * 0.02).astype(np.float32))
+    ref = o_student.sparse_conv3(X.double(), o_student.build_kernel_map(coords.astype(np.int64)), W.double())[perm.long().cpu()]
+    Xd = X.cuda()[perm.long()].contiguous()
+    p2 = 2.0 ** int(np.floor(np.log2(16384.0 / float(W.abs().max()))))
+    whi, wlo = ops.conv_weights_split(W.cuda(), p2)
+    sc = torch.full((C,), 1.0 / p2, device="cuda")
+    hi, lo, rinv = ops.split_f16(Xd, per_row=True)
+    y = ops.sparse_conv_f16x3(None, pairs, whi, wlo, sc, None, x_split=(hi, lo), x_row_inv=rinv)
+    scale = ref.abs().max().item()
+    err = (y.cpu().double() - ref).abs().max().item() / scale
+    assert err <= 2e-6, err                                           # fp32-class relative to the result's scale (fp32 GEMM: ~1e-6)
+    h0, l0 = ops.split_f16(Xd)
+    y0 = ops.sparse_conv_f16x3(None, pairs, whi, wlo, sc, None, x_split=(h0, l0))
+    err0 = (y0.cpu().double() - ref).abs().max().item() / scale
+    assert err0 > 4 * err                                             # the unscaled split is visibly worse on such inputs
+    # pooling: 19 applications on features of magnitude ~1e-3, relative to the pooled magnitude
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    E = torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1)
+    w = ops.affinity_softmax(E, nbr, 20.0)
+    F = torch.zeros((Nv, 544), device="cuda")
+    F[:, :512] = torch.from_numpy((rng.normal(0, 1, size=(Nv, 512)) * 1e-3).astype(np.float32)).cuda()
+    ref_p = o_aff.pool_gather(F[:, :512].cpu(), nbr.long().cpu(), w.cpu(), T)
+    for mode in ("mfma", "mfma_persist"):
+        hp = pl.HotPath(None, (8, 8), K=K, num_iters=T, device="cuda", pool_mode=mode)
+        Y = hp._pool(F, nbr, w, Nv, 512)
+        rel = (Y.cpu().double() - ref_p).abs().max().item() / ref_p.abs().max().item()
+        assert rel <= 2e-6, (mode, rel)
