@@ -577,6 +577,7 @@ size_t scan_tmp32(int64_t n) {
 extern int g_gp_knobs[16];
 #define g_conv_ablate g_gp_knobs[3]
 
+
 extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {
     if (nv <= 0 || kv <= 0) return 0;
     GpCarver cv(nullptr, 0);
@@ -685,8 +686,16 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     // Measured and left out: pipelining the chunks over helper streams (phase 2 of chunk c beside phase 1 of chunk c+1, two
     // partial slots) -- 2.13 vs 2.07 ms per 512->512 layer: phase 1 is co-limited by its own L2 traffic (A gather + weight
     // tiles + partial stores), so a memory-bound neighbour only takes bandwidth from it.
-    const bool chunked = num_chunks > 1 && chunk_tile_off_host && chunk_pair_off_host;
+    // chunk tables (host copies of the per-chunk tile / pair offsets) give EXACT tile counts; without them tile_count is an
+    // upper bound and only the one-tile-per-workgroup kernels (which test tile_start[nseg] on the device) may run
+    const bool chunked = num_chunks >= 1 && chunk_tile_off_host && chunk_pair_off_host;
     const int nchunk = chunked ? num_chunks : 1;
+    // Measured and left out (round 2): a persistent phase 1 (one workgroup per CU, 3-deep ring for the gathered rows issued two
+    // steps ahead, weight tiles one step ahead, split staging roles, rings and epilogue stores running through tile boundaries,
+    // swapped MFMA operands for 16-byte partial stores): bit-identical results, 1.99 vs 1.96 ms per 512->512 layer.  Its
+    // ablations say why: matrix work alone 0.86 ms, loads alone 0.50 ms, loads + partial stores 0.97 ms, all three 1.45 ms,
+    // loop skeleton 0.08 ms -- phase 1 is co-limited by its 9.7 GB of L2 / Infinity-Cache traffic per layer (3.9 GB gathered
+    // rows + 3.8 GB weight tiles + 2 GB partial rows), which scheduling does not change.
     for (int c = 0; c < nchunk; ++c) {
         int tile_begin = chunked ? chunk_tile_off_host[c] : 0;
         int tile_count = chunked ? chunk_tile_off_host[c + 1] - tile_begin : (int)(num_pairs / TM + nseg);

@@ -216,13 +216,11 @@ def conv_pairs_build(nbr_map, chunk_rows=16384):
     num_pairs = bounds[0][-1]
     cp = ConvPairs(pair_in, pair_pos, seg_off, tile_start, nseg, num_pairs, nv)
     cp.tile_desc = tile_desc
-    if nchunks > 1:
-        cp.chunk_rows, cp.num_chunks = chunk_rows, nchunks
-        cp.chunk_pair_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[0])
-        cp.chunk_tile_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[1])
-        cp.max_chunk_pairs = max(bounds[0][i + 1] - bounds[0][i] for i in range(nchunks))
-    else:
-        cp.max_chunk_pairs = num_pairs
+    # host copies of the chunk boundaries (exact tile / pair counts per chunk; a single chunk included)
+    cp.chunk_rows, cp.num_chunks = chunk_rows, nchunks
+    cp.chunk_pair_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[0])
+    cp.chunk_tile_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[1])
+    cp.max_chunk_pairs = max(bounds[0][i + 1] - bounds[0][i] for i in range(nchunks))
     return cp
 
 

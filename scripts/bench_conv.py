@@ -44,8 +44,7 @@ def timeit(fn, n=5):
 
 
 ab = lambda v: lib.gp_debug_set(3, v.value)
-for name, v in (("full", 0), ("no global loads after step 0", 1), ("no MFMA", 2), ("no loads, no LDS stores", 5),
-                ("no MFMA, no epilogue store", 10), ("no epilogue store", 8)):
+for name, v in (("full", 0),):
     if ab is not None:
         ab(ctypes.c_int(v))
     t = timeit(lambda: ops.sparse_conv_f16x3(X, pairs, hi, lo, sc_, sh, relu=True))
@@ -58,10 +57,12 @@ t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True
 print(f"{'LDS-DMA path (pre-split in/out)':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
 t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs))
 print(f"{'LDS-DMA path (no split output)':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s effective)", flush=True)
-for name, v in (("DMA: LDS-staged epilogue (old)", 32), ("DMA: no MFMA", 2), ("DMA: no MFMA, no epilogue", 10), ("DMA: no epilogue", 8)):
+for name, v in (("DMA: full", 0), ("DMA: no MFMA", 2), ("DMA: no MFMA, no epilogue", 10), ("DMA: no epilogue", 8)):
     lib.gp_debug_set(3, v)
     t = timeit(lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs))
     print(f"{name:36s} {t:7.3f} ms", flush=True)
 lib.gp_debug_set(3, 0)
+if os.environ.get("GP_SKIP_V1"):
+    sys.exit(0)
 t = timeit(lambda: ops.sparse_conv(X, nm, W, sc_, sh, relu=True), 2)
 print(f"{'v1 fp32 MFMA kernel':36s} {t:7.3f} ms  ({flops / t / 1e9:7.1f} TFLOP/s)")
