@@ -3,6 +3,8 @@
 // 16 B per lane coalesced row segments, wave-uniform neighbour indices and weights in SGPRs.
 #include "gp_common.h"
 
+extern int g_gp_knobs[16];
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -183,6 +185,151 @@ __global__ void __launch_bounds__(256) pool_ell_kernel(const float *__restrict__
     if (act) *reinterpret_cast<float4 *>(y + row * ld_y + c) = acc;
 }
 
+// affinity, block form (D = 128, K <= 128): one 1024-thread workgroup owns 16 consecutive rows (Morton-adjacent when the
+// caller orders the voxels so), one wave per row.  The 16 x K neighbour ids are de-duplicated through an LDS hash table
+// (~13 distinct rows per row instead of 96), the distinct embedding rows are loaded ONCE into LDS and every dot product
+// reads its neighbour row from there: 7x less traffic through L2 than the one-wave-per-row kernel above, same arithmetic
+// order per row (same 4-lane split of the 128 floats, same shuffles, same softmax) => bit-identical weights.
+// Rows of the union beyond the LDS capacity are read from global memory as before.
+// LDS row layout: the 32-float segment of lane `sub` starts at float sub * 36 and a row is 144 floats, so the four lanes of a
+// neighbour group read four different bank quads (offsets 0, 36, 8, 44 mod 64) and rows idx, idx+1, idx+2, idx+3 fill the rest.
+constexpr int AB_D = 128, AB_SEG_LD = 36, AB_LD = 144;
+template <int R> struct AbGeo {                               // R rows per workgroup (R waves): 16 -> one workgroup per CU, 8 -> two
+    static constexpr int HS = R * 128, CAP = R == 16 ? 240 : 120;
+    static constexpr size_t SMEM = (size_t)CAP * AB_LD * 4 + HS * 4 + HS * 2 + HS * 4;
+};
+template <int R>
+__global__ void __launch_bounds__(R * 64)
+affinity_block_kernel(const float *__restrict__ e, int64_t ld_e, const int32_t *__restrict__ nbr, int k, int64_t nv, float sharpen,
+                      float *__restrict__ w) {
+    constexpr int AB_ROWS = R, AB_HS = AbGeo<R>::HS, AB_CAP = AbGeo<R>::CAP, NT = R * 64;
+    extern __shared__ __align__(16) unsigned char ab_smem[];
+    float *rows = reinterpret_cast<float *>(ab_smem);                                   // [AB_CAP][AB_LD]
+    int *keys = reinterpret_cast<int *>(ab_smem + (size_t)AB_CAP * AB_LD * 4);           // [AB_HS] voxel id or -1
+    short *index = reinterpret_cast<short *>(keys + AB_HS);                            // [AB_HS] compact row index of a slot
+    int *ulist = reinterpret_cast<int *>(index + AB_HS);                               // [AB_HS] voxel id of compact index
+    __shared__ int s_wcnt[R];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i = blockIdx.x * (int64_t)AB_ROWS + wv;
+    const bool live = i < nv;
+    int id0 = -1, id1 = -1;                                             // this row's neighbour ids: lane j and j + 64
+    if (live) {
+        if (lane < k) id0 = nbr[i * k + lane];
+        if (lane + 64 < k) id1 = nbr[i * k + lane + 64];
+    }
+    for (int t = tid; t < AB_HS; t += NT) keys[t] = -1;
+    __syncthreads();
+    // ---- phase 1: insert this row's neighbour ids (lane j and j + 64), remember their slots
+    int slot0 = 0, slot1 = 0;
+    auto insert = [&](int id) {
+        unsigned h = ((unsigned)id * 2654435761u) >> (R == 16 ? 21 : 22);    // log2(AB_HS) bits
+        while (true) {
+            const int old = atomicCAS(&keys[h], -1, id);
+            if (old == -1 || old == id) break;
+            h = (h + 1) & (AB_HS - 1);
+        }
+        return (int)h;
+    };
+    if (id0 >= 0) slot0 = insert(id0);
+    if (id1 >= 0) slot1 = insert(id1);
+    __syncthreads();
+    // ---- phase 2: compact the occupied slots (two per thread, in slot order)
+    {
+        const int k0 = keys[2 * tid], k1 = keys[2 * tid + 1];
+        const int c = (k0 >= 0) + (k1 >= 0);
+        int incl = c;                                                    // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wcnt[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < wv; ++q) base += s_wcnt[q];
+        int idx = base + incl - c;
+        index[2 * tid] = (short)(k0 >= 0 ? idx : -1);
+        if (k0 >= 0) { ulist[idx] = k0; ++idx; }
+        index[2 * tid + 1] = (short)(k1 >= 0 ? idx : -1);
+        if (k1 >= 0) ulist[idx] = k1;
+    }
+    __syncthreads();
+    int U = 0;
+    for (int q = 0; q < R; ++q) U += s_wcnt[q];
+    const int Uc = U < AB_CAP ? U : AB_CAP;
+    // ---- phase 3: the distinct rows, once (a wave moves two 512-byte rows per instruction; all loads in flight together)
+    {
+        constexpr int NI = (AB_CAP + 2 * R - 1) / (2 * R);
+        const int q4 = lane & 31;
+        float4 t[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int u = wv * 2 + (lane >> 5) + q * 2 * R;
+            t[q] = *reinterpret_cast<const float4 *>(e + (int64_t)ulist[u < Uc ? u : 0] * ld_e + q4 * 4);   // U >= 1
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int u = wv * 2 + (lane >> 5) + q * 2 * R;
+            if (u < Uc) *reinterpret_cast<float4 *>(rows + (size_t)u * AB_LD + (q4 >> 3) * AB_SEG_LD + (q4 & 7) * 4) = t[q];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- phase 4: the row's K dot products and its softmax, exactly as affinity_softmax_kernel<128>
+    const int sub = lane & 3, grp = lane >> 2;
+    constexpr int SEG = AB_D / 4;
+    float ei[SEG];
+    const float *erow = e + i * ld_e + sub * SEG;
+#pragma unroll
+    for (int c = 0; c < SEG; c += 4) {
+        float4 t = *reinterpret_cast<const float4 *>(erow + c);
+        ei[c] = t.x; ei[c + 1] = t.y; ei[c + 2] = t.z; ei[c + 3] = t.w;
+    }
+    float logit[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int j = p * 16 + grp;
+        const int sl = __shfl(j < 64 ? slot0 : slot1, j & 63, 64);
+        float dot = 0.f;
+        if (j < k) {
+            const int idx = index[sl];
+            if (idx < AB_CAP) {                                          // two loops: LDS and global address spaces
+                const float *nrow = rows + (size_t)idx * AB_LD + sub * AB_SEG_LD;
+#pragma unroll
+                for (int c = 0; c < SEG; c += 4) {
+                    float4 t = *reinterpret_cast<const float4 *>(nrow + c);
+                    dot += ei[c] * t.x + ei[c + 1] * t.y + ei[c + 2] * t.z + ei[c + 3] * t.w;
+                }
+            } else {
+                const float *nrow = e + (int64_t)keys[sl] * ld_e + sub * SEG;
+#pragma unroll
+                for (int c = 0; c < SEG; c += 4) {
+                    float4 t = *reinterpret_cast<const float4 *>(nrow + c);
+                    dot += ei[c] * t.x + ei[c + 1] * t.y + ei[c + 2] * t.z + ei[c + 3] * t.w;
+                }
+            }
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        logit[p] = (j < k) ? dot * sharpen : -INFINITY;
+        mx = fmaxf(mx, logit[p]);
+    }
+    mx = gp_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        logit[p] = (logit[p] == -INFINITY) ? 0.f : expf(logit[p] - mx);
+        if (sub == 0) sum += logit[p];
+    }
+    sum = gp_wave_sum(sum);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int j = p * 16 + grp;
+        if (sub == 0 && j < k) w[i * k + j] = logit[p] / sum;
+    }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -227,6 +374,22 @@ extern "C" int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, cons
     GP_CHECK_ARG(ld_e % 4 == 0 && (uintptr_t)e % 16 == 0, "gp_affinity_softmax: rows must be 16-byte aligned");
     int blocks = (int)((nv * 64 + 255) / 256);
     hipStream_t s = gp_stream(stream_);
+    if (d == 128 && g_gp_knobs[15] != 1) {              // block form: distinct neighbour rows of R rows staged once in LDS
+        static bool attr_set = false;
+        if (!attr_set) {
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(affinity_block_kernel<16>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeo<16>::SMEM));
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(affinity_block_kernel<8>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeo<8>::SMEM));
+            attr_set = true;
+        }
+        if (g_gp_knobs[15] == 2)                        // measured on config S: 16 rows 0.49 ms, 8 rows 0.55 ms, wave form 0.81 ms
+            affinity_block_kernel<8><<<(unsigned)((nv + 7) / 8), 512, AbGeo<8>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w);
+        else
+            affinity_block_kernel<16><<<(unsigned)((nv + 15) / 16), 1024, AbGeo<16>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w);
+        GP_CHECK_LAUNCH();
+        return GP_OK;
+    }
     switch (d) {
         case 128: affinity_softmax_kernel<128><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
         case 64: affinity_softmax_kernel<64><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;

@@ -438,7 +438,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
                     a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
                 }
                 if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-                *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
+                if (y) *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;      // fp32 copy only where a later layer reads it (residual, linear)
                 av[ch] = a;
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
             }
@@ -471,7 +471,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
             a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
         }
         if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-        *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
+        if (y) *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
         if (y_hi) {                                           // pre-split operand of the next layer
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             float v[4] = {a.x, a.y, a.z, a.w};
@@ -661,7 +661,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
                                     const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
                                     void *stream_) {
-    GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && tile_desc && nseg > 0 && w_hi && w_lo && partial && y, "gp_sparse_conv_f16x3: null argument");
+    GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && tile_desc && nseg > 0 && w_hi && w_lo && partial && (y || y_hi), "gp_sparse_conv_f16x3: null argument");
     GP_CHECK_ARG(!x_hi || (ld_xh % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0), "gp_sparse_conv_f16x3: pre-split rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (y_lo && ld_yh % 4 == 0), "gp_sparse_conv_f16x3: y_hi/y_lo come as a pair");
     GP_CHECK_ARG(!x_row_inv_scale || x_hi, "gp_sparse_conv_f16x3: x_row_inv_scale belongs to pre-split operands (x_hi/x_lo)");

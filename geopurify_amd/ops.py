@@ -264,7 +264,7 @@ def pow2_scale(x, d=None):
 
 
 def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=None, relu=False, out=None,
-                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None):
+                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None, want_f32=True):
     """x fp32 [nv, >=cin] and/or x_split=(hi, lo) f16 (pre-split operand -> LDS-DMA path);
     out_split=(hi, lo) f16 buffers to also receive the split output.  x_row_inv fp32 [nv]: the per-row inverse scales of
     a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled)."""
@@ -274,8 +274,8 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     dev = w_hi.device
     if pairs.partial is None or pairs.partial.shape[1] < cout:
         pairs.partial = torch.empty((max(pairs.max_chunk_pairs, 1), cout), dtype=torch.float32, device=dev)
-    if out is None:
-        out = torch.empty((nv, cout), dtype=torch.float32, device=dev)
+    if out is None and (want_f32 or out_split is None):
+        out = torch.empty((nv, cout), dtype=torch.float32, device=dev)        # want_f32=False: only the split planes are written
     xh, xl = x_split if x_split is not None else (None, None)
     yh, yl = out_split if out_split is not None else (None, None)
     check(lib.gp_sparse_conv_f16x3(_ptr(x), x.stride(0) if x is not None else 0, _ptr(xh), _ptr(xl),
@@ -283,7 +283,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    _ptr(pairs.pair_off), _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
                                    _ptr(pairs.partial), _ptr(scale), _ptr(shift), _ptr(residual),
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
-                                   out.stride(0), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
+                                   out.stride(0) if out is not None else 0, _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                    int(pairs.chunk_rows), int(pairs.num_chunks), pairs.chunk_tile_off, pairs.chunk_pair_off,
                                    _ptr(x_row_inv), _ptr(out_row_inv), _stream()),
           "gp_sparse_conv_f16x3")

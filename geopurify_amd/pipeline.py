@@ -76,8 +76,9 @@ class StudentWeights:
         else:
             self.layers.append(("f32", w, scale, shift))
 
-    def _conv(self, li, x, ctx, residual=None, x_split=None, want_split=False):
-        """x_split / the returned split: (hi, lo, row_inv_scale) -- operands pre-scaled by a power of two per row."""
+    def _conv(self, li, x, ctx, residual=None, x_split=None, want_split=False, want_f32=True):
+        """x_split / the returned split: (hi, lo, row_inv_scale) -- operands pre-scaled by a power of two per row.
+        want_f32=False: the fp32 copy of the output is not written (only the next convolution reads this layer)."""
         kind, w, scale, shift = self.layers[li]
         if kind == "f16x3":
             out_split = None
@@ -90,7 +91,7 @@ class StudentWeights:
                                       x_split=x_split[:2] if x_split is not None else None,
                                       out_split=out_split[:2] if out_split is not None else None,
                                       x_row_inv=x_split[2] if x_split is not None else None,
-                                      out_row_inv=out_split[2] if out_split is not None else None)
+                                      out_row_inv=out_split[2] if out_split is not None else None, want_f32=want_f32)
             return y, out_split
         return ops.sparse_conv(x, ctx["nbr_map"], w, scale, shift, residual=residual, relu=True), None
 
@@ -105,7 +106,7 @@ class StudentWeights:
         xs = ops.split_f16(x, self.cin_pad, per_row=True) if fast else None
         h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast)
         for b in range(self.num_blocks):
-            t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast)
+            t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast, want_f32=not fast)   # conv1 output: next conv only
             last = b == self.num_blocks - 1
             h, hs = self._conv(2 + 2 * b, t, ctx, residual=h, x_split=ts, want_split=fast and not last)
         e = ops.sparse_conv(h, None, self.w_out)

@@ -129,7 +129,7 @@ int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, int32_t cout,
                           void *w_hi, void *w_lo, void *stream);
 /* Optional pre-split operands: x_hi/x_lo f16 [nv, ld_xh] (from gp_split_f16 or a previous layer's   */
 /* y_hi/y_lo) select the LDS-DMA staging path (x may then be NULL); y_hi/y_lo f16 [nv, ld_yh] (or      */
-/* NULL) receive the split output for the next layer.                                                */
+/* NULL) receive the split output for the next layer; with them y may be NULL (no fp32 copy).          */
 int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
                  void *stream);
 /* Power-of-two pre-scaling of split operands, so that the f16 lo halves stay NORMAL numbers and x = hi + lo holds to  */

@@ -232,6 +232,43 @@ def test_affinity_and_pooling(ops):
     assert (cur.cpu() - ref32).abs().max() < 1e-4
 
 
+def test_affinity_block_form_is_bit_identical_to_the_wave_form(ops):
+    """The block kernel (distinct neighbour rows of 16 rows staged once in LDS) keeps the per-row arithmetic order of the
+    one-wave-per-row kernel: same bits.  Covers the LDS path (Morton-adjacent rows share neighbours), the global fallback
+    (random neighbours: the union of 16 rows exceeds the LDS capacity), K = 20 / 96 / 128, a ragged last block, duplicate
+    neighbour ids inside a row and padded embedding rows (ld_e > 128)."""
+    from geopurify_amd._lib import load
+    lib = load()
+    rng = np.random.default_rng(41)
+    c = surface_voxels(rng, 3001)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    cases = []
+    for K in (20, 96, 128):
+        nbr = torch.as_tensor(o_aff.knn_lattice(cs.cpu().numpy(), K)).to(torch.int32)
+        cases.append((K, nbr, "morton"))
+    Nv = len(c)
+    cases.append((96, torch.from_numpy(rng.integers(0, Nv, (Nv, 96))).to(torch.int32), "random"))
+    dup = torch.from_numpy(rng.integers(0, 7, (Nv, 33))).to(torch.int32)
+    cases.append((33, dup, "duplicates"))
+    g = torch.Generator().manual_seed(3)
+    Epad = torch.randn(Nv, 160, generator=g)
+    Epad[:, :128] = F.normalize(Epad[:, :128], dim=1)
+    E = dev(Epad)[:, :128]                                            # row stride 160 floats
+    for K, nbr, name in cases:
+        n = dev(nbr)
+        w_block = ops.affinity_softmax(E, n, 20.0)                    # default: 16 rows per workgroup
+        try:
+            lib.gp_debug_set(15, 1)
+            w_wave = ops.affinity_softmax(E, n, 20.0)
+            lib.gp_debug_set(15, 2)                                   # 8 rows per workgroup
+            w_block8 = ops.affinity_softmax(E, n, 20.0)
+        finally:
+            lib.gp_debug_set(15, 0)
+        assert torch.equal(w_block, w_wave) and torch.equal(w_block8, w_wave), (name, K)
+        w_ref = o_aff.affinity_weights(Epad[:, :128].contiguous(), nbr.long(), 20.0)
+        assert (w_block.cpu() - w_ref).abs().max() < 2e-6, (name, K)
+
+
 # ------------------------------------------------------------------------------------------ row 9
 def _bn_fold(sd, prefix):
     s = sd[prefix + ".bn.weight"] / torch.sqrt(sd[prefix + ".bn.running_var"] + 1e-5)
