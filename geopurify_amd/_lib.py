@@ -57,7 +57,7 @@ SIGNATURES = {
     "gp_pool_mfma_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P]),
     "gp_pool_mfma_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_pool_mfma_apply_persistent": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64,
-                                                _P, c_int64, c_int64, _P, _P]),
+                                                _P, c_int64, c_int64, _P, _P, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_lift_dense_bilinear_accum": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P,
                                                c_int64, _P, _P]),

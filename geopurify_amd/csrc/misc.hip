@@ -142,16 +142,24 @@ __global__ void nn_bbox_kernel(const float *__restrict__ xyz, int64_t n, float *
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { float v = xyz[i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    // wave reduce -> block reduce in LDS -> one atomic per block and bound (same-address atomics serialise: one per wave
+    // of a 586-block grid cost 160 us)
+    __shared__ float s_lo[4][3], s_hi[4][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
-        if (gp_lane() == 0) {
-            // float atomic min/max through the ordered-int trick (values are finite)
-            int *pl = reinterpret_cast<int *>(bb + a), *ph = reinterpret_cast<int *>(bb + 3 + a);
-            int il = __float_as_int(lo[a]), ih = __float_as_int(hi[a]);
-            if (il >= 0) atomicMin(pl, il); else atomicMax(reinterpret_cast<unsigned *>(pl), (unsigned)il);
-            if (ih >= 0) atomicMax(ph, ih); else atomicMin(reinterpret_cast<unsigned *>(ph), (unsigned)ih);
-        }
+        if (gp_lane() == 0) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][a], s_lo[1][a]), fminf(s_lo[2][a], s_lo[3][a]));
+        const float h = fmaxf(fmaxf(s_hi[0][a], s_hi[1][a]), fmaxf(s_hi[2][a], s_hi[3][a]));
+        // float atomic min/max through the ordered-int trick (values are finite; an empty block contributes +-inf: no-ops)
+        int *pl = reinterpret_cast<int *>(bb + a), *ph = reinterpret_cast<int *>(bb + 3 + a);
+        int il = __float_as_int(l), ih = __float_as_int(h);
+        if (il >= 0) atomicMin(pl, il); else atomicMax(reinterpret_cast<unsigned *>(pl), (unsigned)il);
+        if (ih >= 0) atomicMax(ph, ih); else atomicMin(reinterpret_cast<unsigned *>(ph), (unsigned)ih);
     }
 }
 __global__ void nn_bbox_init_kernel(float *bb) {
@@ -516,7 +524,7 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
         // grid path: bbox of all points; references bucketed by cell on a fine grid (near queries settle within
         // 2 shells) and on a coarse 32^3 grid (far queries: empty space is crossed in few, large steps)
         nn_bbox_init_kernel<<<1, 64, 0, st>>>(bb);
-        nn_bbox_kernel<<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(xyz, n, bb);
+        nn_bbox_kernel<<<blocks < 64 ? blocks : 64, 256, 0, st>>>(xyz, n, bb);       // 256 threads: the LDS reduce assumes 4 waves
         auto bucket = [&](int ng, int32_t *cnt, int32_t *start, int32_t *cur, float *sx, int64_t *si) -> int {
             int64_t nc = (int64_t)ng * ng * ng;
             GP_CHECK_HIP(hipMemsetAsync(cnt, 0, (nc + 1) * sizeof(int32_t), st));

@@ -17,16 +17,22 @@ __global__ void minmax_kernel(const int32_t *__restrict__ c, int64_t nv, int32_t
             hi[a] = max(hi[a], v);
         }
     }
+    // wave reduce -> block reduce in LDS -> ONE atomic per block and bound (same-address atomics serialise at the memory
+    // side: one per wave of a 586-block grid cost 140 us, 64 blocks x 6 cost 1 us)
+    __shared__ int s_lo[4][3], s_hi[4][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) {
             lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64));
             hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64));
         }
-        if (gp_lane() == 0) {
-            atomicMin(&mm[a], lo[a]);
-            atomicMax(&mm[3 + a], hi[a]);
-        }
+        if (gp_lane() == 0) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        atomicMin(&mm[a], min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a])));
+        atomicMax(&mm[3 + a], max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a])));
     }
 }
 
@@ -161,7 +167,7 @@ extern "C" int gp_morton_order(const int32_t *coords, int64_t nv, int32_t *perm,
     if (!cv.ok()) { gp_set_error("gp_morton_order: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
     int blocks = (int)((nv + 255) / 256);
     init_minmax_kernel<<<1, 64, 0, s>>>(mm);
-    minmax_kernel<<<min(blocks, 1024), 256, 0, s>>>(coords, nv, mm);
+    minmax_kernel<<<min(blocks, 64), 256, 0, s>>>(coords, nv, mm);          // 256 threads: the kernel's LDS reduce assumes 4 waves
     morton_keys_kernel<<<blocks, 256, 0, s>>>(coords, nv, mm, k0, v0);
     GP_CHECK_LAUNCH();
     GP_CHECK_HIP(rocprim::radix_sort_pairs(t, tmp, k0, k1, v0, perm, (size_t)nv, 0, 64, s));

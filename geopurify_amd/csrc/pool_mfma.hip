@@ -28,6 +28,7 @@ typedef short s16x4 __attribute__((vector_size(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PM_KS = 32;             // union rows per step (MFMA K)
+constexpr int PM_MIN_STEPS = 9;       // every row block is padded to at least this many steps
 constexpr int PM_D = 512;             // columns
 constexpr int PM_MAXID = 16384;       // ids sorted per block in the builder (block_rows x K <= 16384)
 constexpr float PM_WSCALE = 1024.f;   // weights (<= 1) are stored x 2^10 so that their f16 lo parts stay normal
@@ -94,7 +95,9 @@ pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int6
         if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += s_wcnt[w]; s_base += tot; }
         __syncthreads();
     }
-    const int U = s_base, Up = (U + PM_KS - 1) / PM_KS * PM_KS;
+    // padded to whole steps and to at least PM_MIN_STEPS steps (pad rows repeat the first id with zero weights): the persistent
+    // kernel learns its next tile at step 5 and needs it from step n - 4 on
+    const int U = s_base, Up = max((U + PM_KS - 1) / PM_KS, PM_MIN_STEPS) * PM_KS;
     if (!bu_row) {
         if (tid == 0) { padded_cnt[b] = Up; bu_n[b] = U; }
         return;
@@ -347,6 +350,7 @@ struct PgGeo {
 };
 
 struct PgTile { int64_t b; int col0; int64_t ub0; int n; };
+typedef int pg_i32x4 __attribute__((ext_vector_type(4)));
 
 template <int OFF>
 __device__ __forceinline__ void pg_wr64(uint32_t addr, f16x4 v) {
@@ -371,22 +375,39 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
                          const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
                          const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nblocks,
                          _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
-                         int64_t ld_yf, const float *__restrict__ out_scale, int knobs, int chunk) {
+                         int64_t ld_yf, const float *__restrict__ out_scale, int knobs, unsigned *__restrict__ queue) {
     using P = PgGeo<MT, XD>;
     using G = typename P::Q;
     static_assert(MT == 1, "the staged epilogue is written for 16 rows x 128 columns per wave");
     constexpr int NWF = P::NWF, AHX = P::AHX, NSTORE = 8;      // per wave and tile: 2 passes x 4 row-run stores
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // ---- this workgroup's tile list
+    // ---- this workgroup's tiles.  XCD label q = blockIdx & 7 owns the contiguous tile range [lo, hi); workgroup wi of the label
+    // starts with tile lo + wi.  queue != nullptr: every further tile is CLAIMED from the label's counter (queue[q], zero at
+    // launch; claim c -> tile lo + W + c) one tile ahead, so the label's W workgroups always work on the W lowest unfinished
+    // tiles -- what the hardware dispatcher does for a one-tile-per-workgroup grid, and what keeps the halo rows of
+    // neighbouring tiles meeting in the XCD's L2.  queue == nullptr: the static list lo + wi, lo + wi + W, ... (workgroups
+    // drift apart by tens of microseconds over the ~60 rounds of a launch; X-row L2 hits 54 % instead of 70 %).
+    // The claim is asynchronous so that the rings never drain: wave 0 issues the atomic at step 0 of a tile (complete
+    // after the hand-over of step 1), the load of the claimed tile's two union offsets at step 2 (complete after the
+    // hand-over of step 3), writes {tile, steps, first union row} into an LDS slot at step 4 and every wave reads it at
+    // step 5 -- the first step that can need the next tile (its row ids ride in W stages from step n - 4 on, n >= 9).
+    // Extra vector-memory operations in wave 0's queue only make its hand-counted waits stricter.
     const int64_t T = nblocks * 2;
-    // chunk == 0: persistent, workgroup wi of the label walks tiles lo+wi, lo+wi+32, ...; chunk = G > 0: workgroup wi takes the G
-    // consecutive tiles lo + G wi .. (the grid then has T/G workgroups, handed out in order by the dispatcher)
-    const int label = blockIdx.x & 7, wi = blockIdx.x >> 3, stride = chunk > 0 ? 1 : (int)(gridDim.x >> 3);
-    const int64_t lo = label * T / 8, hi_label = (label + 1) * T / 8;
-    int64_t t = chunk > 0 ? lo + (int64_t)wi * chunk : lo + wi;
-    const int64_t hi = chunk > 0 ? (t + chunk < hi_label ? t + chunk : hi_label) : hi_label;
-    if (t >= hi) return;
+    const int label = blockIdx.x & 7, wi = blockIdx.x >> 3, W = (int)(gridDim.x >> 3);
+    const int64_t lo = label * T / 8, hi = (label + 1) * T / 8;
+    const bool dynamic = queue != nullptr;
+    auto leave = [&]() {                                     // the last workgroup out re-arms the counters for the next launch
+        if (dynamic && tid == 0) {
+            const unsigned done = atomicAdd(queue + 8, 1u);
+            if (done == gridDim.x - 1) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) queue[q] = 0u;
+            }
+        }
+    };
+    int64_t t = lo + wi;
+    if (t >= hi) { leave(); return; }
     auto load_tile = [&](int64_t tt) {
         PgTile r;
         r.b = tt >> 1;
@@ -396,9 +417,9 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
         return r;
     };
     PgTile cur = load_tile(t);
-    bool has1 = t + stride < hi, has2 = t + 2 * (int64_t)stride < hi;
-    PgTile nx1 = has1 ? load_tile(t + stride) : cur;
-    PgTile nx2 = has2 ? load_tile(t + 2 * (int64_t)stride) : cur;
+    PgTile nx1 = cur;
+    bool has1 = false;
+    int64_t claimed = 0;                                     // wave 0: the tile its last claim returned
     const bool late_issue = !(knobs & 32) && wv >= 4;
 
     // ---- DMA roles (same staging geometry as PqGeo<8,256,..>: 4 rows per wave, two 1-KiB instructions per plane)
@@ -446,6 +467,7 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
     const uint32_t addr_id = lds0 + P::WRING + P::OFF_ID + wv * 256 + du * 8;
     const uint32_t stg = lds0 + P::OFF_STG + wv * P::STG_WAVE;                          // epilogue staging, wave-private
     const uint32_t rd = stg + (lane >> 4) * P::STG_PITCH + (lane & 15) * 16;
+    const uint32_t slot = lds0 + P::OFF_STG + 256;           // 16 bytes of pitch padding in wave 0's staging row 0: the next-tile slot
 
     f32x4 acc[MT * G::NCB];
 #pragma unroll
@@ -478,6 +500,58 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
         const int n = cur.n;
         for (int s = 0; s < n; ++s) {
             const uint32_t xoff = (uint32_t)xs * P::XSTAGE, woff = (uint32_t)ws * P::WSTAGE;
+            if (s <= 5) {                                    // the next tile (see the head of the kernel)
+                if (dynamic) {
+                    if (wv == 0) {
+                        // The two asynchronous results land in v200 / v[202:203]: registers named here and nowhere else, far
+                        // above what the compiler allocates for this kernel (~122; a compiler-chosen destination would be
+                        // copied or reused between the issue and the arrival two steps later).
+                        if (s == 0) {
+                            const unsigned *qa = queue + label;
+                            const unsigned one = 1u;
+                            if (lane == 0)                                // ONE atomic per claim: same-address atomics serialise
+                                asm volatile("global_atomic_add v200, %0, %1, off sc0" ::"v"(qa), "v"(one) : "memory", "v200");
+                        } else if (s == 2) {
+                            uint32_t c;
+                            asm volatile("v_readfirstlane_b32 %0, v200" : "=s"(c)::"memory");
+                            claimed = lo + W + (int64_t)c;
+                            int64_t cb = claimed >> 1;
+                            cb = cb < nblocks ? cb : nblocks - 1;
+                            const int64_t *da = bu_off + cb + (lane & 1);
+                            asm volatile("global_load_dwordx2 v[202:203], %0, off" ::"v"(da) : "memory", "v202", "v203");
+                        } else if (s == 4) {
+                            uint32_t d0l, d0h, d1l, d1h;
+                            asm volatile("v_readlane_b32 %0, v202, 0\n\tv_readlane_b32 %1, v203, 0\n\t"
+                                         "v_readlane_b32 %2, v202, 1\n\tv_readlane_b32 %3, v203, 1"
+                                         : "=s"(d0l), "=s"(d0h), "=s"(d1l), "=s"(d1h)::"memory");
+                            const int64_t u0 = (int64_t)(((uint64_t)d0h << 32) | d0l), u1 = (int64_t)(((uint64_t)d1h << 32) | d1l);
+                            pg_i32x4 sv;                   // (an int vector: bit casts of float-vector elements are miscompiled)
+                            sv[0] = claimed < hi ? (int32_t)(claimed - lo) : (int32_t)-1;
+                            sv[1] = (int32_t)((u1 - u0) / PM_KS);
+                            sv[2] = (int32_t)d0l;
+                            sv[3] = (int32_t)d0h;
+                            asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(slot), "v"(sv) : "memory");
+                        }
+                    }
+                    if (s == 5) {
+                        pg_i32x4 sv;
+                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(slot) : "memory");
+                        const int32_t rel = __builtin_amdgcn_readfirstlane(sv[0]);
+                        has1 = rel >= 0;
+                        if (has1) {
+                            const int64_t tt = lo + rel;
+                            nx1.b = tt >> 1;
+                            nx1.col0 = (int)(tt & 1) * 256;
+                            nx1.n = __builtin_amdgcn_readfirstlane(sv[1]);
+                            nx1.ub0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(sv[3]) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readfirstlane(sv[2]));
+                        }
+                    }
+                } else if (s == 5) {
+                    has1 = t + W < hi;
+                    if (has1) nx1 = load_tile(t + W);
+                }
+            }
             uint32_t a[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] = addr[k] + xoff;
@@ -579,13 +653,11 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
         }
         if (!has1) break;
         first_tile = false;
-        t += stride;
+        t = nx1.b * 2 + (nx1.col0 >> 8);
         cur = nx1;
-        nx1 = nx2;
-        has1 = has2;
-        has2 = t + 2 * (int64_t)stride < hi;
-        if (has2) nx2 = load_tile(t + 2 * (int64_t)stride);
+        has1 = false;                                          // known again from step 5 of the new tile
     }
+    leave();
 }
 
 template <int NW, int NC, int MT, int CGN>
@@ -785,7 +857,7 @@ int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
 template <int MT, int XD, bool F32OUT>
 int pg_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row, const void *wa_hi,
               const void *wa_lo, int64_t nblocks, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
-              const float *out_scale, hipStream_t s) {
+              const float *out_scale, unsigned *queue, hipStream_t s) {
     using P = PgGeo<MT, XD>;
     static bool attr_set = false;
     static int n_cu = 0;
@@ -798,12 +870,11 @@ int pg_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
         attr_set = true;
     }
     int per_label = g_gp_knobs[10] > 0 ? g_gp_knobs[10] : (n_cu >= 8 ? n_cu / 8 : 1);      // workgroups per XCD label
-    const int chunk = g_gp_knobs[12];                                                      // tuning aid: G consecutive tiles per workgroup
-    if (chunk > 0) per_label = (int)(((nblocks * 2 + 7) / 8 + chunk - 1) / chunk) + 1;
+    if (g_gp_knobs[12] == 1) queue = nullptr;                                              // tuning aid: the static tile lists
     pool_mfma_persist_kernel<MT, XD, F32OUT><<<(unsigned)(per_label * 8), 512, P::SMEM, s>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
         static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nblocks, static_cast<_Float16 *>(y_hi),
-        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, out_scale, g_gp_knobs[4], chunk);
+        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, out_scale, g_gp_knobs[4], queue);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -811,18 +882,22 @@ int pg_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
 }  // namespace
 
 // Persistent variant (one 512-thread workgroup per CU, 256 columns per workgroup, ring kept full across row blocks).
-// Requirements beyond gp_pool_mfma_apply: every row block has at least 4 steps (5 for the deep X ring) (min_steps, from the builder's bu_off:
-// min over blocks of (bu_off[b+1]-bu_off[b])/32 -- true whenever k >= 97 per block union), and the OUTPUT buffers hold
-// y_rows >= ceil(nv / block_rows) * block_rows rows (rows >= nv receive zeros).  Exactly one of (y_hi, y_lo) / y_f32.
+// Requirements beyond gp_pool_mfma_apply: every row block has at least 9 steps (min_steps, from the builder's bu_off:
+// min over blocks of (bu_off[b+1]-bu_off[b])/32; a block of 64 rows with 96 neighbours each has 13 on scenes), and the
+// OUTPUT buffers hold y_rows >= ceil(nv / block_rows) * block_rows rows (rows >= nv receive zeros).  Exactly one of
+// (y_hi, y_lo) / y_f32.  queue: 9 x uint32 of device memory, ZERO at the first launch and left zero by every launch (the
+// tile counters of the 8 XCD labels + a finished-workgroup counter); launches that share a queue must be stream-ordered.
+// NULL selects static tile lists (slower: see the kernel's comment).
 // out_scale: optional device scalar multiplied into the fp32 output (power-of-two pre-scaling of the split operands).
 extern "C" int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
                                              const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                                              int32_t block_rows, int32_t min_steps, void *y_hi, void *y_lo, int64_t ld_y,
-                                             float *y_f32, int64_t ld_yf, int64_t y_rows, const float *out_scale, void *stream_) {
+                                             float *y_f32, int64_t ld_yf, int64_t y_rows, const float *out_scale, uint32_t *queue,
+                                             void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && wa_hi && wa_lo && nv > 0, "gp_pool_mfma_apply_persistent: null/empty argument");
     GP_CHECK_ARG(d == PM_D, "gp_pool_mfma_apply_persistent: d=%d (kernel specialised for %d columns)", d, PM_D);
     GP_CHECK_ARG(block_rows == 64, "gp_pool_mfma_apply_persistent: block_rows=%d (64; 128-row blocks: gp_pool_mfma_apply)", block_rows);
-    GP_CHECK_ARG(min_steps >= 4, "gp_pool_mfma_apply_persistent: a row block with %d < 4 steps (use gp_pool_mfma_apply)", min_steps);
+    GP_CHECK_ARG(min_steps >= 9, "gp_pool_mfma_apply_persistent: a row block with %d < 9 steps (use gp_pool_mfma_apply)", min_steps);
     GP_CHECK_ARG(((y_hi && y_lo) != 0) != (y_f32 != nullptr), "gp_pool_mfma_apply_persistent: exactly one output form");
     GP_CHECK_ARG(ld_x % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0, "gp_pool_mfma_apply_persistent: x rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (ld_y % 8 == 0 && (uintptr_t)y_hi % 16 == 0 && (uintptr_t)y_lo % 16 == 0 && y_hi != x_hi && y_lo != x_lo),
@@ -832,7 +907,7 @@ extern "C" int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo,
     GP_CHECK_ARG(y_rows >= nb * block_rows, "gp_pool_mfma_apply_persistent: output needs %lld rows (whole row blocks), has %lld",
                  (long long)(nb * block_rows), (long long)y_rows);
     hipStream_t s = gp_stream(stream_);
-#define PG_ARGS x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nb, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s
+#define PG_ARGS x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nb, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, queue, s
     return y_f32 ? pg_launch<1, 3, true>(PG_ARGS) : pg_launch<1, 3, false>(PG_ARGS);
 #undef PG_ARGS
 }

@@ -366,6 +366,14 @@ class PoolMfma:
     def __init__(self, bu_off, bu_n, bu_row, wa_hi, wa_lo, nv, total, block_rows, min_steps=0):
         self.bu_off, self.bu_n, self.bu_row, self.wa_hi, self.wa_lo = bu_off, bu_n, bu_row, wa_hi, wa_lo
         self.nv, self.total, self.block_rows, self.min_steps = nv, total, block_rows, min_steps
+        self._queue = None
+
+    @property
+    def queue(self):
+        """Tile counters of the persistent kernel (9 x uint32, zero between launches)."""
+        if self._queue is None:
+            self._queue = torch.zeros(16, dtype=torch.int32, device=self.bu_off.device)
+        return self._queue
 
     @property
     def rows_padded(self):
@@ -407,8 +415,9 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None
     return out_f32 if out_f32 is not None else out_split
 
 
-def pool_mfma_apply_persistent(x_split, op, d, out_split=None, out_f32=None, out_scale=None):
-    """Persistent matrix-core pooling (one workgroup per CU).  Outputs need op.rows_padded rows; exactly one output form."""
+def pool_mfma_apply_persistent(x_split, op, d, out_split=None, out_f32=None, out_scale=None, dynamic=True):
+    """Persistent matrix-core pooling (one workgroup per CU).  Outputs need op.rows_padded rows; exactly one output form.
+    dynamic: workgroups claim tiles from op.queue (False: static tile lists, the slower tuning reference)."""
     lib = _lib.load()
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
@@ -417,7 +426,8 @@ def pool_mfma_apply_persistent(x_split, op, d, out_split=None, out_f32=None, out
     check(lib.gp_pool_mfma_apply_persistent(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.wa_hi),
                                             _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows), int(op.min_steps), _ptr(yh), _ptr(yl),
                                             yh.stride(0) if yh is not None else 0, _ptr(out_f32),
-                                            out_f32.stride(0) if out_f32 is not None else 0, int(rows), _ptr(out_scale), _stream()),
+                                            out_f32.stride(0) if out_f32 is not None else 0, int(rows), _ptr(out_scale),
+                                            _ptr(op.queue) if dynamic else None, _stream()),
           "gp_pool_mfma_apply_persistent")
     return out_f32 if out_f32 is not None else out_split
 

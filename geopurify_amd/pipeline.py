@@ -451,7 +451,7 @@ class HotPath:
             # by both column groups, rings kept full across row blocks) -- same speed within run-to-run noise on MI355X
             # (DESIGN.md section 6); needs >= 4 steps per row block and 64-row blocks, else falls back to "mfma"
             op = ops.pool_mfma_build(nbr, w, self.pool_block_rows)
-            persistent = mode == "mfma_persist" and op.min_steps >= 4 and self.pool_block_rows == 64
+            persistent = mode == "mfma_persist" and op.min_steps >= 9 and self.pool_block_rows == 64
             rows = op.rows_padded if persistent else Nv
             out = torch.empty((rows, D), dtype=torch.float32, device=dev)
             # one power of two for the whole operand (pooling is a convex combination: magnitudes never grow), so that the lo

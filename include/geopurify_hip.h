@@ -211,15 +211,18 @@ int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const i
 /* Persistent form of the same operator (one 512-thread workgroup per CU walks (row block, 256-column half) tiles;  */
 /* both column groups of waves share every staged weight fragment; the LDS-DMA ring stays full across row blocks; */
 /* the epilogue stores straight from the accumulators).  Extra requirements: min_steps = min over row blocks of   */
-/* (bu_off[b+1]-bu_off[b])/32 must be >= 4; the output holds y_rows >= ceil(nv/block_rows)*block_rows rows (rows  */
+/* (bu_off[b+1]-bu_off[b])/32 must be >= 9; the output holds y_rows >= ceil(nv/block_rows)*block_rows rows (rows  */
 /* >= nv receive zeros); exactly one of (y_hi,y_lo) / y_f32.  out_scale: optional device scalar multiplied into  */
-/* the fp32 output (undoes a power-of-two pre-scaling of the split operands).  Replaces the 19 torch.sparse.mm    */
-/* calls of models/affinity_module.py:1584-1587 like gp_pool_mfma_apply.                                          */
+/* the fp32 output (undoes a power-of-two pre-scaling of the split operands).  queue: 9 x uint32 of device memory, */
+/* zero before the first launch and left zero by every launch (per-XCD tile counters: workgroups claim their next */
+/* tile dynamically, which keeps neighbouring tiles together in L2); launches sharing a queue must be stream-     */
+/* ordered; NULL = static tile lists.  Replaces the 19 torch.sparse.mm calls of                                    */
+/* models/affinity_module.py:1584-1587 like gp_pool_mfma_apply.                                                    */
 int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off,
                                   const int32_t *bu_row, const void *wa_hi, const void *wa_lo, int64_t nv,
                                   int32_t d, int32_t block_rows, int32_t min_steps, void *y_hi, void *y_lo,
                                   int64_t ld_y, float *y_f32, int64_t ld_yf, int64_t y_rows,
-                                  const float *out_scale, void *stream);
+                                  const float *out_scale, uint32_t *queue, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */

@@ -65,6 +65,7 @@ ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in ran
 variants += [("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
              ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0)),
              ("persist64 (split out)", ("persist", 64, 0, 0)), ("persist64 (fp32 out)", ("persist32", 64, 0, 0)),
+             ("persist64 static tile lists (split out)", ("persist", 64, 0, 0, 1)),
              ("persist64 no-stagger (split out)", ("persist", 64, 32, 0))]
 ysp = {br: tuple(torch.empty((mf[br].rows_padded, D), dtype=torch.float16, device="cuda") for _ in range(2)) for br in (64,)}
 Yp = {br: torch.empty((mf[br].rows_padded, D), device="cuda") for br in (64,)}

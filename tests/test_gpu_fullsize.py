@@ -100,7 +100,7 @@ def test_pooling_properties_full_size(big):
             ops.pool_tiles_apply(z, tiles, D, out)
         elif isinstance(mode, str):                         # "p64": the persistent kernel (outputs padded to row blocks)
             op = mfma[int(mode[1:])]
-            assert op.min_steps >= 4
+            assert op.min_steps >= 9                        # the builder pads every row block to >= 9 steps
             outp = torch.empty(op.rows_padded, D, device="cuda")
             ops.pool_mfma_apply_persistent(ops.split_f16(z, D), op, D, out_f32=outp)
             # two chained applications through the split (hi, lo) hand-off == two fp32 applications
@@ -129,6 +129,17 @@ def test_pooling_properties_full_size(big):
         ops.pool_ell(ref, nbr, w, D, ref2)
         assert (outp[:Nv] - ref2).abs().max() < 2e-5
         assert (outp[Nv:] == 0).all()                                                 # padded rows receive zeros
+        # tiles claimed from the per-XCD counters (default) and static tile lists give the same bits; every launch
+        # leaves the counters at zero for the next one
+        assert int(op.queue.abs().sum()) == 0
+        outs = torch.empty(op.rows_padded, D, device="cuda")
+        ops.pool_mfma_apply_persistent(mid, op, D, out_f32=outs, dynamic=False)
+        assert torch.equal(outs, outp)
+        for _ in range(5):
+            outd = torch.full((op.rows_padded, D), float("nan"), device="cuda")
+            ops.pool_mfma_apply_persistent(mid, op, D, out_f32=outd)
+            assert torch.equal(outd, outp)
+        assert int(op.queue.abs().sum()) == 0
 
 
 def test_conv_paths_agree_full_size(big):
