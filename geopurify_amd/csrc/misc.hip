@@ -368,6 +368,72 @@ __global__ void classify16_kernel(const float *__restrict__ feat, int64_t ld, in
     }
 }
 
+// the same arithmetic (same 16-lane split of the row, same sum16 order, same divisions => the same bits and labels), but the
+// text matrix staged ONCE per workgroup in LDS (19 x 512 floats = 38 KiB do not fit the 32-KiB vector L1: the kernel above
+// re-fetches them from L2 for every group of points) and two points per 16-lane group and class sweep
+constexpr int CL_Q = 2;
+__global__ void __launch_bounds__(256)
+classify16_lds_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t n, const float *__restrict__ text, int C,
+                      float scale, int64_t *__restrict__ pred, uint8_t *__restrict__ zero_row) {
+    extern __shared__ __align__(16) float cl_text[];        // [C][d]
+    for (int i = threadIdx.x * 4; i < C * d; i += 256 * 4) *reinterpret_cast<float4 *>(cl_text + i) = *reinterpret_cast<const float4 *>(text + i);
+    __syncthreads();
+    const int l = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int nj = d / 64;
+    for (int64_t base = blockIdx.x * (int64_t)(16 * CL_Q); base < n; base += (int64_t)gridDim.x * (16 * CL_Q)) {
+        float4 v[CL_Q][CL_MAXJ];
+        float sa[CL_Q], bestv[CL_Q];
+        int bestc[CL_Q];
+        bool live[CL_Q];
+#pragma unroll
+        for (int q = 0; q < CL_Q; ++q) {
+            const int64_t p = base + g * CL_Q + q;
+            live[q] = p < n;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < CL_MAXJ; ++j) {
+                v[q][j] = (live[q] && j < nj) ? *reinterpret_cast<const float4 *>(feat + p * ld + (j * 16 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ss += v[q][j].x * v[q][j].x + v[q][j].y * v[q][j].y + v[q][j].z * v[q][j].z + v[q][j].w * v[q][j].w;
+            }
+            ss = sum16(ss);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < CL_MAXJ; ++j) {
+                v[q][j].x /= nrm; v[q][j].y /= nrm; v[q][j].z /= nrm; v[q][j].w /= nrm;
+                a += fabsf(v[q][j].x) + fabsf(v[q][j].y) + fabsf(v[q][j].z) + fabsf(v[q][j].w);
+            }
+            sa[q] = sum16(a);
+            bestv[q] = -INFINITY;
+            bestc[q] = 0;
+        }
+        for (int k = 0; k < C; ++k) {
+            float dot[CL_Q];
+#pragma unroll
+            for (int q = 0; q < CL_Q; ++q) dot[q] = 0.f;
+#pragma unroll
+            for (int j = 0; j < CL_MAXJ; ++j)
+                if (j < nj) {
+                    const float4 t = *reinterpret_cast<const float4 *>(cl_text + k * d + (j * 16 + l) * 4);
+#pragma unroll
+                    for (int q = 0; q < CL_Q; ++q) dot[q] += v[q][j].x * t.x + v[q][j].y * t.y + v[q][j].z * t.z + v[q][j].w * t.w;
+                }
+#pragma unroll
+            for (int q = 0; q < CL_Q; ++q) {
+                const float dv = sum16(dot[q]) * scale;
+                if (dv > bestv[q]) { bestv[q] = dv; bestc[q] = k; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CL_Q; ++q)
+            if (live[q] && l == 0) {
+                const int64_t p = base + g * CL_Q + q;
+                pred[p] = bestc[q];
+                if (zero_row) zero_row[p] = (sa[q] == 0.f) ? 1 : 0;
+            }
+    }
+}
+
 // generic shape: one wave per point
 __global__ void classify_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t n,
                                 const float *__restrict__ text, int C, float scale, int64_t *__restrict__ pred,
@@ -581,7 +647,18 @@ extern "C" int gp_visible_lists(const int64_t *mapping, int64_t n, int64_t *pt, 
 extern "C" int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int64_t n, const float *text_norm, int32_t c,
                                   float logit_scale, int64_t *pred, uint8_t *zero_row, void *stream_) {
     GP_CHECK_ARG(feat && text_norm && pred && n > 0 && d > 0 && c > 0, "gp_classify_argmax: null/empty argument");
-    if (d % 64 == 0 && d <= 64 * CL_MAXJ && ld % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)text_norm % 16 == 0)
+    const bool fast = d % 64 == 0 && d <= 64 * CL_MAXJ && ld % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)text_norm % 16 == 0;
+    const size_t text_bytes = (size_t)c * d * sizeof(float);
+    if (fast && text_bytes <= 64 * 1024 && !g_gp_knobs[14]) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(classify16_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr_set = true;
+        }
+        const int64_t groups = (n + 16 * CL_Q - 1) / (16 * CL_Q);
+        classify16_lds_kernel<<<(int)(groups < 2048 ? groups : 2048), 256, text_bytes, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
+                                                                                                     pred, zero_row);
+    } else if (fast)
         classify16_kernel<<<(int)((n * 16 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale, pred, zero_row);
     else
         classify_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,

@@ -381,31 +381,34 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
     }
 }
 
-// sum of a voxel's partial rows in ASCENDING offset order (bitwise reproducible), four independent loads in flight per step
+// sum of a voxel's partial rows in ASCENDING offset order (bitwise reproducible), NL independent loads in flight per round
+// (a voxel has 7.3 partial rows on average: one round of 8 for most voxels)
+template <int NL>
 __device__ __forceinline__ float4 conv_gather_sum(const float *__restrict__ P, int mypos, int kv, int cout, int c, int pair_base) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned long long m = __ballot(mypos >= 0) & ((kv >= 64) ? ~0ull : ((1ull << kv) - 1ull));
     while (m) {
-        int kk[4];
-        float4 t[4];
+        int kk[NL];
+        float4 t[NL];
         int cntv = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NL; ++i) {
             if (m) { kk[i] = __builtin_ctzll(m); m &= m - 1; ++cntv; } else kk[i] = -1;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NL; ++i)
             if (i < cntv) {
                 const int pos = __shfl(mypos, kk[i], 64);
                 t[i] = *reinterpret_cast<const float4 *>(P + (int64_t)(pos - pair_base) * cout + c);
             }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NL; ++i)
             if (i < cntv) { a.x += t[i].x; a.y += t[i].y; a.z += t[i].z; a.w += t[i].w; }
     }
     return a;
 }
 
+constexpr int GS_NL = 8;
 // phase 2: one wave per output voxel; lanes hold 2 x float4 of the 512 (or cout) channels
 __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *__restrict__ pair_pos, int64_t nv, int kv,
                                    int cout, const float *__restrict__ scale, const float *__restrict__ shift,
@@ -429,7 +432,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
         for (int ch = 0; ch < 4; ++ch) {
             const int c = lane * 4 + ch * 256;
             if (c < cout) {
-                float4 a = conv_gather_sum(P, mypos, kv, cout, c, pair_base);
+                float4 a = conv_gather_sum<GS_NL>(P, mypos, kv, cout, c, pair_base);
                 float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
                 float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
@@ -462,7 +465,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
         return;
     }
     for (int c = lane * 4; c < cout; c += 256) {
-        float4 a = conv_gather_sum(P, mypos, kv, cout, c, pair_base);
+        float4 a = conv_gather_sum<GS_NL>(P, mypos, kv, cout, c, pair_base);
         float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;

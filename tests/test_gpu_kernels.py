@@ -478,6 +478,19 @@ def test_classify_and_iou(ops):
     safe = (top2[:, 0] - top2[:, 1]) > 1e-4
     assert torch.equal(pred.cpu()[safe], ref_pred[safe]) and safe.float().mean() > 0.99
     assert torch.equal(zero.cpu().bool(), Fp.abs().sum(1) == 0)
+    # the kernel with the text matrix staged in LDS (default) keeps the arithmetic of the plain one: identical labels,
+    # also on a ragged point count and a padded feature stride
+    from geopurify_amd._lib import load
+    lib = load()
+    for n_pts, pad in ((N, 0), (N - 37, 32)):
+        Fd = dev(torch.cat([Fp[:n_pts], torch.zeros(n_pts, pad)], 1)) if pad else dev(Fp[:n_pts])
+        a = ops.classify_argmax(Fd, dev(tn), 14.285, d=D)
+        lib.gp_debug_set(14, 1)
+        try:
+            b = ops.classify_argmax(Fd, dev(tn), 14.285, d=D)
+        finally:
+            lib.gp_debug_set(14, 0)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     # large class count: logits by the exact-fp32 MFMA GEMM, same decisions
     text160 = torch.randn(160, D)
     tn160 = F.normalize(text160, dim=-1)
