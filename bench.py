@@ -415,6 +415,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     iou_target_points = int(counts[2].sum().item())   # labelled points counted over ALL ranks (before any untimed side pass)
+    iou_intersection_points = int(counts[0].sum().item())
     if world == 1:
         busy = dt
     pool_timer.enabled = conv_timer.enabled = False
@@ -488,6 +489,7 @@ def main():
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
             "iou_target_points": iou_target_points,
+            "iou_intersection_points": iou_intersection_points,
         }
         if val_mode:
             out["shard"] = dict(shard, busy_s_per_rank=[round(b, 4) for b in busy_all],

@@ -409,6 +409,37 @@ __device__ __forceinline__ float4 conv_gather_sum(const float *__restrict__ P, i
 }
 
 constexpr int GS_NL = 8;
+// the same sum for two column blocks (c and c + 256) of the same partial rows at once: 2 NL loads in flight per round
+template <int NL>
+__device__ __forceinline__ void conv_gather_sum2(const float *__restrict__ P, int mypos, int kv, int cout, int c, int pair_base,
+                                                 float4 &a0, float4 &a1) {
+    a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    a1 = a0;
+    unsigned long long m = __ballot(mypos >= 0) & ((kv >= 64) ? ~0ull : ((1ull << kv) - 1ull));
+    while (m) {
+        int kk[NL];
+        float4 t0[NL], t1[NL];
+        int cntv = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            if (m) { kk[i] = __builtin_ctzll(m); m &= m - 1; ++cntv; } else kk[i] = -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < cntv) {
+                const int pos = __shfl(mypos, kk[i], 64);
+                const float *row = P + (int64_t)(pos - pair_base) * cout + c;
+                t0[i] = *reinterpret_cast<const float4 *>(row);
+                t1[i] = *reinterpret_cast<const float4 *>(row + 256);
+            }
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < cntv) {
+                a0.x += t0[i].x; a0.y += t0[i].y; a0.z += t0[i].z; a0.w += t0[i].w;
+                a1.x += t1[i].x; a1.y += t1[i].y; a1.z += t1[i].z; a1.w += t1[i].w;
+            }
+    }
+}
 // phase 2: one wave per output voxel; lanes hold 2 x float4 of the 512 (or cout) channels
 __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *__restrict__ pair_pos, int64_t nv, int kv,
                                    int cout, const float *__restrict__ scale, const float *__restrict__ shift,
@@ -428,11 +459,13 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
         // accuracy of the split; the next layer's phase 1 multiplies its partial rows by y_inv_scale[row] = 2^-e (exact)
         float4 av[4];
         float amax = 0.f;
+        const bool pair512 = cout == 512;                    // the usual width: both column blocks of a row gathered together
+        if (pair512) conv_gather_sum2<GS_NL>(P, mypos, kv, cout, lane * 4, pair_base, av[0], av[1]);
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const int c = lane * 4 + ch * 256;
             if (c < cout) {
-                float4 a = conv_gather_sum<GS_NL>(P, mypos, kv, cout, c, pair_base);
+                float4 a = pair512 ? av[ch & 1] : conv_gather_sum<GS_NL>(P, mypos, kv, cout, c, pair_base);
                 float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
                 float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
@@ -527,8 +560,12 @@ __global__ void amax_kernel(const float *__restrict__ x, int64_t ld_x, int d, in
         float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
     }
+    // one atomic per block (same-address atomics serialise at the memory side)
+    __shared__ float s_m[4];
     m = gp_wave_max(m);
-    if (gp_lane() == 0) atomicMax(out, __float_as_uint(m));
+    if (gp_lane() == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 __global__ void pow2_scale_kernel(const unsigned *__restrict__ amax_bits, float *__restrict__ out2) {
     const float s = gp_pow2_for(__uint_as_float(amax_bits[0]));
@@ -637,7 +674,7 @@ extern "C" int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n,
                  "gp_pow2_scale: bad argument");
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(workspace, 0, 4, s));
-    amax_kernel<<<1024, 256, 0, s>>>(x, ld_x, d, n, static_cast<unsigned *>(workspace));
+    amax_kernel<<<1024, 256, 0, s>>>(x, ld_x, d, n, static_cast<unsigned *>(workspace));      // 256 threads: 4-wave block reduce
     pow2_scale_kernel<<<1, 1, 0, s>>>(static_cast<const unsigned *>(workspace), scale2);
     GP_CHECK_LAUNCH();
     return GP_OK;

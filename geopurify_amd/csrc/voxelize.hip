@@ -34,13 +34,23 @@ __global__ void vox_affine_kernel(const double *__restrict__ c, int64_t n, Mat34
             lo[a] = iv < lo[a] ? iv : lo[a];
         }
     }
+    // wave reduce -> block reduce -> one atomic per block and axis (same-address atomics serialise at the memory side)
+    __shared__ long long s_lo[4][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) {
             long long t = __shfl_xor(lo[a], o, 64);
             lo[a] = t < lo[a] ? t : lo[a];
         }
-        if (gp_lane() == 0) atomicMin(&mn[a], lo[a]);
+        if (gp_lane() == 0) s_lo[threadIdx.x >> 6][a] = lo[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        long long v = s_lo[0][a];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v = s_lo[w][a] < v ? s_lo[w][a] : v;
+        atomicMin(&mn[a], v);
     }
 }
 
@@ -209,7 +219,7 @@ extern "C" int gp_voxelize_f64(const double *coords, int64_t n, const double *ri
         for (int k = 0; k < 4; ++k) R.m[a][k] = rigid_host[a * 4 + k];
     int blocks = (int)((n + 255) / 256);
     init_min_kernel<<<1, 64, 0, s>>>(w.mn);
-    vox_affine_kernel<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(coords, n, R, w.ctmp, w.mn);
+    vox_affine_kernel<<<blocks < 256 ? blocks : 256, 256, 0, s>>>(coords, n, R, w.ctmp, w.mn);       // 256 threads: 4-wave block reduce
     vox_hash_kernel<<<blocks, 256, 0, s>>>(w.ctmp, n, w.mn, w.k0, w.v0);
     GP_CHECK_LAUNCH();
     size_t tb = w.tmp_bytes;
