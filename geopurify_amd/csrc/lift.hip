@@ -90,16 +90,11 @@ __global__ void transpose_kernel(const float *__restrict__ src, int rows, int co
 
 // row 6: one wave per visible point, lanes over queries.  Separable resize in the torch CPU order:
 // horizontal taps first (t = s0*w0; t = fma(s_i, w_i, t)), then vertical over the row results.
-__global__ void lift_masks_kernel(const float *__restrict__ mt /*[h*w, Q]*/, int Q, int h, int w,
-                                  const float *__restrict__ scores, const int32_t *__restrict__ tx0,
-                                  const float *__restrict__ twx, const int32_t *__restrict__ ty0,
-                                  const float *__restrict__ twy, int out_h, int out_w,
-                                  const int64_t *__restrict__ px, const int64_t *__restrict__ py, int64_t n_v,
-                                  int32_t *__restrict__ seg, float *__restrict__ seg_logit) {
-    int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    if (i >= n_v) return;
-    int lane = gp_lane();
-    int row = (int)px[i], col = (int)py[i];                     // x_label = pixel row, y_label = pixel col
+__device__ __forceinline__ void lift_masks_point(const float *__restrict__ mt /*[h*w, Q]*/, int Q, int h, int w,
+                                                 const float *__restrict__ scores, const int32_t *__restrict__ tx0,
+                                                 const float *__restrict__ twx, const int32_t *__restrict__ ty0,
+                                                 const float *__restrict__ twy, int out_h, int out_w, int row, int col, int lane,
+                                                 int &seg_out, float &logit_out) {
     bool inb = (unsigned)row < (unsigned)out_h && (unsigned)col < (unsigned)out_w;
     float best = -1.f, best_logit = 0.f;
     int best_q = -1;
@@ -139,11 +134,192 @@ __global__ void lift_masks_kernel(const float *__restrict__ mt /*[h*w, Q]*/, int
         bool take = (oq >= 0) && (best_q < 0 || ob > best || (ob == best && oq < best_q));
         if (take) { best = ob; best_q = oq; best_logit = ol; }
     }
+    float sg = 1.f / (1.f + expf(-best_logit));
+    seg_out = (best_q >= 0 && sg >= 0.5f) ? best_q : -1;
+    logit_out = best_logit;
+}
+__global__ void lift_masks_kernel(const float *__restrict__ mt /*[h*w, Q]*/, int Q, int h, int w,
+                                  const float *__restrict__ scores, const int32_t *__restrict__ tx0,
+                                  const float *__restrict__ twx, const int32_t *__restrict__ ty0,
+                                  const float *__restrict__ twy, int out_h, int out_w,
+                                  const int64_t *__restrict__ px, const int64_t *__restrict__ py, int64_t n_v,
+                                  int32_t *__restrict__ seg, float *__restrict__ seg_logit) {
+    int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (i >= n_v) return;
+    int lane = gp_lane();
+    int sg;
+    float lg;
+    lift_masks_point(mt, Q, h, w, scores, tx0, twx, ty0, twy, out_h, out_w, (int)px[i], (int)py[i], lane, sg, lg);   // x_label = pixel row
     if (lane == 0) {
-        float sg = 1.f / (1.f + expf(-best_logit));
-        seg[i] = (best_q >= 0 && sg >= 0.5f) ? best_q : -1;
-        if (seg_logit) seg_logit[i] = best_logit;
+        seg[i] = sg;
+        if (seg_logit) seg_logit[i] = lg;
     }
+}
+
+// ---- the same for ALL views of a scene: entries e = (view, point, pixel) in view-major order (gp_views_visible_lists); the masks
+// of view v are mt + v * h*w*Q, its scores scores + v * Q.  Entries of dropped views get -1.
+__global__ void transpose_views_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int64_t vo = (int64_t)blockIdx.z * rows * cols;
+    int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        int row = by + r, col = bx + tx;
+        tile[r][tx] = (row < rows && col < cols) ? src[vo + (int64_t)row * cols + col] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        int orow = bx + r, ocol = by + tx;
+        if (orow < cols && ocol < rows) dst[vo + (int64_t)orow * rows + ocol] = tile[tx][r];
+    }
+}
+__global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, Q]*/, int Q, int h, int w,
+                                        const float *__restrict__ scores /*[V,Q]*/, const int32_t *__restrict__ tx0,
+                                        const float *__restrict__ twx, const int32_t *__restrict__ ty0,
+                                        const float *__restrict__ twy, int out_h, int out_w,
+                                        const int64_t *__restrict__ ent_x, const int64_t *__restrict__ ent_y,
+                                        const int32_t *__restrict__ ent_view, const uint8_t *__restrict__ keep, int64_t total,
+                                        int32_t *__restrict__ seg) {
+    int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (e >= total) return;
+    int lane = gp_lane();
+    const int v = ent_view[e];
+    int sg = -1;
+    float lg;
+    if (keep[v])                                                 // wave-uniform
+        lift_masks_point(mt + (int64_t)v * h * w * Q, Q, h, w, scores + (int64_t)v * Q, tx0, twx, ty0, twy, out_h, out_w,
+                         (int)ent_x[e], (int)ent_y[e], lane, sg, lg);
+    if (lane == 0) seg[e] = sg;
+}
+
+// ---- in-view fill for all views (affinity_module.py:604-625): every entry without a segment takes the segment of the
+// nearest entry WITH one in the same view -- lexicographic minimum of (squared distance in fp64, entry index), the rule of
+// gp_nn1_masked_f64.  Covered entries are compacted (exclusive scan of the flags: view-major order is kept, so a view's
+// references are one contiguous range), queries likewise; blocks of 256 queries of one view stream that view's references
+// through LDS tiles, the reference range cut into FV_CHUNKS parts for parallelism, then the parts are reduced in order.
+constexpr int FV_CHUNKS = 16, FV_TILE = 1024;
+__global__ void fill_flags_kernel(const int32_t *__restrict__ seg, int64_t total, int32_t *__restrict__ cov /*[total+1]*/) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e < total) cov[e] = seg[e] >= 0 ? 1 : 0;
+    else if (e == total) cov[e] = 0;
+}
+__global__ void fill_compact_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ ent_pt, const int32_t *__restrict__ seg,
+                                    const int32_t *__restrict__ rs /*[total+1]*/, int64_t total, float *__restrict__ rxyz,
+                                    int32_t *__restrict__ rent, int32_t *__restrict__ qent) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int r = rs[e];
+    if (seg[e] >= 0) {
+        const int64_t p = ent_pt[e];
+        rxyz[(int64_t)r * 3] = xyz[p * 3]; rxyz[(int64_t)r * 3 + 1] = xyz[p * 3 + 1]; rxyz[(int64_t)r * 3 + 2] = xyz[p * 3 + 2];
+        rent[r] = (int32_t)e;
+    } else {
+        qent[e - r] = (int32_t)e;
+    }
+}
+// block -> (view, block of 256 queries of that view); blocks beyond the last view's exit
+__device__ __forceinline__ bool fill_locate(const int64_t *__restrict__ view_off, const int32_t *__restrict__ rs, int nviews,
+                                            int64_t bx, int &q0, int &q1, int &r0, int &r1) {
+    int64_t before = 0;
+    for (int v = 0; v < nviews; ++v) {
+        const int64_t o0 = view_off[v], o1 = view_off[v + 1];
+        const int rr0 = rs[o0], rr1 = rs[o1];
+        const int qq0 = (int)(o0 - rr0), qq1 = (int)(o1 - rr1);
+        const int64_t nb = (qq1 - qq0 + 255) / 256;
+        if (bx < before + nb) {
+            q0 = qq0 + (int)(bx - before) * 256;
+            q1 = qq1;
+            r0 = rr0;
+            r1 = rr1;
+            return true;
+        }
+        before += nb;
+    }
+    return false;
+}
+__global__ void __launch_bounds__(256)
+fill_part_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ ent_pt, const int64_t *__restrict__ view_off,
+                 const int32_t *__restrict__ rs, int nviews, const float *__restrict__ rxyz, const int32_t *__restrict__ qent,
+                 double *__restrict__ part_d, int32_t *__restrict__ part_i, int64_t stride) {
+    __shared__ double sx[FV_TILE], sy[FV_TILE], sz[FV_TILE];
+    int q0, q1, vr0, vr1;
+    if (!fill_locate(view_off, rs, nviews, blockIdx.x, q0, q1, vr0, vr1)) return;       // block-uniform
+    const int n_ref = vr1 - vr0;
+    if (n_ref == 0) return;
+    const int per = (n_ref + FV_CHUNKS - 1) / FV_CHUNKS;
+    const int r0 = vr0 + blockIdx.y * per, r1 = r0 + per < vr1 ? r0 + per : vr1;
+    const int qi = q0 + threadIdx.x;
+    const bool live = qi < q1;
+    double qx = 0, qy = 0, qz = 0;
+    if (live) {
+        const int64_t p = ent_pt[qent[qi]];
+        qx = xyz[p * 3]; qy = xyz[p * 3 + 1]; qz = xyz[p * 3 + 2];
+    }
+    double best = INFINITY;
+    int bi = -1;
+    for (int t0 = r0; t0 < r1; t0 += FV_TILE) {
+        int cnt = r1 - t0 < FV_TILE ? r1 - t0 : FV_TILE;
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += 256) {
+            sx[j] = rxyz[(int64_t)(t0 + j) * 3]; sy[j] = rxyz[(int64_t)(t0 + j) * 3 + 1]; sz[j] = rxyz[(int64_t)(t0 + j) * 3 + 2];
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            double dx = qx - sx[j], dy = qy - sy[j], dz = qz - sz[j];
+            double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; bi = t0 + j; }
+        }
+    }
+    if (live) { part_d[(int64_t)blockIdx.y * stride + qi] = best; part_i[(int64_t)blockIdx.y * stride + qi] = bi; }
+}
+__global__ void fill_reduce_kernel(const int64_t *__restrict__ view_off, const int32_t *__restrict__ rs, int nviews,
+                                   const double *__restrict__ part_d, const int32_t *__restrict__ part_i, int64_t stride,
+                                   const int32_t *__restrict__ rent, const int32_t *__restrict__ qent, int32_t *__restrict__ seg) {
+    int q0, q1, vr0, vr1;
+    if (!fill_locate(view_off, rs, nviews, blockIdx.x, q0, q1, vr0, vr1)) return;
+    if (vr1 == vr0) return;
+    const int qi = q0 + threadIdx.x;
+    if (qi >= q1) return;
+    const int per = (vr1 - vr0 + FV_CHUNKS - 1) / FV_CHUNKS;
+    double best = INFINITY;
+    int bi = -1;
+    for (int c = 0; c < FV_CHUNKS; ++c) {
+        if (vr0 + c * per >= vr1) break;                         // chunks beyond the range wrote nothing
+        double d = part_d[(int64_t)c * stride + qi];
+        int i = part_i[(int64_t)c * stride + qi];
+        if (i >= 0 && d < best) { best = d; bi = i; }
+    }
+    if (bi >= 0) seg[qent[qi]] = seg[rent[bi]];                  // references keep their segment: no read/write overlap
+}
+
+// ---- point -> (view, segment) CSR for all views at once.  vmask[p] = bit set of the kept views that see p (<= 128 views),
+// a point's entries are ordered by view like the sequential per-view fill: position = start[p] + popcount(lower views).
+__global__ void pv_mask_kernel(const int64_t *__restrict__ ent_pt, const int32_t *__restrict__ ent_view, const uint8_t *__restrict__ keep,
+                               int64_t total, unsigned long long *__restrict__ vmask) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int v = ent_view[e];
+    if (keep[v]) atomicOr(&vmask[ent_pt[e] * 2 + (v >> 6)], 1ull << (v & 63));
+}
+__global__ void pv_cnt_kernel(const unsigned long long *__restrict__ vmask, int64_t n, int64_t *__restrict__ cnt /*[n+1]*/) {
+    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p < n) cnt[p] = __popcll(vmask[2 * p]) + __popcll(vmask[2 * p + 1]);
+    else if (p == n) cnt[p] = 0;
+}
+__global__ void pv_fill_views_kernel(const int64_t *__restrict__ ent_pt, const int32_t *__restrict__ ent_view,
+                                     const uint8_t *__restrict__ keep, const int32_t *__restrict__ seg, int64_t total,
+                                     const unsigned long long *__restrict__ vmask, const int64_t *__restrict__ start,
+                                     int32_t *__restrict__ pv_view, int32_t *__restrict__ pv_seg) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int v = ent_view[e];
+    if (!keep[v]) return;
+    const int64_t p = ent_pt[e];
+    const unsigned long long m0 = vmask[2 * p], m1 = vmask[2 * p + 1];
+    const int rank = v < 64 ? __popcll(m0 & ((1ull << v) - 1ull)) : __popcll(m0) + __popcll(m1 & ((1ull << (v - 64)) - 1ull));
+    const int64_t s_ = start[p] + rank;
+    pv_view[s_] = v;
+    pv_seg[s_] = seg[e];
 }
 
 // per-segment tables: f_seg = normalize(embed), logit_seg = scale * f_seg . text_norm
@@ -308,6 +484,88 @@ extern "C" int gp_lift_masks_view(const float *pred_masks, int32_t q, int32_t h,
     transpose_kernel<<<tg, 256, 0, s>>>(pred_masks, q, hw, mt);
     lift_masks_kernel<<<(int)((n_v * 64 + 255) / 256), 256, 0, s>>>(mt, q, h, w, scores, tap_x0, tap_wx, tap_y0, tap_wy,
                                                                     out_h, out_w, x, y, n_v, seg, seg_logit);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// ---- all views of a scene at once (entries from gp_views_visible_lists)
+static size_t lv_scan32_tmp(int64_t n) {
+    size_t t = 0;
+    (void)rocprim::exclusive_scan(nullptr, t, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), 0);
+    return t;
+}
+static size_t lv_scan64_tmp(int64_t n) {
+    size_t t = 0;
+    (void)rocprim::exclusive_scan(nullptr, t, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0);
+    return t;
+}
+struct LvWork {
+    float *mt; int32_t *cov, *rs, *rent, *qent; float *rxyz; double *part_d; int32_t *part_i; unsigned long long *vmask;
+    int64_t *cnt; char *tmp; size_t tmp_bytes;
+};
+static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n, LvWork &k) {
+    GpCarver cv(ws, bytes);
+    k.mt = cv.take<float>((size_t)nsrc * q * h * w);
+    k.cov = cv.take<int32_t>(total + 1);
+    k.rs = cv.take<int32_t>(total + 1);
+    k.rent = cv.take<int32_t>(total);
+    k.qent = cv.take<int32_t>(total);
+    k.rxyz = cv.take<float>(total * 3);
+    k.part_d = cv.take<double>((size_t)FV_CHUNKS * total);
+    k.part_i = cv.take<int32_t>((size_t)FV_CHUNKS * total);
+    k.vmask = cv.take<unsigned long long>(n * 2);
+    k.cnt = cv.take<int64_t>(n + 1);
+    size_t a = lv_scan32_tmp(total + 1), b = lv_scan64_tmp(n + 1);
+    k.tmp_bytes = a > b ? a : b;
+    k.tmp = cv.take<char>(k.tmp_bytes);
+    return cv.off;
+}
+extern "C" size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n) {
+    if (nsrc <= 0 || q <= 0 || h <= 0 || w <= 0 || total <= 0 || n <= 0) return 0;
+    LvWork k;
+    return lv_carve(nullptr, 0, nsrc, q, h, w, total, n, k);
+}
+// seg i32 [total] (out: segment of every entry after the in-view fill, -1 = none); pv_start i64 [n+1], pv_view / pv_seg i32 [total]
+// (out: the point -> (view, segment) CSR that gp_fuse_views_top3 reads).  Replaces, for all views together, the per-view
+// sequence gp_lift_masks_view -> gp_nn1_masked_f64 + gather -> gp_pv_count -> scan -> gp_pv_fill.
+extern "C" int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_t q, int32_t h, int32_t w, const float *scores,
+                                   const int32_t *tap_x0, const float *tap_wx, const int32_t *tap_y0, const float *tap_wy,
+                                   int32_t out_h, int32_t out_w, const float *xyz, int64_t n, const int64_t *ent_pt,
+                                   const int64_t *ent_x, const int64_t *ent_y, const int32_t *ent_view, const int64_t *view_off,
+                                   const uint8_t *keep, int32_t nviews, int64_t total, int32_t *seg, int64_t *pv_start,
+                                   int32_t *pv_view, int32_t *pv_seg, void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(pred_masks && scores && tap_x0 && tap_wx && tap_y0 && tap_wy && xyz && ent_pt && ent_x && ent_y && ent_view && view_off &&
+                     keep && seg && pv_start && pv_view && pv_seg && workspace,
+                 "gp_lift_masks_views: null argument");
+    GP_CHECK_ARG(q > 0 && h > 0 && w > 0 && n > 0 && total > 0, "gp_lift_masks_views: empty shape");
+    GP_CHECK_ARG(nviews > 0 && nviews <= 128 && nviews <= nsrc, "gp_lift_masks_views: %d views (1..128, <= %d mask sets)", nviews, nsrc);
+    GP_CHECK_ARG(total < (int64_t)INT32_MAX, "gp_lift_masks_views: too many entries");
+    LvWork k;
+    if (lv_carve(workspace, workspace_bytes, nsrc, q, h, w, total, n, k) > workspace_bytes) {
+        gp_set_error("gp_lift_masks_views: workspace too small");
+        return GP_ENOMEM;
+    }
+    hipStream_t s = gp_stream(stream_);
+    const int hw = h * w;
+    transpose_views_kernel<<<dim3((hw + 63) / 64, (q + 63) / 64, nviews), 256, 0, s>>>(pred_masks, q, hw, k.mt);
+    lift_masks_views_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, s>>>(k.mt, q, h, w, scores, tap_x0, tap_wx, tap_y0, tap_wy,
+                                                                               out_h, out_w, ent_x, ent_y, ent_view, keep, total, seg);
+    // in-view fill
+    const unsigned eb = (unsigned)((total + 1 + 255) / 256);
+    fill_flags_kernel<<<eb, 256, 0, s>>>(seg, total, k.cov);
+    size_t tb = k.tmp_bytes;
+    GP_CHECK_HIP(rocprim::exclusive_scan(k.tmp, tb, k.cov, k.rs, (int32_t)0, (size_t)(total + 1), rocprim::plus<int32_t>(), s));
+    fill_compact_kernel<<<eb, 256, 0, s>>>(xyz, ent_pt, seg, k.rs, total, k.rxyz, k.rent, k.qent);
+    const unsigned qb = (unsigned)(total / 256 + nviews + 1);                           // >= sum over views of ceil(queries / 256)
+    fill_part_kernel<<<dim3(qb, FV_CHUNKS), 256, 0, s>>>(xyz, ent_pt, view_off, k.rs, nviews, k.rxyz, k.qent, k.part_d, k.part_i, total);
+    fill_reduce_kernel<<<qb, 256, 0, s>>>(view_off, k.rs, nviews, k.part_d, k.part_i, total, k.rent, k.qent, seg);
+    // point -> (view, segment) lists
+    GP_CHECK_HIP(hipMemsetAsync(k.vmask, 0, (size_t)n * 2 * sizeof(unsigned long long), s));
+    pv_mask_kernel<<<eb, 256, 0, s>>>(ent_pt, ent_view, keep, total, k.vmask);
+    pv_cnt_kernel<<<(unsigned)((n + 1 + 255) / 256), 256, 0, s>>>(k.vmask, n, k.cnt);
+    tb = k.tmp_bytes;
+    GP_CHECK_HIP(rocprim::exclusive_scan(k.tmp, tb, k.cnt, pv_start, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    pv_fill_views_kernel<<<eb, 256, 0, s>>>(ent_pt, ent_view, keep, seg, total, k.vmask, pv_start, pv_view, pv_seg);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -115,18 +115,17 @@ __global__ void vox_emit_kernel(const double *__restrict__ c, const int64_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void project_kernel(const double *__restrict__ c, int64_t n, Mat44 M, double fx, double fy, double cx,
-                               double cy, const double *__restrict__ depth, int W, int H, int cut, double tau,
-                               int64_t *__restrict__ mapping, double *__restrict__ weight) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double x = c[i * 3], y = c[i * 3 + 1], z = c[i * 3 + 2];
-    double p0 = dot4_blas(M.m[0], x, y, z), p1 = dot4_blas(M.m[1], x, y, z), p2 = dot4_blas(M.m[2], x, y, z);
+// one point through one view: pixel (vi = row, ui = column) and the visibility decision of fusion_util.py:99-147 / :45-82
+__device__ __forceinline__ bool project_point(double x, double y, double z, const double *m0, const double *m1, const double *m2,
+                                              double fx, double fy, double cx, double cy, const double *__restrict__ depth,
+                                              int W, int H, int cut, double tau, long long &ui, long long &vi) {
+    double p0 = dot4_blas(m0, x, y, z), p1 = dot4_blas(m1, x, y, z), p2 = dot4_blas(m2, x, y, z);
     double u = (p0 * fx) / p2 + cx;
     double v = (p1 * fy) / p2 + cy;
     double ur = rint(u), vr = rint(v);
     bool finite = (fabs(ur) < 9.0e15) && (fabs(vr) < 9.0e15);      // also false for NaN
-    long long ui = finite ? (long long)ur : -1, vi = finite ? (long long)vr : -1;
+    ui = finite ? (long long)ur : -1;
+    vi = finite ? (long long)vr : -1;
     bool inside = finite && ui >= cut && vi >= cut && ui < (long long)W - cut && vi < (long long)H - cut;
     if (depth) {
         if (inside) {
@@ -136,6 +135,56 @@ __global__ void project_kernel(const double *__restrict__ c, int64_t n, Mat44 M,
     } else {
         inside = inside && (p2 > 0.0);
     }
+    return inside;
+}
+
+// ---- all views of a scene in one launch per step (instead of V x {project, flags, scan, compact}):
+// params f64 [V,20] = row-major world->camera (16) | fx fy cx cy; depth f64 [V,H,W] or NULL.  Entries come out view-major,
+// ascending point id inside a view -- the concatenation of the per-view lists of gp_visible_lists.
+__global__ void views_flags_kernel(const double *__restrict__ c, int64_t n, const double *__restrict__ params,
+                                   const double *__restrict__ depth, int W, int H, int cut, double tau, int32_t *__restrict__ flags) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= n) return;
+    const double *P = params + v * 20;
+    long long ui, vi;
+    flags[(int64_t)v * n + i] = project_point(c[i * 3], c[i * 3 + 1], c[i * 3 + 2], P, P + 4, P + 8, P[16], P[17], P[18], P[19],
+                                              depth ? depth + (int64_t)v * W * H : nullptr, W, H, cut, tau, ui, vi) ? 1 : 0;
+}
+__global__ void views_compact_kernel(const double *__restrict__ c, int64_t n, int nviews, const double *__restrict__ params,
+                                     const double *__restrict__ depth, int W, int H, int cut, double tau,
+                                     const int32_t *__restrict__ sc /* exclusive scan of the flags */, int64_t *__restrict__ ent_pt,
+                                     int64_t *__restrict__ ent_x, int64_t *__restrict__ ent_y, int32_t *__restrict__ ent_view,
+                                     int64_t *__restrict__ view_off) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= n) return;
+    const double *P = params + v * 20;
+    long long ui, vi;
+    const bool inside = project_point(c[i * 3], c[i * 3 + 1], c[i * 3 + 2], P, P + 4, P + 8, P[16], P[17], P[18], P[19],
+                                      depth ? depth + (int64_t)v * W * H : nullptr, W, H, cut, tau, ui, vi);
+    const int32_t pos = sc[(int64_t)v * n + i];
+    if (inside) { ent_pt[pos] = i; ent_x[pos] = vi; ent_y[pos] = ui; ent_view[pos] = v; }
+    if (i == 0) view_off[v] = pos;
+    if (v == nviews - 1 && i == n - 1) view_off[nviews] = pos + (inside ? 1 : 0);
+}
+// the view-drop rule of the loader (data_loader_ablation.py:254-255, 280-288) on the device
+__global__ void views_keep_kernel(const int64_t *__restrict__ view_off, int nviews, int64_t min_visible, int64_t val_keep,
+                                  uint8_t *__restrict__ keep) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nviews) return;
+    const int64_t nv = view_off[v + 1] - view_off[v];
+    keep[v] = (nv != 0 && nv >= min_visible && nv <= val_keep) ? 1 : 0;
+}
+
+__global__ void project_kernel(const double *__restrict__ c, int64_t n, Mat44 M, double fx, double fy, double cx,
+                               double cy, const double *__restrict__ depth, int W, int H, int cut, double tau,
+                               int64_t *__restrict__ mapping, double *__restrict__ weight) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long ui, vi;
+    const bool inside = project_point(c[i * 3], c[i * 3 + 1], c[i * 3 + 2], M.m[0], M.m[1], M.m[2], fx, fy, cx, cy, depth, W, H,
+                                      cut, tau, ui, vi);
     mapping[i * 3] = inside ? vi : 0;
     mapping[i * 3 + 1] = inside ? ui : 0;
     mapping[i * 3 + 2] = inside ? 1 : 0;
@@ -251,6 +300,41 @@ extern "C" int gp_project_points_f64(const double *coords, int64_t n, const doub
         for (int k = 0; k < 4; ++k) M.m[a][k] = w2c_host[a * 4 + k];
     project_kernel<<<(int)((n + 255) / 256), 256, 0, gp_stream(stream_)>>>(coords, n, M, fx, fy, cx, cy, depth, width,
                                                                           height, cut_bound, vis_thres, mapping, weight);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+static size_t views_scan_tmp(int64_t n) {
+    size_t t = 0;
+    (void)rocprim::exclusive_scan(nullptr, t, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), 0);
+    return t;
+}
+extern "C" size_t gp_views_visible_lists_workspace_bytes(int64_t n, int32_t nviews) {
+    if (n <= 0 || nviews <= 0) return 0;
+    GpCarver cv(nullptr, 0);
+    cv.take<int32_t>(n * nviews); cv.take<int32_t>(n * nviews); cv.take<char>(views_scan_tmp(n * nviews));
+    return cv.off;
+}
+extern "C" int gp_views_visible_lists(const double *coords, int64_t n, const double *params, const double *depth, int32_t nviews,
+                                      int32_t width, int32_t height, int32_t cut_bound, double vis_thres, int64_t min_visible,
+                                      int64_t val_keep, int64_t *ent_pt, int64_t *ent_x, int64_t *ent_y, int32_t *ent_view,
+                                      int64_t *view_off, uint8_t *keep, void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(coords && params && ent_pt && ent_x && ent_y && ent_view && view_off && keep && workspace && n > 0,
+                 "gp_views_visible_lists: null/empty argument");
+    GP_CHECK_ARG(nviews > 0 && nviews <= 65535 && width > 0 && height > 0, "gp_views_visible_lists: bad view count / image size");
+    GP_CHECK_ARG(n * (int64_t)nviews < (int64_t)INT32_MAX, "gp_views_visible_lists: n * views must stay below 2^31");
+    GpCarver cv(workspace, workspace_bytes);
+    int32_t *flags = cv.take<int32_t>(n * nviews), *sc = cv.take<int32_t>(n * nviews);
+    size_t tb = views_scan_tmp(n * nviews);
+    char *tmp = cv.take<char>(tb);
+    if (!cv.ok()) { gp_set_error("gp_views_visible_lists: workspace too small"); return GP_ENOMEM; }
+    hipStream_t s = gp_stream(stream_);
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)nviews);
+    views_flags_kernel<<<grid, 256, 0, s>>>(coords, n, params, depth, width, height, cut_bound, vis_thres, flags);
+    GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, flags, sc, (int32_t)0, (size_t)(n * nviews), rocprim::plus<int32_t>(), s));
+    views_compact_kernel<<<grid, 256, 0, s>>>(coords, n, nviews, params, depth, width, height, cut_bound, vis_thres, sc, ent_pt, ent_x,
+                                              ent_y, ent_view, view_off);
+    views_keep_kernel<<<(nviews + 255) / 256, 256, 0, s>>>(view_off, nviews, min_visible, val_keep, keep);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -552,6 +552,51 @@ def visible_lists(mapping, pt, x, y, count_dev, workspace=None):
                                workspace.numel(), _stream()), "gp_visible_lists")
 
 
+def views_visible_lists(coords, params, depth_all, width, height, cut_bound, vis_thres, min_visible, val_keep):
+    """All views of a scene at once: coords f64 [N,3]; params f64 [V,20] (device) = world->camera (16) | fx fy cx cy;
+    depth_all f64 [V,H,W] or None.  Returns the view-major entry arrays (sized V*N; view_off[V] = entries used)."""
+    lib = _lib.load()
+    _chk(coords, torch.float64, "coords")
+    _chk(params, torch.float64, "params")
+    n, nv = coords.shape[0], params.shape[0]
+    dev = coords.device
+    if depth_all is not None:
+        _chk(depth_all, torch.float64, "depth_all")
+        assert depth_all.shape == (nv, height, width)
+    ent = {"pt": torch.empty(nv * n, dtype=torch.int64, device=dev), "x": torch.empty(nv * n, dtype=torch.int64, device=dev),
+           "y": torch.empty(nv * n, dtype=torch.int64, device=dev), "view": torch.empty(nv * n, dtype=torch.int32, device=dev),
+           "view_off": torch.empty(nv + 1, dtype=torch.int64, device=dev), "keep": torch.empty(nv, dtype=torch.uint8, device=dev)}
+    ws = _ws(lib.gp_views_visible_lists_workspace_bytes(n, nv), dev)
+    check(lib.gp_views_visible_lists(_ptr(coords), n, _ptr(params), _ptr(depth_all), nv, int(width), int(height), int(cut_bound),
+                                     float(vis_thres), int(min_visible), int(val_keep), _ptr(ent["pt"]), _ptr(ent["x"]), _ptr(ent["y"]),
+                                     _ptr(ent["view"]), _ptr(ent["view_off"]), _ptr(ent["keep"]), _ptr(ws), ws.numel(), _stream()),
+          "gp_views_visible_lists")
+    return ent
+
+
+def lift_masks_views(pred_masks, scores, taps, out_hw, xyz, ent, total, nviews):
+    """Rows 6-7 up to the point -> (view, segment) lists for all views at once.  pred_masks f32 [Vsrc,Q,h,w], scores f32
+    [Vsrc,Q], xyz f32 [N,3], ent = views_visible_lists(...), total = entries used.  Returns (seg, pv_start, pv_view, pv_seg)."""
+    lib = _lib.load()
+    _chk(pred_masks, torch.float32, "pred_masks")
+    _chk(scores, torch.float32, "scores")
+    _chk(xyz, torch.float32, "xyz")
+    nsrc, Q, h, w = pred_masks.shape
+    n = xyz.shape[0]
+    dev = xyz.device
+    seg = torch.empty(total, dtype=torch.int32, device=dev)
+    start = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    pvv = torch.empty(total, dtype=torch.int32, device=dev)
+    pvs = torch.empty(total, dtype=torch.int32, device=dev)
+    ws = _ws(lib.gp_lift_masks_views_workspace_bytes(nsrc, Q, h, w, total, n), dev)
+    tx0, twx, ty0, twy = taps
+    check(lib.gp_lift_masks_views(_ptr(pred_masks), nsrc, Q, h, w, _ptr(scores), _ptr(tx0), _ptr(twx), _ptr(ty0), _ptr(twy),
+                                  int(out_hw[0]), int(out_hw[1]), _ptr(xyz), n, _ptr(ent["pt"]), _ptr(ent["x"]), _ptr(ent["y"]),
+                                  _ptr(ent["view"]), _ptr(ent["view_off"]), _ptr(ent["keep"]), int(nviews), int(total), _ptr(seg),
+                                  _ptr(start), _ptr(pvv), _ptr(pvs), _ptr(ws), ws.numel(), _stream()), "gp_lift_masks_views")
+    return seg, start, pvv, pvs
+
+
 # ------------------------------------------------------------------------------------------ row 13
 def classify_argmax(feat, text_norm, logit_scale, d=None):
     lib = _lib.load()

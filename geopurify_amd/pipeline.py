@@ -141,6 +141,7 @@ class SceneBatch:
     seg_start: Optional[torch.Tensor] = None
     extent: Optional[list] = None              # host ints: max voxel coord + 1 per axis (min is 0)
     imgs: Optional[torch.Tensor] = None        # f32 [V,H,W,3] slot 11 of the tuple: what the 2D VLM is run on (:496)
+    ent: Optional[dict] = None                 # all views' entries in one set of arrays (ops.views_visible_lists) + "total", "max_nv"
 
     def as_tuple(self):
         """The reference's positional 20-tuple (unused per-view voxelization slots are empty)."""
@@ -162,10 +163,25 @@ class SceneBatch:
                 e, e, e, e, e, e, imgs, xl, yl, mask_2ds, e, e, e, (None,) * V, self.scene_gauss_features)
 
 
-def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000):
+def _view_matrices(cfg, views):
+    """Per view: world->camera matrix and intrinsics at image_dim, as the mappers build them."""
+    from .synthetic import mapper_intrinsics
+    out = []
+    for v in views:
+        K = mapper_intrinsics(cfg, v.K)
+        if cfg.dataset == "scannet":
+            w2c = np.asarray(v.pose).T.astype(np.float64)                 # fusion_util.py:114 (W2C^T float32 -> .T)
+        else:
+            w2c = np.linalg.inv(np.asarray(v.pose))                       # fusion_util.py:60 (inverse of the fp32 c2w)
+        out.append((w2c, K))
+    return out
+
+
+def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_views=True):
     """Loader math on the device for one synthetic scene (geopurify_amd.synthetic.Scene):
     scene voxelization (rows 1-2), per-view mapping (row 3), visible lists and the view-drop rule
-    (data_loader_ablation.py:254-255,280-288)."""
+    (data_loader_ablation.py:254-255,280-288).  batch_views: all views in one set of launches (needs the depth maps
+    stacked on the device, upload_scene) -- the same lists as the view-by-view path, bit for bit."""
     from .synthetic import mapper_intrinsics
     cfg = scene.cfg
     dev = torch.device(device)
@@ -174,18 +190,34 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000):
     vox = ops.voxelize(coords64, rigid)                                   # sync #1 (nv)
     W, H = cfg.image_dim
     V = len(scene.views)
+    gauss = scene.gauss_dev if hasattr(scene, "gauss_dev") else torch.from_numpy(
+        np.concatenate([scene.colors, scene.normals], 1).astype(np.float32)).to(dev)
+    labels = scene.labels_dev if hasattr(scene, "labels_dev") else torch.from_numpy(scene.labels).to(dev)
+    if batch_views and V and getattr(scene, "depth_all_dev", None) is not None and V * N < 2 ** 31:
+        mats = _view_matrices(cfg, scene.views)
+        params = np.stack([np.concatenate([m.reshape(16), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]]) for m, K in mats]).astype(np.float64)
+        ent = ops.views_visible_lists(coords64, torch.from_numpy(params).to(dev), scene.depth_all_dev, W, H, cfg.cut_bound,
+                                      cfg.vis_thres, cfg.min_visible, val_keep)
+        tail = torch.cat([ent["view_off"], vox["coords_aug"].amax(0).to(torch.int64) + 1])
+        host = tail.cpu().tolist()                                        # sync #2 (entries per view + extent)
+        views = []
+        for i in range(V):
+            o, n_v = host[i], host[i + 1] - host[i]
+            if n_v == 0 or n_v < cfg.min_visible or n_v > val_keep:
+                continue
+            views.append(ViewLists(ent["pt"][o:o + n_v], ent["x"][o:o + n_v], ent["y"][o:o + n_v], i))
+        ent["total"] = host[V]
+        ent["max_nv"] = max([host[i + 1] - host[i] for i in range(V)] + [0])
+        ent["num_views"] = V
+        return SceneBatch(coords64.float(), vox["coords_aug"].float(), vox["inds_reconstruct"], labels, gauss, views,
+                          vox["order"], vox["seg_start"], host[V + 1:V + 4], ent=ent)
     depth_dev = scene.depth_dev if hasattr(scene, "depth_dev") else [torch.from_numpy(v.depth).to(dev) for v in scene.views]
     pt = torch.empty((V, N), dtype=torch.int64, device=dev)
     xs = torch.empty((V, N), dtype=torch.int64, device=dev)
     ys = torch.empty((V, N), dtype=torch.int64, device=dev)
     counts = torch.zeros(V + 3, dtype=torch.int64, device=dev)
     ws = None
-    for i, v in enumerate(scene.views):
-        K = mapper_intrinsics(cfg, v.K)
-        if cfg.dataset == "scannet":
-            w2c = np.asarray(v.pose).T.astype(np.float64)                 # fusion_util.py:114 (W2C^T float32 -> .T)
-        else:
-            w2c = np.linalg.inv(np.asarray(v.pose))                       # fusion_util.py:60 (inverse of the fp32 c2w)
+    for i, (w2c, K) in enumerate(_view_matrices(cfg, scene.views)):
         mapping = ops.project_points(coords64, w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], depth_dev[i], W, H,
                                      cfg.cut_bound, cfg.vis_thres)
         if ws is None:
@@ -199,9 +231,6 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000):
         if n_v == 0 or n_v < cfg.min_visible or n_v > val_keep:
             continue
         views.append(ViewLists(pt[i, :n_v], xs[i, :n_v], ys[i, :n_v], i))
-    gauss = scene.gauss_dev if hasattr(scene, "gauss_dev") else torch.from_numpy(
-        np.concatenate([scene.colors, scene.normals], 1).astype(np.float32)).to(dev)
-    labels = scene.labels_dev if hasattr(scene, "labels_dev") else torch.from_numpy(scene.labels).to(dev)
     return SceneBatch(coords64.float(), vox["coords_aug"].float(), vox["inds_reconstruct"], labels, gauss, views,
                       vox["order"], vox["seg_start"], host[V:V + 3])
 
@@ -210,7 +239,13 @@ def upload_scene(scene, device="cuda"):
     """Make the raw inputs resident in HBM (outside any timed region)."""
     dev = torch.device(device)
     scene.coords_dev = torch.from_numpy(scene.coords).to(dev)
-    scene.depth_dev = [torch.from_numpy(v.depth).to(dev) for v in scene.views]
+    shapes = {v.depth.shape for v in scene.views}
+    if len(shapes) == 1:                                           # one stacked array: what the all-views loader kernels read
+        scene.depth_all_dev = torch.from_numpy(np.stack([v.depth for v in scene.views])).to(dev)
+        scene.depth_dev = list(scene.depth_all_dev.unbind(0))
+    else:
+        scene.depth_all_dev = None
+        scene.depth_dev = [torch.from_numpy(v.depth).to(dev) for v in scene.views]
     scene.gauss_dev = torch.from_numpy(np.concatenate([scene.colors, scene.normals], 1).astype(np.float32)).to(dev)
     scene.labels_dev = torch.from_numpy(scene.labels).to(dev)
     return scene
@@ -266,8 +301,9 @@ class HotPath:
     constants (affinity_module.py:1492-1493,1584-1587) exposed as options."""
 
     def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda",
-                 pool_mode="auto", pool_tile_rows=8, pool_block_rows=64):
+                 pool_mode="auto", pool_tile_rows=8, pool_block_rows=64, batch_views=True):
         self.student = student
+        self.batch_views = batch_views                 # lift all views of a scene in one set of launches when the inputs allow it
         self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
@@ -319,13 +355,24 @@ class HotPath:
         if batched:
             ops.segment_tables(vlm.mask_embed.view(n_tab * Q, D), text_norm, logit_scale,
                                f_seg.view(n_tab * Q, D), l_seg.view(n_tab * Q, C))
-        cnt = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-        segs = []
-        ws_m = ws_n = None
         # segment scores (:544) of all source views in one softmax + max when the logits are stacked (rows are independent)
         scores_all = None
         if batched and getattr(vlm, "pred_logits", None) is not None and vlm.pred_logits.dim() == 3:
             scores_all = torch.softmax(vlm.pred_logits, dim=-1)[..., :-1].max(-1).values.contiguous()
+        ent = batch.ent
+        pm_all = getattr(vlm, "pred_masks", None)
+        all_views = (self.batch_views and batched and scores_all is not None and ent is not None and ent["total"] > 0
+                     and ent["num_views"] <= 128 and ent["max_nv"] < 32768                 # larger views: the grid search of nn1_masked
+                     and torch.is_tensor(pm_all) and pm_all.dim() == 4 and pm_all.is_contiguous()
+                     and pm_all.shape[0] >= ent["num_views"])
+        if all_views:
+            # every view of the scene in one set of launches: segments, in-view fill and the point -> (view, segment) lists
+            _, start, pvv, pvs = ops.lift_masks_views(pm_all, scores_all, self._tap_tables(pm_all.shape[2], pm_all.shape[3]),
+                                                      self.mask_shape, batch.scene_coords, ent, ent["total"], ent["num_views"])
+            return self._fuse_and_fill(batch, start, pvv, pvs, f_seg, l_seg, D, text_norm, logit_scale)
+        cnt = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        segs = []
+        ws_m = ws_n = None
         for i, v in enumerate(batch.views):
             out = vlm(v.src_view) if batched else outs[i]
             pm = out["pred_masks"].to(dev).contiguous()
@@ -353,6 +400,12 @@ class HotPath:
         pvs = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         for i, v in enumerate(batch.views):
             ops.pv_fill(v.pt, segs[i], v.src_view if batched else i, start, cursor, pvv, pvs)
+        return self._fuse_and_fill(batch, start, pvv, pvs, f_seg, l_seg, D, text_norm if V else text_embed, logit_scale)
+
+    def _fuse_and_fill(self, batch, start, pvv, pvs, f_seg, l_seg, D, text, logit_scale):
+        """Consensus fusion over a point's (view, segment) list (:647-686) and the scene-level fill of never-seen points."""
+        dev = self.device
+        N = batch.scene_coords.shape[0]
         F = torch.empty((N, D), dtype=torch.float32, device=dev)
         seen = ops.fuse_views_top3(start, pvv, pvs, N, f_seg, l_seg, F)
         # scene-level fill of never-seen points (:687-696)
@@ -360,7 +413,7 @@ class HotPath:
         src = torch.where(nn >= 0, nn, torch.arange(N, device=dev))
         F = ops.gather_rows(F, D, src)
         # the reference returns the NORMALISED text embeddings (affinity_module.py:628 rebinds the name returned at :711)
-        return F, (text_norm if V else text_embed), logit_scale
+        return F, text, logit_scale
 
     # ---- row 5 ----------------------------------------------------------------------------------
     def lift_dense(self, batch: SceneBatch, vlm: DenseFeatureVLM):

@@ -249,6 +249,21 @@ int gp_lift_masks_view(const float *pred_masks, int32_t q, int32_t h, int32_t w,
                        const int32_t *tap_y0, const float *tap_wy, int32_t out_h, int32_t out_w,
                        const int64_t *x, const int64_t *y, int64_t n_v, int32_t *seg,
                        float *seg_logit, void *workspace, size_t workspace_bytes, void *stream);
+/* gp_lift_masks_views: rows 6-7 up to the point -> (view, segment) lists for ALL views of a scene at once (entries      */
+/* from gp_views_visible_lists; pred_masks f32 [nsrc,Q,h,w] and scores f32 [nsrc,Q] stacked over the source views,        */
+/* nviews <= nsrc, nviews <= 128).  Per entry the segment of gp_lift_masks_view; then the in-view fill                    */
+/* (affinity_module.py:604-625: an entry without a segment takes the one of the nearest entry with a segment in the       */
+/* same view, (fp64 squared distance of the fp32 xyz [n,3], entry order) minimum = gp_nn1_masked_f64's rule); then the     */
+/* CSR pv_start i64 [n+1], pv_view / pv_seg i32 [total] that gp_fuse_views_top3 reads, a point's entries in ascending      */
+/* view order (= gp_pv_count + scan + gp_pv_fill called view by view).  seg i32 [total] out.  Entries of views with       */
+/* keep == 0 take no part.                                                                                              */
+size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n);
+int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_t q, int32_t h, int32_t w, const float *scores,
+                        const int32_t *tap_x0, const float *tap_wx, const int32_t *tap_y0, const float *tap_wy,
+                        int32_t out_h, int32_t out_w, const float *xyz, int64_t n, const int64_t *ent_pt,
+                        const int64_t *ent_x, const int64_t *ent_y, const int32_t *ent_view, const int64_t *view_off,
+                        const uint8_t *keep, int32_t nviews, int64_t total, int32_t *seg, int64_t *pv_start,
+                        int32_t *pv_view, int32_t *pv_seg, void *workspace, size_t workspace_bytes, void *stream);
 /* gp_segment_tables: per view, f_seg[q,:] = normalize(mask_embed[q,:]) and                         */
 /* logit_seg[q,c] = logit_scale * <f_seg[q], normalize(text[c])>  (affinity_module.py:627-630;       */
 /* every point feature is a segment embedding).                                     */
@@ -290,6 +305,17 @@ int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref_mask, cons
 size_t gp_visible_lists_workspace_bytes(int64_t n);
 int gp_visible_lists(const int64_t *mapping, int64_t n, int64_t *pt, int64_t *x, int64_t *y,
                      int64_t *count_dev, void *workspace, size_t workspace_bytes, void *stream);
+/* The same for ALL views of a scene in four launches (instead of V x {gp_project_points_f64, gp_visible_lists}):      */
+/* params f64 [V,20] on the DEVICE = row-major world->camera matrix (16) | fx fy cx cy; depth f64 [V,H,W] or NULL.      */
+/* Entries (view, point, pixel row, pixel col) come out view-major, ascending point id inside a view -- the               */
+/* concatenation of the per-view lists: ent_pt / ent_x / ent_y i64 and ent_view i32 must hold V*n entries; view_off i64   */
+/* [V+1] = first entry of each view (+ total); keep u8 [V] = the loader's view-drop rule (data_loader_ablation.py:       */
+/* 254-255, 280-288): n_v != 0, n_v >= min_visible, n_v <= val_keep.  V <= 65535, V*n < 2^31.                            */
+size_t gp_views_visible_lists_workspace_bytes(int64_t n, int32_t nviews);
+int gp_views_visible_lists(const double *coords, int64_t n, const double *params, const double *depth, int32_t nviews,
+                           int32_t width, int32_t height, int32_t cut_bound, double vis_thres, int64_t min_visible,
+                           int64_t val_keep, int64_t *ent_pt, int64_t *ent_x, int64_t *ent_y, int32_t *ent_view,
+                           int64_t *view_off, uint8_t *keep, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row 13 + caller tail (run/validation.py:413-416, util/util.py:160-177).                        */

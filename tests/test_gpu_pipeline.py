@@ -312,3 +312,39 @@ def test_fused_feature_loader_on_disk_formats(tmp_path):
                                    (coords.clone(), feats, labels, feat_3d, mask, inv.clone())])
         assert (b[0][:coords.shape[0], 0] == 0).all() and (b[0][coords.shape[0]:, 0] == 1).all()
         assert int(b[5][N:].min()) == coords.shape[0]
+
+
+def test_all_views_loader_and_lift_equal_the_view_by_view_path(env):
+    """The all-views launches (gp_views_visible_lists, gp_lift_masks_views) reproduce the view-by-view path bit for bit:
+    entry lists incl. the view-drop rule, segments after the in-view fill (through the fused features, which read the
+    point -> (view, segment) lists in view order), on a scene where some views are dropped and one with 70 views
+    (second word of the per-point view mask)."""
+    import dataclasses
+    pl, syn = env["pl"], env["syn"]
+    cases = [(dataclasses.replace(syn.CONFIGS["T"], num_points=9000, num_views=7, min_visible=1), 77),
+             (dataclasses.replace(syn.CONFIGS["T"], num_points=3000, num_views=70), 78),
+             (syn.CONFIGS["T"], 321)]
+    for cfg, seed in cases:
+        scene = pl.upload_scene(syn.make_scene(cfg, seed), "cuda")
+        rigid = pl.scene_rigid_transform(cfg.voxel_size, seed)
+        if cfg.min_visible == 1:                                        # drop the views below the median visible count
+            sizes = sorted(len(v.pt) for v in pl.build_scene_batch(scene, rigid, "cuda", batch_views=False).views)
+            cfg = dataclasses.replace(cfg, min_visible=sizes[len(sizes) // 2])
+            scene.cfg = cfg
+        b_all = pl.build_scene_batch(scene, rigid, "cuda")
+        b_one = pl.build_scene_batch(scene, rigid, "cuda", batch_views=False)
+        assert b_all.ent is not None and b_one.ent is None
+        assert [v.src_view for v in b_all.views] == [v.src_view for v in b_one.views] and len(b_all.views) > 0
+        if cfg.num_views == 7:
+            assert 0 < len(b_all.views) < cfg.num_views                 # the drop rule was exercised
+        for va, vo in zip(b_all.views, b_one.views):
+            assert torch.equal(va.pt, vo.pt) and torch.equal(va.x, vo.x) and torch.equal(va.y, vo.y)
+        assert b_all.extent == b_one.extent
+        vlm = pl.SyntheticVLM(syn.make_vlm_outputs(cfg, cfg.num_views, seed), "cuda")
+        sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=128, embed=128, num_blocks=1, seed=1)
+        st = pl.StudentWeights(sd, "cuda")
+        F_all, t_all, _ = pl.HotPath(st, cfg.mask_shape, K=16, num_iters=1, device="cuda").lift_masks(b_all, vlm)
+        F_one, t_one, _ = pl.HotPath(st, cfg.mask_shape, K=16, num_iters=1, device="cuda", batch_views=False).lift_masks(b_all, vlm)
+        F_pv, _, _ = pl.HotPath(st, cfg.mask_shape, K=16, num_iters=1, device="cuda").lift_masks(b_one, vlm)
+        assert torch.equal(F_all, F_one) and torch.equal(F_all, F_pv) and torch.equal(t_all, t_one)
+        assert F_all.abs().sum() > 0
