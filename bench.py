@@ -46,7 +46,13 @@ def parse():
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
     ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma", "mfma_persist", "tiles", "ell"])
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams: consecutive scenes alternate streams so that one scene's\n                    loader/lift kernels overlap the previous scene's pooling tail")
+    ap.add_argument("--streams", type=int, default=2, help="--schedule alternate: HIP streams that consecutive scenes alternate over "
+                    "(1 = everything on one stream); --schedule split always uses two")
+    ap.add_argument("--schedule", default="split", choices=["split", "alternate"],
+                    help="split (default): refine + classify of scene i on one stream, loader + lift of scene i+1 on a second "
+                         "one beside scene i's convolutions and joined before its pooling; alternate: whole scenes alternate "
+                         "over --streams streams (3 %% more scenes/s, but the pooling launches then share the chip with the "
+                         "other scene's kernels: 0.40 instead of 0.26 ms per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step rate (extra object `training_step`)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample")
@@ -346,9 +352,65 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
-    def step(i, stage=None, stream=None):
+    split = args.schedule == "split" and args.streams >= 2          # --streams 1: everything on one stream
+    if split:                                           # [0] loader + lift of the NEXT scene, [1] refine + classify
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    pending = {}                                        # scene index -> (batch, F, text, scale, lift-done event), lifted ahead
+
+    def _tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                yield from _tensors(o)
+        elif isinstance(obj, dict):
+            for o in obj.values():
+                yield from _tensors(o)
+        elif hasattr(obj, "__dataclass_fields__"):
+            for f in obj.__dataclass_fields__:
+                yield from _tensors(getattr(obj, f))
+
+    def step(i, stage=None, stream=None, prefetch=True):
+        if split and stream is None:
+            return _step_split(i, prefetch)
         with torch.cuda.stream(stream if stream is not None else streams[i % len(streams)]):
             return _step(i, stage)
+
+    def _lift_ahead(i, after=None):
+        """Loader + lift of scene i on streams[0], after the event `after` (recorded on streams[1])."""
+        j = i % max(args.scenes, 1)
+        with torch.cuda.stream(streams[0]):
+            if after is not None:
+                streams[0].wait_event(after)
+            batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
+            F, text, scale = hp.lift_dense(batch, vlms[j]) if cfg.dense_features else hp.lift_masks(batch, vlms[j])
+            done = torch.cuda.Event()
+            done.record(streams[0])
+        for t in _tensors([batch, F, text]):            # the consumer stream: the allocator keeps the blocks until its kernels ran
+            t.record_stream(streams[1])
+        pending[i] = (batch, F, text, scale, done)
+
+    def _step_split(i, prefetch):
+        """Scene i's refine + classify on streams[1]; the NEXT scene's loader + lift is enqueued on streams[0] from inside
+        refine (HotPath.refine's after_student hook), gated on the start of this refine and joined before this scene's kNN /
+        affinity / pooling: the lift's memory-bound kernels run beside the matrix-core-bound convolutions, the pooling
+        kernel has the chip to itself.  One scene = one lift + one refine, as in the other schedules."""
+        if i not in pending:
+            _lift_ahead(i)
+        batch, F, text, scale, done = pending.pop(i)
+        with torch.cuda.stream(streams[1]):
+            streams[1].wait_event(done)
+            started = torch.cuda.Event()
+            started.record(streams[1])
+
+            def hook():
+                if prefetch:
+                    _lift_ahead(i + 1, after=started)
+                    streams[1].wait_event(pending[i + 1][4])
+            feats = hp.refine(batch, F, after_student=hook)
+            hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale},
+                                  batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
+        return batch
 
     def _step(i, stage=None):
         j = i % max(args.scenes, 1)
@@ -393,7 +455,7 @@ def main():
     log("inputs resident; warm-up")
     if args.scenes:
         for i in range(args.warmup):
-            step(i)
+            step(i, prefetch=i + 1 < args.warmup)
     barrier()
     log("timing")
     counts.zero_()
@@ -403,7 +465,7 @@ def main():
     last = None
     n_local = args.steps if args.scenes else 0
     for i in range(n_local):
-        last = step(i)
+        last = step(i, prefetch=i + 1 < n_local)
     join_streams()                                    # every scene's histogram atomics precede the collective
     busy_ev = torch.cuda.Event(enable_timing=False)
     busy_ev.record()
@@ -475,7 +537,7 @@ def main():
             "config": {"workload": workload,
                        "sharding": (f"{shard['policy']} assignment of {shard['scenes_total']} scenes to {world} rank(s), " if val_mode else
                                     f"1 scene per GPU x {world}, ") + "one int64 all-reduce of IoU counts",
-                       "streams": len(streams)},
+                       "streams": len(streams), "schedule": "split" if split else "alternate"},
             "roofline": {"kernel": hp.stats["pool_kernel"] + " (affinity pooling, one application of A)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], Nv),
@@ -501,11 +563,11 @@ def main():
             try:
                 hp.num_iters = 3
                 for i in range(2):
-                    step(i)
+                    step(i, prefetch=i + 1 < 2)
                 barrier()
                 t3 = time.perf_counter()
                 for i in range(4):
-                    step(i)
+                    step(i, prefetch=i + 1 < 4)
                 barrier()
                 d3 = (time.perf_counter() - t3) / 4
                 out["variant_pool_iters_3"] = {"value": round(1.0 / d3, 4), "unit": "scenes/s", "ms_per_step": round(d3 * 1e3, 3), "steps": 4}

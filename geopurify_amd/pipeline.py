@@ -446,8 +446,11 @@ class HotPath:
         return ops.gather_rows(s, D, src), vlm.text_embed, vlm.logit_scale
 
     # ---- rows 8-12 ------------------------------------------------------------------------------
-    def refine(self, batch: SceneBatch, F):
-        """evaluate_scene after the lift (affinity_module.py:1524-1589). F fp32 [N,D] -> [N,D]."""
+    def refine(self, batch: SceneBatch, F, after_student=None):
+        """evaluate_scene after the lift (affinity_module.py:1524-1589). F fp32 [N,D] -> [N,D].
+        after_student: optional callable run on the host once the student's kernels are enqueued and before the kNN /
+        affinity / pooling kernels are -- a scheduler's hook (bench.py enqueues the next scene's lift on a second stream
+        there, so that it runs beside the matrix-core-bound convolutions and never beside the HBM-bound pooling)."""
         dev = self.device
         N, D = F.shape
         st = self.student
@@ -471,6 +474,8 @@ class HotPath:
             grid = ops.grid_build(cs)
         nbr_map = ops.kernel_map_build(grid, cs)
         E = st.forward(X, nbr_map)
+        if after_student is not None:
+            after_student()
         nbr = ops.knn_lattice(grid, cs, perm, self.K)
         w = ops.affinity_softmax(E, nbr, self.sharpen)
         self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12
