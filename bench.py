@@ -499,9 +499,11 @@ def main():
     if rank == 0:
         Nv = hp.stats["Nv"]
         D = cfg.feat_dim
-        pool_ms = pool_timer.mean_ms()
         per_row = 2 * D * 4 + 96 * 8                      # algorithmic bytes per voxel row and application of A
         tot_ms, tot_rows = pool_timer.totals()
+        n_launch = max(len(pool_timer.events), 1)
+        pool_ms = tot_ms / n_launch                       # mean launch duration and mean algorithmic bytes per launch over the
+        pool_bytes_mean = tot_rows / n_launch * per_row   # timed launches (scenes differ in size): achieved = their ratio
         # the same launches with nothing else on the GPU (with --streams 2 the timed region overlaps the pooling
         # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth)
         pool_timer.events, pool_timer.enabled = [], True
@@ -540,12 +542,14 @@ def main():
                        "streams": len(streams), "schedule": "split" if split else "alternate"},
             "roofline": {"kernel": hp.stats["pool_kernel"] + " (affinity pooling, one application of A)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], Nv),
-                         "algorithmic_bytes_per_launch": pool_bytes, "avg_launch_ms": round(pool_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], int(round(tot_rows / n_launch))),
+                         "algorithmic_bytes_per_launch": int(round(pool_bytes_mean)), "avg_launch_ms": round(pool_ms, 5),
+                         "launches": n_launch,
                          "avg_launch_ms_isolated": round(pool_ms_alone, 4),
                          "frac_isolated": round(pool_bytes / (pool_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "achieved/frac: HIP events around every launch INSIDE the timed region (the last scene's Nv); "
-                                 "_isolated: the same launches with nothing else on the GPU"},
+                         "note": "achieved = algorithmic_bytes_per_launch / avg_launch_ms, both means over the launches of the timed "
+                                 "region (HIP events around every launch); _isolated: the last scene's launches (Nv in config.workload) "
+                                 "repeated with nothing else on the GPU"},
             "roofline_conv": conv_roofline(conv_timer),
             "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",

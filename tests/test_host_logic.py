@@ -202,10 +202,15 @@ def test_compat_shims_resolve_reference_module_names():
 
 
 def test_bench_line_contract_on_the_committed_run():
-    """The bench.py JSON line of the committed default run (profiles/r01e_bench_default_run.json, produced on the
-    MI355X box by `python bench.py`) carries every key of the driver's contract with consistent values."""
+    """The bench.py JSON lines of the committed default runs (profiles/r01e_... and r02_bench_default_run.json, produced on
+    the MI355X box by `python bench.py`) carry every key of the driver's contract with consistent values."""
+    for name in ("r01e_bench_default_run.json", "r02_bench_default_run.json"):
+        _check_bench_line(name)
+
+
+def _check_bench_line(name):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01e_bench_default_run.json")))
+    d = json.load(open(os.path.join(root, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -220,6 +225,9 @@ def test_bench_line_contract_on_the_committed_run():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] / c["value"] > 50                                           # BASELINE target: >= 50x the CPU path
+    if name.startswith("r02"):
+        assert c["sample"].startswith("oracle") and "ONE whole" in c["sample"]    # a measured scene, not an extrapolation
+        assert d["config"]["schedule"] in ("split", "alternate") and d["iou_target_points"] > 0
 
 
 def test_bench_helpers_traffic_and_schedule():
