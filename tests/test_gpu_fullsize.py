@@ -239,3 +239,27 @@ def test_conv_gradients_adjoint_identities_full_size(big):
     c = float((W.double() * dW.double()).sum())
     scale = float(Y.double().norm() * G.double().norm())
     assert abs(a - b) < 1e-6 * scale and abs(a - c) < 1e-6 * scale, (a, b, c, scale)
+
+
+def test_all_views_lift_equals_view_by_view_full_size(big):
+    """BASELINE config S geometry (150k points, 648x484 images, Q = 200 masks) with 6 views: the all-views loader and lift
+    give the same entry lists and the same fused features, bit for bit, as the view-by-view launches; every point ends up
+    with a convex combination of unit-norm segment embeddings (or a nearest-point copy of one): 0 < norm <= 1."""
+    import dataclasses
+    pl, syn = big["pl"], big["syn"]
+    cfg = dataclasses.replace(syn.CONFIGS["S"], num_views=6)
+    scene = pl.upload_scene(syn.make_scene(cfg, 99), "cuda")
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, 99)
+    b_all = pl.build_scene_batch(scene, rigid, "cuda")
+    b_one = pl.build_scene_batch(scene, rigid, "cuda", batch_views=False)
+    assert b_all.ent is not None and len(b_all.views) == len(b_one.views) > 0
+    for va, vo in zip(b_all.views, b_one.views):
+        assert va.src_view == vo.src_view and torch.equal(va.pt, vo.pt) and torch.equal(va.x, vo.x) and torch.equal(va.y, vo.y)
+    assert b_all.ent["max_nv"] < 32768                                 # the all-views lift is taken
+    vlm = pl.SyntheticVLM(syn.make_vlm_outputs(cfg, cfg.num_views, 99), "cuda")
+    st = pl.StudentWeights(pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=128, embed=128, num_blocks=1, seed=1), "cuda")
+    F_all, _, _ = pl.HotPath(st, cfg.mask_shape, K=16, num_iters=1, device="cuda").lift_masks(b_all, vlm)
+    F_one, _, _ = pl.HotPath(st, cfg.mask_shape, K=16, num_iters=1, device="cuda", batch_views=False).lift_masks(b_one, vlm)
+    assert torch.equal(F_all, F_one)
+    nrm = F_all.norm(dim=1)
+    assert bool((nrm > 0).all()) and bool((nrm < 1 + 1e-4).all()) and ((nrm - 1).abs() < 1e-4).float().mean() > 0.5
