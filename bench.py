@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
     ap.add_argument("--streams", type=int, default=2, help="--schedule alternate: HIP streams that consecutive scenes alternate over "
                     "(1 = everything on one stream); --schedule split always uses two")
-    ap.add_argument("--schedule", default="split", choices=["split", "alternate"],
-                    help="split (default): refine + classify of scene i on one stream, loader + lift of scene i+1 on a second "
+    ap.add_argument("--schedule", default="auto", choices=["auto", "split", "alternate"],
+                    help="auto (default): split for the mask lift, alternate for the dense-feature lift of config P (a handful of "
+                         "small kernels: 100 vs 92 scenes/s).  split: refine + classify of scene i on one stream, loader + lift of scene i+1 on a second "
                          "one beside scene i's convolutions and joined before its pooling; alternate: whole scenes alternate "
                          "over --streams streams (3 %% more scenes/s, but the pooling launches then share the chip with the "
                          "other scene's kernels: 0.40 instead of 0.26 ms per launch)")
@@ -352,6 +353,8 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
+    if args.schedule == "auto":
+        args.schedule = "alternate" if cfg.dense_features else "split"
     split = args.schedule == "split" and args.streams >= 2          # --streams 1: everything on one stream
     if split:                                           # [0] loader + lift of the NEXT scene, [1] refine + classify
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]

@@ -133,7 +133,7 @@ __global__ void nn1_masked_reduce_kernel(const double *__restrict__ part_d, cons
 // scans the cubic shells of cells around its own cell; after shell r every unscanned point is at least
 // r*h away, so the search stops once best_d <= r*h (with a 1e-9 relative slack for the cell rounding).
 // Winner = lexicographic minimum of (d2 in fp64, original index): identical to the brute-force kernel.
-constexpr int NGMAX = 128;                                 // buffers are sized for this many cells per axis
+constexpr int NGMAX = 128, NG2MAX = 64;                                 // buffers are sized for this many cells per axis
 
 struct NnGrid { double lo[3]; double inv_h; double h; int ng; };
 
@@ -550,7 +550,7 @@ extern "C" size_t gp_nn1_masked_workspace_bytes(int64_t n) {
     // grid path
     cv.take<float>(8); cv.take<int32_t>(n); cv.take<int32_t>((size_t)NGMAX * NGMAX * NGMAX + 1); cv.take<int32_t>((size_t)NGMAX * NGMAX * NGMAX + 1);
     cv.take<int32_t>((size_t)NGMAX * NGMAX * NGMAX + 1); cv.take<float>(3 * n); cv.take<int64_t>(n);
-    cv.take<float>(3 * n); cv.take<int64_t>(n); cv.take<int32_t>(3 * (32 * 32 * 32 + 1));
+    cv.take<float>(3 * n); cv.take<int64_t>(n); cv.take<int32_t>(3 * (NG2MAX * NG2MAX * NG2MAX + 1));
     return cv.off;
 }
 
@@ -576,7 +576,7 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     int64_t *sidx = cv.take<int64_t>(n);
     float *sxyz2 = cv.take<float>(3 * n);
     int64_t *sidx2 = cv.take<int64_t>(n);
-    int32_t *cells2 = cv.take<int32_t>(3 * (32 * 32 * 32 + 1));
+    int32_t *cells2 = cv.take<int32_t>(3 * (NG2MAX * NG2MAX * NG2MAX + 1));
     if (!cv.ok()) { gp_set_error("gp_nn1_masked_f64: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
     hipStream_t st = gp_stream(stream_);
     int blocks = (int)((n + 255) / 256);
@@ -588,7 +588,7 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     mask_compact_kernel<<<blocks, 256, 0, st>>>(xyz, ref_mask, query_mask, rs, qs, n, rxyz, ridx, qidx, counts, nn);
     if (n >= 32768 && !g_gp_knobs[5]) {
         // grid path: bbox of all points; references bucketed by cell on a fine grid (near queries settle within
-        // 2 shells) and on a coarse 32^3 grid (far queries: empty space is crossed in few, large steps)
+        // 2 shells) and on a coarse 48^3 grid (far queries: empty space is crossed in few, large steps)
         nn_bbox_init_kernel<<<1, 64, 0, st>>>(bb);
         nn_bbox_kernel<<<blocks < 64 ? blocks : 64, 256, 0, st>>>(xyz, n, bb);       // 256 threads: the LDS reduce assumes 4 waves
         auto bucket = [&](int ng, int32_t *cnt, int32_t *start, int32_t *cur, float *sx, int64_t *si) -> int {
@@ -603,7 +603,9 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
         };
         int rc = bucket(NG, cell_cnt, cell_start, cursor, sxyz, sidx);
         if (rc) return rc;
-        const int NG2 = 32, nc2 = NG2 * NG2 * NG2 + 1;
+        int NG2 = g_gp_knobs[13] > 0 ? g_gp_knobs[13] : 48;            // cells per axis of the coarse grid (S scene: 32 -> 0.80 ms, 48 -> 0.62, 64 -> 0.62)
+        if (NG2 > NG2MAX) NG2 = NG2MAX;
+        const int nc2 = NG2 * NG2 * NG2 + 1;
         rc = bucket(NG2, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
         if (rc) return rc;
         nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
