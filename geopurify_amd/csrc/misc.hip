@@ -183,6 +183,7 @@ __global__ void nn_cell_count_kernel(const float *__restrict__ rxyz, const int32
     int n_ref = counts[0];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_ref) return;
+    if (NG < 0) NG = counts[2];                                   // the coarse grid: size chosen on the device (nn_pick_coarse_kernel)
     NnGrid g; nn_grid_of(bb, g, NG);
     int c = (nn_cell(g, rxyz[i * 3 + 2], 2) * NG + nn_cell(g, rxyz[i * 3 + 1], 1)) * NG + nn_cell(g, rxyz[i * 3], 0);
     rcell[i] = c;
@@ -238,6 +239,12 @@ nn_grid_query_kernel(const float *__restrict__ xyz, const float *__restrict__ sx
     nn[q] = done ? bi : -2;                                   // -2: not settled within r_max shells (next pass)
 }
 
+// cells per axis of the coarse grid, chosen where the counts are: with most points being references (many views: two thirds
+// of an S scene) the far queries are a few coarse cells from their answer and 48^3 beats 32^3 (0.62 vs 0.80 ms); with few
+// references (one view: config P) they cross a lot of empty space and the finer grid doubles the time
+__global__ void nn_pick_coarse_kernel(int32_t *__restrict__ counts, int64_t n, int forced) {
+    counts[2] = forced > 0 ? forced : (2 * (int64_t)counts[0] >= n ? 48 : 32);
+}
 // far queries (not settled within 2 fine shells): one WAVE per query on the coarse grid; the 64 lanes
 // split the (z,y) cell rows of each shell and scan their points, then a wave reduction of (d2, id)
 __global__ void __launch_bounds__(256)
@@ -247,6 +254,7 @@ nn_grid_query_wave_kernel(const float *__restrict__ xyz, const float *__restrict
     const int n_ref = counts[0], n_q = counts[1];
     const int qi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (qi >= n_q || n_ref == 0) return;
+    if (NG < 0) NG = counts[2];
     const int64_t q = qidx[qi];
     if (nn[q] != -2) return;                                   // wave-uniform
     NnGrid g; nn_grid_of(bb, g, NG);
@@ -588,11 +596,12 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     mask_compact_kernel<<<blocks, 256, 0, st>>>(xyz, ref_mask, query_mask, rs, qs, n, rxyz, ridx, qidx, counts, nn);
     if (n >= 32768 && !g_gp_knobs[5]) {
         // grid path: bbox of all points; references bucketed by cell on a fine grid (near queries settle within
-        // 2 shells) and on a coarse 48^3 grid (far queries: empty space is crossed in few, large steps)
+        // 2 shells) and on a coarse 32^3 or 48^3 grid (far queries: empty space is crossed in few, large steps)
         nn_bbox_init_kernel<<<1, 64, 0, st>>>(bb);
         nn_bbox_kernel<<<blocks < 64 ? blocks : 64, 256, 0, st>>>(xyz, n, bb);       // 256 threads: the LDS reduce assumes 4 waves
         auto bucket = [&](int ng, int32_t *cnt, int32_t *start, int32_t *cur, float *sx, int64_t *si) -> int {
-            int64_t nc = (int64_t)ng * ng * ng;
+            // ng < 0: the device picks the size (<= -ng cells per axis); the arrays are cleared / scanned at the maximum size
+            int64_t nc = (int64_t)ng * ng * (ng < 0 ? -ng : ng);
             GP_CHECK_HIP(hipMemsetAsync(cnt, 0, (nc + 1) * sizeof(int32_t), st));
             GP_CHECK_HIP(hipMemsetAsync(cur, 0, (nc + 1) * sizeof(int32_t), st));
             nn_cell_count_kernel<<<blocks, 256, 0, st>>>(rxyz, counts, bb, cnt, rcell, ng);
@@ -603,13 +612,14 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
         };
         int rc = bucket(NG, cell_cnt, cell_start, cursor, sxyz, sidx);
         if (rc) return rc;
-        int NG2 = g_gp_knobs[13] > 0 ? g_gp_knobs[13] : 48;            // cells per axis of the coarse grid (S scene: 32 -> 0.80 ms, 48 -> 0.62, 64 -> 0.62)
-        if (NG2 > NG2MAX) NG2 = NG2MAX;
-        const int nc2 = NG2 * NG2 * NG2 + 1;
-        rc = bucket(NG2, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
+        // coarse grid: 32 or 48 cells per axis, picked on the device from the reference count (arrays sized for NG2MAX)
+        int forced = g_gp_knobs[13] > NG2MAX ? NG2MAX : g_gp_knobs[13];
+        nn_pick_coarse_kernel<<<1, 1, 0, st>>>(counts, n, forced);
+        const int nc2 = NG2MAX * NG2MAX * NG2MAX + 1;
+        rc = bucket(-NG2MAX, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
         if (rc) return rc;
         nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
-        nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, NG2);
+        nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, -1);
     } else {
         // the cell arrays of the grid path are idle here: partial results of the reference ranges live in them
         double *part_d = reinterpret_cast<double *>(cell_cnt);
