@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int KNN_MAXSEL = 128;   // K+1 <= 128
-constexpr int KNN_MAXTIE = 1024;
+constexpr int KNN_MAXTIE = 256;    // ties at the threshold distance kept in LDS (more: the query retries on the next ring / exhaustively)
 
 template <int R>
 struct KnnCfg {
@@ -34,6 +34,7 @@ knn_ring_kernel(const void *grid, const int32_t *__restrict__ coords, const int3
     __shared__ int s_tieid[WAVES][KNN_MAXTIE];
     __shared__ int s_tierow[WAVES][KNN_MAXTIE];
     __shared__ int s_cnt[WAVES][2];
+    __shared__ int s_cstart[WAVES][(2 * R + 1) * (2 * R + 1) * (2 * R + 1)], s_coff[WAVES][(2 * R + 1) * (2 * R + 1) * (2 * R + 1) + 1];
 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t widx = (int64_t)blockIdx.x * WAVES + wv;
@@ -46,22 +47,52 @@ knn_ring_kernel(const void *grid, const int32_t *__restrict__ coords, const int3
     int *hist = s_hist[wv];
     for (int b = lane; b < HB; b += 64) hist[b] = 0;
     if (lane < 2) s_cnt[wv][lane] = 0;
+    // ---- candidate table: the (2R+1)^3 cells' (first row, rows before) in LDS, fetched with all lanes at once -- one round
+    // of dependent loads (cell index -> record) instead of one per cell -- and a flat candidate numbering 0 .. total-1
+    constexpr int SIDE = 2 * R + 1, NC = SIDE * SIDE * SIDE;
+    int *cstart = s_cstart[wv], *coff = s_coff[wv];
+    int total_c = 0;
+    for (int c0 = 0; c0 < NC; c0 += 64) {
+        const int c = c0 + lane;
+        int start = 0, cnt = 0;
+        if (c < NC) {
+            const int dx = c % SIDE - R, dy = (c / SIDE) % SIDE - R, dz = c / (SIDE * SIDE) - R;
+            const int slot = g.cell_slot(cx0 + dx, cy0 + dy, cz0 + dz);
+            if (slot >= 0) { start = g.recs[slot].start; cnt = g.recs[slot].count; }
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (c < NC) { cstart[c] = start; coff[c] = total_c + incl - cnt; }
+        total_c += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) coff[NC] = total_c;
     gp_wave_sync();
+    // candidate j -> row: the cell whose range holds j (binary search over the NC + 1 offsets in LDS)
+    auto row_of = [&](int j) {
+        int lo = 0, hi = NC - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (coff[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        return cstart[lo] + (j - coff[lo]);
+    };
 
-    // ---- pass 1: histogram of d^2 over the candidate block
-    for (int dz = -R; dz <= R; ++dz)
-        for (int dy = -R; dy <= R; ++dy)
-            for (int dx = -R; dx <= R; ++dx) {
-                int slot = g.cell_slot(cx0 + dx, cy0 + dy, cz0 + dz);
-                if (slot < 0) continue;
-                int start = g.recs[slot].start, cnt = g.recs[slot].count;
-                for (int j = lane; j < cnt; j += 64) {
-                    int64_t r = start + j;
-                    int ex = coords[r * 3] - qx, ey = coords[r * 3 + 1] - qy, ez = coords[r * 3 + 2] - qz;
-                    int d2 = ex * ex + ey * ey + ez * ez;
-                    if (d2 < B) atomicAdd(&hist[d2], 1);
-                }
-            }
+    // ---- pass 1: histogram of d^2 over the candidates (two per lane and round: both coordinate loads in flight together)
+    for (int j0 = 0; j0 < total_c; j0 += 128) {
+        const int ja = j0 + lane, jb = j0 + 64 + lane;
+        const bool va = ja < total_c, vb = jb < total_c;
+        const int64_t ra = va ? row_of(ja) : 0, rb = vb ? row_of(jb) : 0;
+        const int ax = coords[ra * 3], ay = coords[ra * 3 + 1], az = coords[ra * 3 + 2];
+        const int bx = coords[rb * 3], by = coords[rb * 3 + 1], bz = coords[rb * 3 + 2];
+        const int da = (ax - qx) * (ax - qx) + (ay - qy) * (ay - qy) + (az - qz) * (az - qz);
+        const int db = (bx - qx) * (bx - qx) + (by - qy) * (by - qy) + (bz - qz) * (bz - qz);
+        if (va && da < B) atomicAdd(&hist[da], 1);
+        if (vb && db < B) atomicAdd(&hist[db], 1);
+    }
     gp_wave_sync();
 
     // ---- threshold: smallest T with cum(<=T) >= K+1
@@ -105,28 +136,25 @@ knn_ring_kernel(const void *grid, const int32_t *__restrict__ coords, const int3
     }
 
     // ---- pass 2: emit winners below T, collect ties at T
-    for (int dz = -R; dz <= R; ++dz)
-        for (int dy = -R; dy <= R; ++dy)
-            for (int dx = -R; dx <= R; ++dx) {
-                int slot = g.cell_slot(cx0 + dx, cy0 + dy, cz0 + dz);
-                if (slot < 0) continue;
-                int start = g.recs[slot].start, cnt = g.recs[slot].count;
-                for (int j = lane; j < cnt; j += 64) {
-                    int64_t r = start + j;
-                    int ex = coords[r * 3] - qx, ey = coords[r * 3 + 1] - qy, ez = coords[r * 3 + 2] - qz;
-                    int d2 = ex * ex + ey * ey + ez * ez;
-                    int id = ids ? ids[r] : (int)r;
-                    if (d2 < T) {
-                        int p = atomicAdd(&s_cnt[wv][0], 1);
-                        s_selkey[wv][p] = ((unsigned long long)(unsigned)d2 << 32) | (unsigned)id;
-                        s_selrow[wv][p] = (int)r;
-                    } else if (d2 == T) {
-                        int p = atomicAdd(&s_cnt[wv][1], 1);
-                        s_tieid[wv][p] = id;
-                        s_tierow[wv][p] = (int)r;
-                    }
-                }
+    for (int j0 = 0; j0 < total_c; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < total_c) {
+            const int64_t r = row_of(j);
+            int ex = coords[r * 3] - qx, ey = coords[r * 3 + 1] - qy, ez = coords[r * 3 + 2] - qz;
+            int d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < T) {
+                int id = ids ? ids[r] : (int)r;
+                int p = atomicAdd(&s_cnt[wv][0], 1);
+                s_selkey[wv][p] = ((unsigned long long)(unsigned)d2 << 32) | (unsigned)id;
+                s_selrow[wv][p] = (int)r;
+            } else if (d2 == T) {
+                int id = ids ? ids[r] : (int)r;
+                int p = atomicAdd(&s_cnt[wv][1], 1);
+                s_tieid[wv][p] = id;
+                s_tierow[wv][p] = (int)r;
             }
+        }
+    }
     gp_wave_sync();
     const int m_tie = s_cnt[wv][1];
     const int take = need - c_lt;                  // ties to keep: the `take` smallest ids
