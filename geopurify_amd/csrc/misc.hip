@@ -183,7 +183,6 @@ __global__ void nn_cell_count_kernel(const float *__restrict__ rxyz, const int32
     int n_ref = counts[0];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_ref) return;
-    if (NG < 0) NG = counts[2];                                   // the coarse grid: size chosen on the device (nn_pick_coarse_kernel)
     NnGrid g; nn_grid_of(bb, g, NG);
     int c = (nn_cell(g, rxyz[i * 3 + 2], 2) * NG + nn_cell(g, rxyz[i * 3 + 1], 1)) * NG + nn_cell(g, rxyz[i * 3], 0);
     rcell[i] = c;
@@ -239,12 +238,6 @@ nn_grid_query_kernel(const float *__restrict__ xyz, const float *__restrict__ sx
     nn[q] = done ? bi : -2;                                   // -2: not settled within r_max shells (next pass)
 }
 
-// cells per axis of the coarse grid, chosen where the counts are: with most points being references (many views: two thirds
-// of an S scene) the far queries are a few coarse cells from their answer and 48^3 beats 32^3 (0.62 vs 0.80 ms); with few
-// references (one view: config P) they cross a lot of empty space and the finer grid doubles the time
-__global__ void nn_pick_coarse_kernel(int32_t *__restrict__ counts, int64_t n, int forced) {
-    counts[2] = forced > 0 ? forced : (2 * (int64_t)counts[0] >= n ? 48 : 32);
-}
 // far queries (not settled within 2 fine shells): one WAVE per query on the coarse grid; the 64 lanes
 // split the (z,y) cell rows of each shell and scan their points, then a wave reduction of (d2, id)
 __global__ void __launch_bounds__(256)
@@ -254,7 +247,6 @@ nn_grid_query_wave_kernel(const float *__restrict__ xyz, const float *__restrict
     const int n_ref = counts[0], n_q = counts[1];
     const int qi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (qi >= n_q || n_ref == 0) return;
-    if (NG < 0) NG = counts[2];
     const int64_t q = qidx[qi];
     if (nn[q] != -2) return;                                   // wave-uniform
     NnGrid g; nn_grid_of(bb, g, NG);
@@ -262,23 +254,62 @@ nn_grid_query_wave_kernel(const float *__restrict__ xyz, const float *__restrict
     const int cx = nn_cell(g, qx, 0), cy = nn_cell(g, qy, 1), cz = nn_cell(g, qz, 2);
     double best = INFINITY;
     long long bi = INT64_MAX;
+    __shared__ int s_cs[4][64], s_off[4][65];
+    int *cs_ = s_cs[threadIdx.x >> 6], *off_ = s_off[threadIdx.x >> 6];
     for (int r = 0; r < NG; ++r) {
         const int z0 = cz - r, y0 = cy - r, x0 = cx - r, x1 = cx + r, side = 2 * r + 1;
-        for (int p = lane; p < side * side; p += 64) {
-            const int z = z0 + p / side, y = y0 + p % side;
-            if (z < 0 || z >= NG || y < 0 || y >= NG) continue;
-            const bool face = (z == z0 || z == cz + r || y == y0 || y == cy + r);
-            const int xs = face ? 1 : (side > 1 ? side - 1 : 1);
-            for (int x = x0; x <= x1; x += xs) {
-                if (x < 0 || x >= NG) continue;
-                const int c = (z * NG + y) * NG + x;
-                for (int j = cell_start[c]; j < cell_start[c + 1]; ++j) {
-                    double dx = qx - sxyz[j * 3], dy = qy - sxyz[j * 3 + 1], dz = qz - sxyz[j * 3 + 2];
-                    double d2 = (dx * dx + dy * dy) + dz * dz;
-                    long long id = sidx[j];
-                    if (d2 < best || (d2 == best && id < bi)) { best = d2; bi = id; }
+        // the shell's cells, 64 at a time: every lane fetches one cell's point range (one round of loads), the ranges are
+        // numbered flat by a wave prefix sum and the lanes then share the POINTS evenly (the former loop gave a lane a whole
+        // row of cells: tens of dependent loads in sequence).  Same candidate set, same (d2, id) minimum.
+        // shell cells in a fixed order: the two z faces (side^2 each), then per middle slab its ring of 4 side - 4 cells
+        const int face = side * side, ring = 4 * side - 4;
+        const int nshell = r == 0 ? 1 : 2 * face + (side - 2) * ring;
+        for (int t0 = 0; t0 < nshell; t0 += 64) {
+            const int t = t0 + lane;
+            int c_start = 0, c_cnt = 0;
+            if (t < nshell) {
+                int dz, dy, dx;
+                if (t < face) { dz = 0; dy = t / side; dx = t % side; }
+                else if (t < 2 * face) { const int u = t - face; dz = side - 1; dy = u / side; dx = u % side; }
+                else {
+                    const int u = t - 2 * face, v = u % ring;
+                    dz = 1 + u / ring;
+                    if (v < side) { dy = 0; dx = v; }
+                    else if (v < 2 * side) { dy = side - 1; dx = v - side; }
+                    else { const int w = v - 2 * side; dy = 1 + (w >> 1); dx = (w & 1) ? side - 1 : 0; }
+                }
+                const int z = z0 + dz, y = y0 + dy, x = x0 + dx;
+                if (z >= 0 && z < NG && y >= 0 && y < NG && x >= 0 && x < NG) {
+                    const int c = (z * NG + y) * NG + x;
+                    c_start = cell_start[c];
+                    c_cnt = cell_start[c + 1] - c_start;
                 }
             }
+            int incl = c_cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            const int total_p = __shfl(incl, 63, 64);
+            if (total_p == 0) continue;                              // wave-uniform
+            cs_[lane] = c_start;
+            off_[lane] = incl - c_cnt;
+            if (lane == 63) off_[64] = total_p;
+            gp_wave_sync();
+            for (int j = lane; j < total_p; j += 64) {
+                int lo = 0, hi = 63;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (off_[mid] <= j) lo = mid; else hi = mid - 1;
+                }
+                const int pj = cs_[lo] + (j - off_[lo]);
+                double dx = qx - sxyz[pj * 3], dy = qy - sxyz[pj * 3 + 1], dz = qz - sxyz[pj * 3 + 2];
+                double d2 = (dx * dx + dy * dy) + dz * dz;
+                long long id = sidx[pj];
+                if (d2 < best || (d2 == best && id < bi)) { best = d2; bi = id; }
+            }
+            gp_wave_sync();
         }
         // wave-wide lexicographic minimum (all lanes end up with the same value)
 #pragma unroll
@@ -596,12 +627,11 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     mask_compact_kernel<<<blocks, 256, 0, st>>>(xyz, ref_mask, query_mask, rs, qs, n, rxyz, ridx, qidx, counts, nn);
     if (n >= 32768 && !g_gp_knobs[5]) {
         // grid path: bbox of all points; references bucketed by cell on a fine grid (near queries settle within
-        // 2 shells) and on a coarse 32^3 or 48^3 grid (far queries: empty space is crossed in few, large steps)
+        // 2 shells) and on a coarse 32^3 grid (far queries: empty space is crossed in few, large steps)
         nn_bbox_init_kernel<<<1, 64, 0, st>>>(bb);
         nn_bbox_kernel<<<blocks < 64 ? blocks : 64, 256, 0, st>>>(xyz, n, bb);       // 256 threads: the LDS reduce assumes 4 waves
         auto bucket = [&](int ng, int32_t *cnt, int32_t *start, int32_t *cur, float *sx, int64_t *si) -> int {
-            // ng < 0: the device picks the size (<= -ng cells per axis); the arrays are cleared / scanned at the maximum size
-            int64_t nc = (int64_t)ng * ng * (ng < 0 ? -ng : ng);
+            int64_t nc = (int64_t)ng * ng * ng;
             GP_CHECK_HIP(hipMemsetAsync(cnt, 0, (nc + 1) * sizeof(int32_t), st));
             GP_CHECK_HIP(hipMemsetAsync(cur, 0, (nc + 1) * sizeof(int32_t), st));
             nn_cell_count_kernel<<<blocks, 256, 0, st>>>(rxyz, counts, bb, cnt, rcell, ng);
@@ -612,14 +642,13 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
         };
         int rc = bucket(NG, cell_cnt, cell_start, cursor, sxyz, sidx);
         if (rc) return rc;
-        // coarse grid: 32 or 48 cells per axis, picked on the device from the reference count (arrays sized for NG2MAX)
-        int forced = g_gp_knobs[13] > NG2MAX ? NG2MAX : g_gp_knobs[13];
-        nn_pick_coarse_kernel<<<1, 1, 0, st>>>(counts, n, forced);
-        const int nc2 = NG2MAX * NG2MAX * NG2MAX + 1;
-        rc = bucket(-NG2MAX, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
+        int NG2 = g_gp_knobs[13] > 0 ? g_gp_knobs[13] : 32;           // cells per axis of the coarse grid (tuning aid: knob 13)
+        if (NG2 > NG2MAX) NG2 = NG2MAX;
+        const int nc2 = NG2 * NG2 * NG2 + 1;
+        rc = bucket(NG2, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
         if (rc) return rc;
         nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
-        nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, -1);
+        nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, NG2);
     } else {
         // the cell arrays of the grid path are idle here: partial results of the reference ranges live in them
         double *part_d = reinterpret_cast<double *>(cell_cnt);
