@@ -111,27 +111,47 @@ pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int6
     for (int i = tid; i < Up; i += 1024) bu_row[o + i] = i < U ? dense[i] : dense[0];
 }
 
-// scatter the ELL weights into MFMA A-fragment order: wa[(kstep*nw + wave)*64 + lane][8], lane = (k>>3)*16 + m
-__global__ void pm_weights_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int br,
-                                  const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_n,
-                                  const int32_t *__restrict__ bu_row, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
-    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= nv * k) return;
+// scatter the ELL weights into MFMA A-fragment order: wa[(kstep*nw + wave)*64 + lane][8], lane = (k>>3)*16 + m.
+// One workgroup per row block: the block's sorted union (typically ~430 ids) is staged in LDS and every (row, neighbour)
+// element finds its column there by binary search (in global memory the nine dependent loads per element were the cost:
+// 0.17 ms per scene); unions beyond the LDS buffer fall back to the search in global memory.
+constexpr int PW_LDS = 2048;
+__global__ void __launch_bounds__(256)
+pm_weights_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int br,
+                  const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_n,
+                  const int32_t *__restrict__ bu_row, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
+    __shared__ int s_u[PW_LDS];
+    const int64_t b = blockIdx.x;
     const int nw = br / 16;
-    int64_t r = e / k;
-    int64_t b = r / br;
-    int wv = (int)((r % br) / 16), m = (int)(r % 16);
-    int id = nbr[e];
-    const int32_t *u = bu_row + bu_off[b];
-    int lo = 0, hi = bu_n[b] - 1;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (u[mid] < id) lo = mid + 1; else hi = mid; }
-    int64_t ks = bu_off[b] / PM_KS + lo / PM_KS;
-    int kk = lo % PM_KS;
-    int64_t idx = ((ks * nw + wv) * 64 + (kk >> 3) * 16 + m) * 8 + (kk & 7);
-    float v = w[e] * PM_WSCALE;
-    _Float16 h = (_Float16)v;
-    wa_hi[idx] = h;
-    wa_lo[idx] = (_Float16)(v - (float)h);
+    const int64_t off = bu_off[b];
+    const int un = bu_n[b];
+    const int32_t *ug = bu_row + off;
+    const bool in_lds = un <= PW_LDS;
+    if (in_lds)
+        for (int i = threadIdx.x; i < un; i += 256) s_u[i] = ug[i];
+    __syncthreads();
+    const int64_t r0 = b * br;
+    const int rows = (int)((nv - r0) < br ? (nv - r0) : br);
+    const int64_t ks0 = off / PM_KS;
+    for (int t = threadIdx.x; t < rows * k; t += 256) {
+        const int rl = t / k;
+        const int64_t e = (r0 + rl) * k + (t - rl * k);
+        const int id = nbr[e];
+        int lo = 0, hi = un - 1;
+        if (in_lds) {
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (s_u[mid] < id) lo = mid + 1; else hi = mid; }
+        } else {
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (ug[mid] < id) lo = mid + 1; else hi = mid; }
+        }
+        const int wv = rl / 16, m = rl % 16;
+        const int64_t ks = ks0 + lo / PM_KS;
+        const int kk = lo % PM_KS;
+        const int64_t idx = ((ks * nw + wv) * 64 + (kk >> 3) * 16 + m) * 8 + (kk & 7);
+        const float v = w[e] * PM_WSCALE;
+        const _Float16 h = (_Float16)v;
+        wa_hi[idx] = h;
+        wa_lo[idx] = (_Float16)(v - (float)h);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ apply
@@ -961,9 +981,8 @@ extern "C" int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv,
     GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pm_union_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (PM_HS + PM_MAXID) * (int)sizeof(int)));
     pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, nullptr, nullptr, bu_off, bu_row);
-    int64_t ne = nv * k;
-    pm_weights_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(nbr, w, nv, k, block_rows, bu_off, bu_n, bu_row,
-                                                                   static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo));
+    pm_weights_kernel<<<(unsigned)nb, 256, 0, s>>>(nbr, w, nv, k, block_rows, bu_off, bu_n, bu_row, static_cast<_Float16 *>(wa_hi),
+                                                   static_cast<_Float16 *>(wa_lo));
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
