@@ -238,6 +238,10 @@ nn_grid_query_kernel(const float *__restrict__ xyz, const float *__restrict__ sx
     nn[q] = done ? bi : -2;                                   // -2: not settled within r_max shells (next pass)
 }
 
+__global__ void nn_mark_pending_kernel(const int64_t *__restrict__ qidx, const int32_t *__restrict__ counts, int64_t *__restrict__ nn) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi < counts[1] && counts[0] > 0) nn[qidx[qi]] = -2;
+}
 // far queries (not settled within 2 fine shells): one WAVE per query on the coarse grid; the 64 lanes
 // split the (z,y) cell rows of each shell and scan their points, then a wave reduction of (d2, id)
 __global__ void __launch_bounds__(256)
@@ -626,8 +630,8 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, t, qf, qs, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), st));
     mask_compact_kernel<<<blocks, 256, 0, st>>>(xyz, ref_mask, query_mask, rs, qs, n, rxyz, ridx, qidx, counts, nn);
     if (n >= 32768 && !g_gp_knobs[5]) {
-        // grid path: bbox of all points; references bucketed by cell on a fine grid (near queries settle within
-        // 2 shells) and on a coarse 32^3 grid (far queries: empty space is crossed in few, large steps)
+        // grid path: bbox of all points; references bucketed by cell on a coarse 32^3 grid, one wave per query scanning cubic
+        // shells of cells (optionally near queries first on a fine grid, one thread each: knob 7)
         nn_bbox_init_kernel<<<1, 64, 0, st>>>(bb);
         nn_bbox_kernel<<<blocks < 64 ? blocks : 64, 256, 0, st>>>(xyz, n, bb);       // 256 threads: the LDS reduce assumes 4 waves
         auto bucket = [&](int ng, int32_t *cnt, int32_t *start, int32_t *cur, float *sx, int64_t *si) -> int {
@@ -640,14 +644,18 @@ extern "C" int gp_nn1_masked_f64(const float *xyz, int64_t n, const uint8_t *ref
             nn_cell_fill_kernel<<<blocks, 256, 0, st>>>(rxyz, ridx, counts, rcell, start, cur, sx, si);
             return GP_OK;
         };
-        int rc = bucket(NG, cell_cnt, cell_start, cursor, sxyz, sidx);
+        // every query on the coarse grid, one wave each (default); knob 7 = 2 brings back the two-level search (near queries by
+        // one thread each on a fine grid first): 0.39 vs 0.26 ms on the S scene since the wave kernel enumerates points flat
+        const bool wave_only = g_gp_knobs[7] != 2;
+        int rc = wave_only ? GP_OK : bucket(NG, cell_cnt, cell_start, cursor, sxyz, sidx);
         if (rc) return rc;
         int NG2 = g_gp_knobs[13] > 0 ? g_gp_knobs[13] : 32;           // cells per axis of the coarse grid (tuning aid: knob 13)
         if (NG2 > NG2MAX) NG2 = NG2MAX;
         const int nc2 = NG2 * NG2 * NG2 + 1;
         rc = bucket(NG2, cells2, cells2 + nc2, cells2 + 2 * nc2, sxyz2, sidx2);
         if (rc) return rc;
-        nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
+        if (wave_only) nn_mark_pending_kernel<<<blocks, 256, 0, st>>>(qidx, counts, nn);
+        else nn_grid_query_kernel<<<blocks, 256, 0, st>>>(xyz, sxyz, sidx, cell_start, qidx, counts, bb, nn, NG, 2, 0);
         nn_grid_query_wave_kernel<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(xyz, sxyz2, sidx2, cells2 + nc2, qidx, counts, bb, nn, NG2);
     } else {
         // the cell arrays of the grid path are idle here: partial results of the reference ranges live in them

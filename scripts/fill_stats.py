@@ -37,7 +37,8 @@ for _ in range(2):
 from geopurify_amd import _lib
 lib = _lib.load()
 ref = orig(xyz, rm, qm)
-for ng in (128, 96, 80, 64, 48, 40, 32):
+lib.gp_debug_set(7, 2)
+for ng in (128, 64):
     lib.gp_debug_set(6, ng)
     out = orig(xyz, rm, qm); torch.cuda.synchronize()
     ts = []
@@ -45,7 +46,7 @@ for ng in (128, 96, 80, 64, 48, 40, 32):
         t = time.time(); orig(xyz, rm, qm); torch.cuda.synchronize(); ts.append((time.time() - t) * 1e3)
     print(f"NG={ng}: {min(ts):.3f} ms  same={bool(torch.equal(out, ref))}")
 lib.gp_debug_set(6, 0)
-for ng2 in (32, 40, 48, 56, 64):
+for ng2 in (32, 48):
     lib.gp_debug_set(13, ng2)
     out = orig(xyz, rm, qm); torch.cuda.synchronize()
     ts = []
@@ -53,3 +54,12 @@ for ng2 in (32, 40, 48, 56, 64):
         t = time.time(); orig(xyz, rm, qm); torch.cuda.synchronize(); ts.append((time.time() - t) * 1e3)
     print(f"NG2={ng2}: {min(ts):.3f} ms  same={bool(torch.equal(out, ref))}")
 lib.gp_debug_set(13, 0)
+lib.gp_debug_set(7, 0)
+for ng2 in (32, 40, 48, 56, 64):
+    lib.gp_debug_set(13, ng2)
+    out = orig(xyz, rm, qm); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t = time.time(); orig(xyz, rm, qm); torch.cuda.synchronize(); ts.append((time.time() - t) * 1e3)
+    print(f"wave-only (default) NG2={ng2}: {min(ts):.3f} ms  same={bool(torch.equal(out, ref))}")
+lib.gp_debug_set(13, 0); lib.gp_debug_set(7, 0)
