@@ -94,7 +94,7 @@ def conv_roofline(timer):
             "avg_layer_ms": round(ms, 4)}
 
 
-def training_step_rate(batch, dev, sd, steps=3):
+def training_step_rate(batch, dev, sd, steps=6):
     """SURVEY 8f-1 (BASELINE config 5 shape): optimisation steps per second of the student on the bench scene --
     4096 anchors x (1 + 63) samples, teacher features [N, 1088] synthetic, lifted features random unit rows
     (the lift itself is timed by the headline metric), sampler + forward + backward + AdamW inside the timed region."""
@@ -111,7 +111,8 @@ def training_step_rate(batch, dev, sd, steps=3):
         o = tr.scene_step(F_lift, batch.scene_gauss_features, batch.scene_inds_reconstruct, batch.scene_coords_3d, xyz, F_teacher,
                           anchors, num_negatives=63, K=96, optimize=True)
         return o
-    o = one()
+    for _ in range(2):                                 # warm-up: allocator, operator plans
+        o = one()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
