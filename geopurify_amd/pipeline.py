@@ -13,6 +13,8 @@ per-view visible counts (one readback).
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -304,6 +306,9 @@ class HotPath:
                  pool_mode="auto", pool_tile_rows=8, pool_block_rows=64, batch_views=True):
         self.student = student
         self.batch_views = batch_views                 # lift all views of a scene in one set of launches when the inputs allow it
+        # the all-views in-view fill is a brute-force search per view (queries x references of that view); views with more
+        # visible points than this go through the view-by-view path, whose fill uses the grid search
+        self.all_views_max_nv = int(os.environ.get("GP_ALL_VIEWS_MAX_NV", "131072"))
         self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
@@ -362,7 +367,7 @@ class HotPath:
         ent = batch.ent
         pm_all = getattr(vlm, "pred_masks", None)
         all_views = (self.batch_views and batched and scores_all is not None and ent is not None and ent["total"] > 0
-                     and ent["num_views"] <= 128 and ent["max_nv"] < 32768                 # larger views: the grid search of nn1_masked
+                     and ent["num_views"] <= 128 and ent["max_nv"] < self.all_views_max_nv
                      and torch.is_tensor(pm_all) and pm_all.dim() == 4 and pm_all.is_contiguous()
                      and pm_all.shape[0] >= ent["num_views"])
         if all_views:

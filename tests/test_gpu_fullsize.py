@@ -255,7 +255,7 @@ def test_all_views_lift_equals_view_by_view_full_size(big):
     assert b_all.ent is not None and len(b_all.views) == len(b_one.views) > 0
     for va, vo in zip(b_all.views, b_one.views):
         assert va.src_view == vo.src_view and torch.equal(va.pt, vo.pt) and torch.equal(va.x, vo.x) and torch.equal(va.y, vo.y)
-    assert b_all.ent["max_nv"] < 32768                                 # the all-views lift is taken
+    assert b_all.ent["max_nv"] < 131072                                # the all-views lift is taken
     vlm = pl.SyntheticVLM(syn.make_vlm_outputs(cfg, cfg.num_views, 99), "cuda")
     st = pl.StudentWeights(pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=128, embed=128, num_blocks=1, seed=1), "cuda")
     F_all, _, _ = pl.HotPath(st, cfg.mask_shape, K=16, num_iters=1, device="cuda").lift_masks(b_all, vlm)
