@@ -70,20 +70,35 @@ pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int6
     const int64_t r0 = b * br;
     const int rows = (int)((nv - r0) < br ? (nv - r0) : br);
     const int n = rows * k;
-    for (int i = tid; i < PM_HS; i += 1024) keys[i] = -1;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int id = nbr[r0 * k + i];
-        unsigned h = ((unsigned)id * 2654435761u) >> 18;                // 14 bits
-        while (true) {
-            const int old = atomicCAS(&keys[h], -1, id);
-            if (old == -1 || old == id) break;
-            h = (h + 1) & (PM_HS - 1);
+    // a small table first (unions of lattice neighbourhoods are a few hundred ids: 2048 slots at < 25 % load; clearing and
+    // compacting 16384 slots was most of this kernel's time), the full-size one if more than 1024 distinct ids show up or a
+    // probe sequence gets long
+    __shared__ int s_new, s_over;
+    int hs = 2048, shift = 21;
+    for (;;) {
+        for (int i = tid; i < hs; i += 1024) keys[i] = -1;
+        if (tid == 0) { s_base = 0; s_new = 0; s_over = 0; }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const int id = nbr[r0 * k + i];
+            unsigned h = ((unsigned)id * 2654435761u) >> shift;
+            int probes = 0;
+            while (true) {
+                const int old = atomicCAS(&keys[h], -1, id);
+                if (old == -1) { atomicAdd(&s_new, 1); break; }
+                if (old == id) break;
+                h = (h + 1) & (hs - 1);
+                if (++probes > 256 && hs < PM_HS) { s_over = 1; break; }   // (the full table always has a free slot)
+            }
         }
+        __syncthreads();
+        const bool redo = hs < PM_HS && (s_over || s_new > 1024);          // block-uniform
+        __syncthreads();
+        if (!redo) break;
+        hs = PM_HS;
+        shift = 18;
     }
-    __syncthreads();
-    for (int i0 = 0; i0 < PM_HS; i0 += 1024) {                          // compact the occupied slots
+    for (int i0 = 0; i0 < hs; i0 += 1024) {                             // compact the occupied slots
         const int key = keys[i0 + tid];
         const unsigned long long m = __ballot(key >= 0);
         if (lane == 0) s_wcnt[wv] = __popcll(m);

@@ -631,6 +631,28 @@ def test_pool_mfma_tiny_voxel_sets(ops, n_vox, K, BR):
     assert (out.cpu().double() - ref).abs().max() < 1e-5
 
 
+
+def test_pool_mfma_operator_with_non_local_neighbours(ops):
+    """Neighbour lists that are NOT local (random ids): a 64-row block's union has thousands of distinct ids, which takes the
+    operator builder's full-size hash table instead of the small one; the operator still equals the ELL gather."""
+    rng = np.random.default_rng(77)
+    Nv, K, D = 5000, 96, 512
+    nbr = dev(torch.from_numpy(np.stack([rng.choice(Nv, K, replace=False) for _ in range(Nv)])).to(torch.int32))
+    w = torch.softmax(torch.randn(Nv, K), dim=1)
+    op = ops.pool_mfma_build(nbr, dev(w), 64)
+    bn, bo, br = op.bu_n.cpu().numpy(), op.bu_off.cpu().numpy(), op.bu_row.cpu().numpy()
+    assert bn[:-1].min() > 1024 and bn[-1] < 1024                     # full blocks: beyond the small table; the ragged last one: inside
+    for b in (0, len(bn) - 1):
+        u = br[bo[b]:bo[b] + bn[b]]
+        rows = np.arange(b * 64, min(b * 64 + 64, Nv))
+        assert (np.diff(u) > 0).all() and set(u) == set(nbr.cpu().numpy()[rows].reshape(-1))
+    X = torch.randn(Nv, D)
+    out = torch.empty((Nv, D), device="cuda")
+    ops.pool_mfma_apply(ops.split_f16(dev(X), D), op, D, out_f32=out)
+    ref = torch.empty((Nv, D), device="cuda")
+    ops.pool_ell(dev(X), nbr, dev(w), D, ref)
+    assert (out - ref).abs().max() < 1e-5
+
 @pytest.mark.parametrize("n_vox,BR", [(2500, 64), (2531, 64), (2500, 128), (2531, 128)])
 def test_pool_mfma_matches_ell_and_oracle(ops, n_vox, BR):
     """Matrix-core pooling (split f16 operands, fp32 accumulation) against the ELL gather and the oracle
