@@ -386,14 +386,38 @@ __global__ void fuse_top3_kernel(const int64_t *__restrict__ start, const int32_
         for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<float4 *>(out + p * ld_out + c) = make_float4(0, 0, 0, 0);
         return;
     }
-    // consensus class: argmax_c of (sum_v logits_v[c]) / M, first maximum
+    // a point's (view, segment) entries, one per lane (M <= 64: one round of loads; the loops below read them by shuffle
+    // instead of re-loading pv_view / pv_seg in every iteration -- the dependent loads were this kernel's time).  Points seen
+    // by more than 64 views take the plain loops.
+    const bool in_regs = M <= 64;
+    int my_sg = -1, my_v = 0;
+    if (in_regs && lane < M) { my_sg = pv_seg[b + lane]; my_v = pv_view[b + lane]; }
+    // consensus class: argmax_c of (sum_v logits_v[c]) / M, first maximum (sum in ascending entry order)
     float bestv = -INFINITY;
     int bestc = 0x7fffffff;
-    for (int c = lane; c < C; c += 64) {
-        float s = 0.f;
-        for (int64_t j = b; j < e; ++j) { int sg = pv_seg[j]; s += sg >= 0 ? lseg[((int64_t)pv_view[j] * Q + sg) * C + c] : 0.f; }
-        s = s / (float)M;
-        if (s > bestv) { bestv = s; bestc = c; }
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        float sum = 0.f;
+        if (in_regs) {
+            for (int j0 = 0; j0 < M; j0 += 4) {                      // four independent logit loads in flight, added in order
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    const int sg = __shfl(my_sg, j < M ? j : 0, 64), vw = __shfl(my_v, j < M ? j : 0, 64);
+                    t[u] = (j < M && sg >= 0 && c < C) ? lseg[((int64_t)vw * Q + sg) * C + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < M) sum += t[u];
+            }
+        } else if (c < C) {
+            for (int64_t j = b; j < e; ++j) { int sg = pv_seg[j]; sum += sg >= 0 ? lseg[((int64_t)pv_view[j] * Q + sg) * C + c] : 0.f; }
+        }
+        if (c < C) {
+            sum = sum / (float)M;
+            if (sum > bestv) { bestv = sum; bestc = c; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -404,12 +428,23 @@ __global__ void fuse_top3_kernel(const int64_t *__restrict__ start, const int32_
     // top-3 views by agreement score (stable: earlier view wins ties)
     float s0 = -INFINITY, s1 = -INFINITY, s2 = -INFINITY;
     int64_t j0 = -1, j1 = -1, j2 = -1;
-    for (int64_t j = b; j < e; ++j) {
-        int sg = pv_seg[j];
-        float s = sg >= 0 ? lseg[((int64_t)pv_view[j] * Q + sg) * C + bestc] : 0.f;
-        if (s > s0) { s2 = s1; j2 = j1; s1 = s0; j1 = j0; s0 = s; j0 = j; }
-        else if (s > s1) { s2 = s1; j2 = j1; s1 = s; j1 = j; }
-        else if (s > s2) { s2 = s; j2 = j; }
+    if (in_regs) {
+        const float my_s = (lane < M && my_sg >= 0) ? lseg[((int64_t)my_v * Q + my_sg) * C + bestc] : 0.f;   // all scores in one round
+        for (int jj = 0; jj < M; ++jj) {
+            const float sc = __shfl(my_s, jj, 64);
+            const int64_t j = b + jj;
+            if (sc > s0) { s2 = s1; j2 = j1; s1 = s0; j1 = j0; s0 = sc; j0 = j; }
+            else if (sc > s1) { s2 = s1; j2 = j1; s1 = sc; j1 = j; }
+            else if (sc > s2) { s2 = sc; j2 = j; }
+        }
+    } else {
+        for (int64_t j = b; j < e; ++j) {
+            int sg = pv_seg[j];
+            float sc = sg >= 0 ? lseg[((int64_t)pv_view[j] * Q + sg) * C + bestc] : 0.f;
+            if (sc > s0) { s2 = s1; j2 = j1; s1 = s0; j1 = j0; s0 = sc; j0 = j; }
+            else if (sc > s1) { s2 = s1; j2 = j1; s1 = sc; j1 = j; }
+            else if (sc > s2) { s2 = sc; j2 = j; }
+        }
     }
     // softmax over the top-min(M,3) scores (missing slots are -inf -> weight 0)
     float e0 = 1.f, e1 = (j1 >= 0) ? expf(s1 - s0) : 0.f, e2 = (j2 >= 0) ? expf(s2 - s0) : 0.f;
