@@ -25,6 +25,7 @@ SIGNATURES = {
                                         c_double, _P, c_int32, c_int32, c_int32, c_double, _P, _P, _P]),
     "gp_render_depth_f64": (c_int32, [_P, c_int64, POINTER(c_double), c_double, c_double, c_double, c_double,
                                       c_int32, c_int32, c_int32, _P, _P]),
+    "gp_minmax_i32": (c_int32, [_P, c_int64, _P, _P]),
     "gp_morton_order_workspace_bytes": (c_size_t, [c_int64]),
     "gp_morton_order": (c_int32, [_P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gp_grid_bytes": (c_size_t, [c_int64, POINTER(c_int32)]),

@@ -138,6 +138,18 @@ __global__ void kernel_map_kernel(const void *grid, const int32_t *__restrict__ 
 }  // namespace
 
 // ============================================================================================
+// per-axis minimum and maximum of integer coordinates [nv,3] -> mm i32 [6] = (min xyz, max xyz), on the device, no sync
+// (the loader needs the voxel extent; torch's column reduction of an [n,3] array took 0.115 ms)
+extern "C" int gp_minmax_i32(const int32_t *coords, int64_t nv, int32_t *mm, void *stream_) {
+    GP_CHECK_ARG(coords && mm && nv > 0, "gp_minmax_i32: null/empty argument");
+    hipStream_t s = gp_stream(stream_);
+    int blocks = (int)((nv + 255) / 256);
+    init_minmax_kernel<<<1, 64, 0, s>>>(mm);
+    minmax_kernel<<<min(blocks, 64), 256, 0, s>>>(coords, nv, mm);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
 extern "C" size_t gp_morton_order_workspace_bytes(int64_t nv) {
     size_t tmp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,

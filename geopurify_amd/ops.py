@@ -91,6 +91,15 @@ def render_depth(coords, w2c, fx, fy, cx, cy, width, height, cut_bound):
 
 
 # ------------------------------------------------------------------------------------------ order / grid
+def minmax_i32(coords):
+    """Per-axis (min xyz, max xyz) of int32 coordinates [n,3] -> int32 [6] on the device, no sync."""
+    lib = _lib.load()
+    _chk(coords, torch.int32, "coords")
+    mm = torch.empty(6, dtype=torch.int32, device=coords.device)
+    check(lib.gp_minmax_i32(_ptr(coords), coords.shape[0], _ptr(mm), _stream()), "gp_minmax_i32")
+    return mm
+
+
 def morton_order(coords_i32):
     lib = _lib.load()
     _chk(coords_i32, torch.int32, "coords")

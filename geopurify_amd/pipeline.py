@@ -179,6 +179,12 @@ def _view_matrices(cfg, views):
     return out
 
 
+def _voxel_extent(vox):
+    """max voxel coordinate + 1 per axis (the voxelizer shifts the minimum to 0), i64 [3] on the device."""
+    ci = vox["coords_aug"].to(torch.int32)
+    return ops.minmax_i32(ci.contiguous())[3:6].to(torch.int64) + 1
+
+
 def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_views=True):
     """Loader math on the device for one synthetic scene (geopurify_amd.synthetic.Scene):
     scene voxelization (rows 1-2), per-view mapping (row 3), visible lists and the view-drop rule
@@ -200,7 +206,7 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_vi
         params = np.stack([np.concatenate([m.reshape(16), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]]) for m, K in mats]).astype(np.float64)
         ent = ops.views_visible_lists(coords64, torch.from_numpy(params).to(dev), scene.depth_all_dev, W, H, cfg.cut_bound,
                                       cfg.vis_thres, cfg.min_visible, val_keep)
-        tail = torch.cat([ent["view_off"], vox["coords_aug"].amax(0).to(torch.int64) + 1])
+        tail = torch.cat([ent["view_off"], _voxel_extent(vox)])
         host = tail.cpu().tolist()                                        # sync #2 (entries per view + extent)
         views = []
         for i in range(V):
@@ -225,7 +231,7 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_vi
         if ws is None:
             ws = torch.empty(ops._lib.load().gp_visible_lists_workspace_bytes(N), dtype=torch.uint8, device=dev)
         ops.visible_lists(mapping, pt[i], xs[i], ys[i], counts[i:i + 1], ws)
-    counts[V:V + 3] = vox["coords_aug"].amax(0).to(torch.int64) + 1
+    counts[V:V + 3] = _voxel_extent(vox)
     host = counts.cpu().tolist()                                          # sync #2 (n_v per view + extent)
     views = []
     for i in range(V):

@@ -75,6 +75,8 @@ int gp_render_depth_f64(const double *coords, int64_t n, const double *w2c_host,
 /* Internal voxel order + lattice grid (shared by kernel-map build and kNN).                     */
 /* gp_morton_order: perm i32 [nv] = voxel rows sorted by the Morton code of (coords - min);      */
 /* rank i32 [nv] = inverse permutation.  coords i32 [nv,3].                                      */
+/* per-axis minimum / maximum of integer coordinates [nv,3] -> mm i32 [6] = (min x,y,z, max x,y,z); no host sync      */
+int gp_minmax_i32(const int32_t *coords, int64_t nv, int32_t *mm, void *stream);
 size_t gp_morton_order_workspace_bytes(int64_t nv);
 int gp_morton_order(const int32_t *coords, int64_t nv, int32_t *perm, int32_t *rank,
                     void *workspace, size_t workspace_bytes, void *stream);
