@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """CPU oracle, both variants of the consensus fusion: "faithful" keeps the reference's two per-point
 Python loops (affinity_module.py:633-638, 664-670), "vectorised" replaces them by tensor ops (the stronger baseline that
-bench.py reports).  Timed on a 50k-point mask-lift scene (the size of the plumbing config); CPU only."""
+bench.py reports).  Timed on a 50k-point mask-lift scene (the size of the plumbing config); CPU only.
+Lives under tests/ because it runs the oracle, which only tests, smoke() and bench.py's CPU-baseline leg may do."""
 import dataclasses
 import os
 import sys
