@@ -20,7 +20,7 @@ extern "C" int gp_version(void) { return 100; }
 // 8 no weight fragments, 16 no output stores), 5 = force brute-force 1-NN, 6 = 1-NN grid cells per axis,
 // 8 no weight fragments, 16 no output stores; persistent kernel: 32 waves 4-7 issue DMA after the sweep, 64 nt weight loads),
 // 9 = matrix-core pooling: force one workgroup per CU, 10 = persistent pooling: workgroups per XCD label (0 = CUs/8),
-// 11 = persistent pooling: 3 forces the 3-deep X ring, 12 = persistent pooling: 1 forces the static tile lists (no queue),
+// 11 = matrix-core pooling: 4 = column-sliced waves (64 rows x 32 columns each), 12 = persistent pooling: 1 forces the static tile lists (no queue),
 // 7 = 1-NN: 2 brings back the fine-grid pass for near queries, 13 = 1-NN coarse grid cells per axis (<= 64),
 // 14 = classify: 1 forces the kernel without the LDS-staged text matrix,
 // 15 = affinity: 1 forces the one-wave-per-row kernel (no LDS staging of the distinct neighbour rows), 2 = 8 rows per workgroup instead of 16

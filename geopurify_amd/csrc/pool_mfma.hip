@@ -240,6 +240,12 @@ __device__ __forceinline__ void pq_wait_lgkm3(int2 &id, f16x8 (&a)[2], f16x8 (&b
     asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(id), "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]) : [n] "n"(N));
 }
 template <int N>
+__device__ __forceinline__ void pq_wait_lgkm3(int2 &id, f16x8 (&a)[4], f16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%[n])"
+                 : "+v"(id), "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3])
+                 : [n] "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void pq_handover() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
@@ -791,12 +797,21 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
                 pq_rd64(idn, addr_id + J * G::STAGE);
                 pq_rd128<0>(ah[0], addr_w + J * G::STAGE);
                 pq_rd128<NW * 1024>(al[0], addr_w + J * G::STAGE);
-                if constexpr (MT == 2) {
+                if constexpr (MT >= 2) {
                     pq_rd128<1024>(ah[1], addr_w + J * G::STAGE);
                     pq_rd128<NW * 1024 + 1024>(al[1], addr_w + J * G::STAGE);
                 }
-                pq_read_group<G, 0>(f0, a);
-                pq_wait_lgkm3<8>(idn, ah, al);
+                if constexpr (MT == 4) {                   // a wave that owns all 64 rows reads all four weight fragments
+                    pq_rd128<2048>(ah[2], addr_w + J * G::STAGE);
+                    pq_rd128<NW * 1024 + 2048>(al[2], addr_w + J * G::STAGE);
+                    pq_rd128<3072>(ah[3], addr_w + J * G::STAGE);
+                    pq_rd128<NW * 1024 + 3072>(al[3], addr_w + J * G::STAGE);
+                    pq_wait_lgkm3<0>(idn, ah, al);         // 9 + 8 reads would overflow the 4-bit LDS counter
+                    pq_read_group<G, 0>(f0, a);
+                } else {
+                    pq_read_group<G, 0>(f0, a);
+                    pq_wait_lgkm3<8>(idn, ah, al);
+                }
                 if (s + 2 < n) issue(idn, s + 2, (J + 2) % G::NST);
                 if (!(ablate & 1)) pq_sweep<G, MT, 0>(acc, f0, f1, a, ah, al);   // tuning aid: bit 0 skips reads + MFMAs
                 else pq_wait_lgkm<0>(f0);
@@ -1014,6 +1029,8 @@ extern "C" int gp_pool_mfma_apply(const void *x_hi, const void *x_lo, int64_t ld
     GP_CHECK_ARG(!y_hi || (ld_y % 4 == 0 && y_hi != x_hi && y_lo != x_lo), "gp_pool_mfma_apply: y must not alias x");
     GP_CHECK_ARG(!y_f32 || ld_yf % 4 == 0, "gp_pool_mfma_apply: fp32 output rows must be 16-byte aligned");
     hipStream_t s = gp_stream(stream_);
+    if (block_rows == 64 && g_gp_knobs[11] == 4)           // tuning aid: every wave owns all 64 rows x 32 columns (X read once from LDS)
+        return pm_launch<4, 128, 4, 4>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s);
     if (block_rows == 64)
         return pm_launch<4, 128, 1, 1>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s);
     return pm_launch<8, 256, 2, 2>(x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, s);

@@ -63,6 +63,7 @@ for R in (8,):
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
 variants += [("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
+             ("mfma64 column-sliced waves (split out)", ("mfmacs", 64, 0, 0)),
              ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0)),
              ("persist64 (split out)", ("persist", 64, 0, 0)), ("persist64 (fp32 out)", ("persist32", 64, 0, 0)),
              ("persist64 static tile lists (split out)", ("persist", 64, 0, 0, 1)),
@@ -83,6 +84,10 @@ for rnd in range(3):
         elif v[0] == "mfma":
             lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
+        elif v[0] == "mfmacs":
+            lib.gp_debug_set(11, 4)
+            t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
+            lib.gp_debug_set(11, 0)
         elif v[0] == "persist":
             lib.gp_debug_set(4, v[2]); lib.gp_debug_set(11, v[3]); lib.gp_debug_set(12, v[4] if len(v) > 4 else 0)
             t = timeit(lambda: ops.pool_mfma_apply_persistent(xs, mf[v[1]], D, out_split=ysp[v[1]]))
@@ -102,3 +107,13 @@ for rnd in range(3):
 for name, ts in res.items():
     t = min(ts)
     print(f"{name:32s} min {t:7.3f} ms  med {np.median(ts):7.3f} ms  -> {bytes_alg / t / 1e6:7.1f} GB/s algorithmic ({bytes_alg / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+# the column-sliced wave mapping computes the same sums in the same order per element: identical outputs
+ya = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+yb = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+ops.pool_mfma_apply(xs, mf[64], D, out_split=ya)
+lib.gp_debug_set(11, 4)
+ops.pool_mfma_apply(xs, mf[64], D, out_split=yb)
+lib.gp_debug_set(11, 0)
+torch.cuda.synchronize()
+print("column-sliced == default:", bool(torch.equal(ya[0], yb[0]) and torch.equal(ya[1], yb[1])),
+      float((ya[0].float() - yb[0].float()).abs().max()))
