@@ -30,3 +30,12 @@ extern "C" int gp_debug_set(int32_t key, int32_t value) {
     g_gp_knobs[key] = value;
     return GP_OK;
 }
+
+// device buffers for experiments (gp_debug_ptr): 0 = matrix-core pooling: in-kernel time stamps, 10 x uint64 per wave
+// (selects the stamped instantiation while non-null)
+void *g_gp_debug_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+extern "C" int gp_debug_ptr(int32_t key, void *p) {
+    if (key < 0 || key > 3) return GP_EINVAL;
+    g_gp_debug_ptr[key] = p;
+    return GP_OK;
+}

@@ -19,8 +19,21 @@
 #include "gp_common.h"
 
 extern int g_gp_knobs[16];
+extern void *g_gp_debug_ptr[4];
 
 namespace {
+
+// in-kernel time stamps (tuning aid, STAMP instantiations only: gp_debug_ptr(0, buffer) selects them)
+__device__ __forceinline__ uint64_t pq_now() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ uint64_t pq_real() {
+    uint64_t t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -701,15 +714,17 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
     leave();
 }
 
-template <int NW, int NC, int MT, int CGN>
+template <int NW, int NC, int MT, int CGN, bool STAMP = false>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1)
 pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
                  const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
                  const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
                  _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
-                 int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale) {
+                 int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp = nullptr) {
     using G = PqGeo<NW, NC, MT, CGN>;
     static_assert(G::BR / 16 == NW, "one weight fragment group per wave to stage");
+    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
+    if constexpr (STAMP) { st_t0 = pq_now(); st_r0 = pq_real(); }
     constexpr int NQ = PM_D / NC;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -783,6 +798,7 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
         issue(i1, k1, 1);
         pq_handover<G::DMA_PER_STAGE>();
     }
+    if constexpr (STAMP) st_pro = pq_now();
     s16x4 f0[2][2][2], f1[2][2][2];
     f16x8 ah[MT], al[MT];
     int2 idn;
@@ -792,6 +808,8 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
             const int s = s0 + J;
             if (s < n) {
                 uint32_t a[8];
+                uint64_t st_a = 0, st_b = 0;
+                if constexpr (STAMP) st_a = pq_now();
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a[k] = addr[k] + J * G::STAGE;
                 pq_rd64(idn, addr_id + J * G::STAGE);
@@ -813,13 +831,18 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
                     pq_wait_lgkm3<8>(idn, ah, al);
                 }
                 if (s + 2 < n) issue(idn, s + 2, (J + 2) % G::NST);
+                if constexpr (STAMP) if (ablate & 64) { pq_wait_lgkm<0>(f0); st_issue += pq_now() - st_a; }
                 if (!(ablate & 1)) pq_sweep<G, MT, 0>(acc, f0, f1, a, ah, al);   // tuning aid: bit 0 skips reads + MFMAs
                 else pq_wait_lgkm<0>(f0);
+                if constexpr (STAMP) { st_b = pq_now(); st_work += st_b - st_a; }
                 if (s + 2 < n) pq_handover<G::DMA_PER_STAGE>(); else pq_handover<0>();
+                if constexpr (STAMP) st_wait += pq_now() - st_b;
             }
         }
     }
     if (ablate & 4) return;                                // tuning aid: bit 2 skips the epilogue
+    uint64_t st_e0 = 0;
+    if constexpr (STAMP) st_e0 = pq_now();
     // ---- epilogue through LDS (the ring is drained: the last hand-over waited for vmcnt(0))
     // the split planes carry x * s (s = the power of two of gp_pow2_scale, so that the lo halves stay normal f16 numbers);
     // pooling is linear, so the planes written for the next application stay in that domain and only the fp32 output is
@@ -867,6 +890,17 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
             }
         }
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t3 = pq_now(), r3 = pq_real();
+        if (lane == 0 && stamp) {
+            uint64_t *o = stamp + ((int64_t)blockIdx.x * NW + wv) * 10;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_work; o[4] = st_wait; o[5] = st_issue;
+            o[6] = t3 - st_e0; o[7] = t3 - st_t0; o[8] = (uint64_t)n; o[9] = xcc;
+        }
+    }
 }
 
 size_t pm_scan_tmp(int64_t n) {
@@ -895,6 +929,21 @@ int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
         smem = 90 * 1024;
         GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel<NW, NC, MT, CGN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    if (g_gp_debug_ptr[0]) {                              // tuning aid: the instantiation with in-kernel time stamps
+        static bool sattr = false;
+        if (!sattr) {
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel<NW, NC, MT, CGN, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem > G::SMEM ? smem : G::SMEM)));
+            sattr = true;
+        }
+        pool_mfma_kernel<NW, NC, MT, CGN, true><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(
+            static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
+            static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
+            static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale,
+            static_cast<uint64_t *>(g_gp_debug_ptr[0]));
+        GP_CHECK_LAUNCH();
+        return GP_OK;
     }
     pool_mfma_kernel<NW, NC, MT, CGN><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,

@@ -1,0 +1,598 @@
+// Row 12, column-sliced matrix-core pooling ("cs"; the default pooling kernel from round 3 on).
+//
+// What the counters and in-kernel time stamps of pool_mfma.hip said (profiles/r03_pool_stamps_*.log): in the steady
+// state of its loop a CU already takes in 65 GB/s of gathered rows and weight fragments -- the measured ceiling of the
+// L2 -> LDS gather path (MI355X_MICROARCH.md, "Indexed rows: gather into LDS") -- and waits only 190 of 1 560 cycles
+// per step at the hand-over; a quarter of every workgroup's life is prologue and epilogue.  The kernel is bound by the
+// BYTES each CU pulls through L2, so this kernel pulls fewer:
+//   * a workgroup owns 128 Morton-adjacent rows x 256 columns (pool_mfma.hip: 64 x 128): the union of a 128-row block
+//     has 4.75 rows per output row instead of 6.66, and the weight fragments are read by 2 column halves, not 4
+//     quarters:  X 9.7 KB + weights 2.4 KB per output row and application instead of 13.6 + 6.8 KB;
+//   * every wave owns ALL 128 rows x 32 columns (column-sliced), so the eight 16-row groups see the same staged union
+//     rows and a (group, step) weight fragment that is entirely zero can be skipped by the whole workgroup with no
+//     imbalance: the builder orders a block's union rows by (first group, last group) that use them, which leaves 60 %
+//     of the 16 x 32 fragments non-empty (sorted by id: 79 %), and stores one bit per (step, group);
+//     empty fragments are neither fetched (their LDS-DMA reads one hot line) nor read from LDS nor multiplied;
+//   * row ids and fragment masks come through the scalar cache (s_load one step ahead) instead of an LDS-DMA + LDS
+//     read-back per step.
+// Numerics are those of pool_mfma.hip: pre-split f16 (hi, lo) operands, hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation, the union swept in the order the builder fixed (bitwise reproducible).
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include "gp_common.h"
+
+extern int g_gp_knobs[16];
+extern void *g_gp_debug_ptr[4];
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((vector_size(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CS_KS = 32;              // union rows per step (MFMA K)
+constexpr int CS_D = 512;              // feature columns
+constexpr int CS_BR = 128;             // rows per block
+constexpr int CS_NG = CS_BR / 16;      // 16-row groups per block = weight fragments per step
+constexpr int CS_NC = 256;             // columns per workgroup
+constexpr int CS_NW = 8;               // waves per workgroup
+constexpr int CS_WC = CS_NC / CS_NW;   // columns per wave
+constexpr int CS_MAXID = 16384;        // sort buffers of the builder (a power of two)
+constexpr int CS_MAXNK = 12288;        // block_rows x K ids per block (K <= 96): with the position table the builder's LDS is full
+constexpr int CS_HS = 16384;           // hash slots of the builder
+constexpr float CS_WSCALE = 1024.f;    // weights (<= 1) are stored x 2^10 so that their f16 lo parts stay normal
+
+// LDS stage: X hi [32 rows][512 B] | X lo | weights hi [8 groups][1 KiB] | weights lo
+constexpr int CS_RB = CS_NC * 2;                   // bytes per staged row and plane
+constexpr int CS_PLANE = CS_KS * CS_RB;            // 16 KiB
+constexpr int CS_OFF_W = 2 * CS_PLANE;             // 32 KiB
+constexpr int CS_WPL = CS_NG * 1024;               // one weight plane: 8 KiB
+constexpr int CS_STAGE = CS_OFF_W + 2 * CS_WPL;    // 48 KiB
+constexpr int CS_NST = 3;
+constexpr int CS_DMA = 6;                          // LDS-DMA instructions per wave and stage: 4 x rows, 2 x weights
+constexpr int CS_EP = CS_WC + 4;                   // epilogue staging pitch (floats)
+constexpr size_t CS_SMEM = (size_t)CS_NST * CS_STAGE;
+static_assert((size_t)CS_NW * CS_BR * CS_EP * sizeof(float) <= CS_SMEM, "epilogue staging must fit in the ring");
+
+__device__ __forceinline__ uint64_t cs_now() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ uint64_t cs_real() {
+    uint64_t t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ void cs_glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void cs_tr(s16x4 &d, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void cs_rd128(f16x8 &d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// every LDS read issued so far has landed; ties the fragment registers to the wait so that no use moves above it
+__device__ __forceinline__ void cs_wait_b(s16x4 (&f)[2][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]),
+                   "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+}
+__device__ __forceinline__ void cs_wait_a(f16x8 (&h)[4], f16x8 (&l)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
+}
+template <int N>
+__device__ __forceinline__ void cs_handover() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ f16x8 cs_cat(s16x4 a, s16x4 b) {
+    typedef short s16x8 __attribute__((vector_size(16)));
+    s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, v);
+}
+
+// ------------------------------------------------------------------------------------------------ builder
+__device__ __forceinline__ void cs_bitonic(int *a, int n_pow2, int tid, int nthreads) {
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pow2; i += nthreads) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    int x = a[i], y = a[ixj];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// distinct neighbour ids of the rows of block b -> dense[0 .. U) (unsorted), through an LDS hash table: a small table
+// first (unions of lattice neighbourhoods are a few hundred ids), the full-size one if it overflows
+__device__ int cs_union(const int32_t *__restrict__ nbr, int n, int *keys, int *dense) {
+    __shared__ int s_wcnt[16];
+    __shared__ int s_base, s_new, s_over;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int hs = 2048, shift = 21;
+    for (;;) {
+        for (int i = tid; i < hs; i += 1024) keys[i] = -1;
+        if (tid == 0) { s_base = 0; s_new = 0; s_over = 0; }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const int id = nbr[i];                                       // (nbr points at the block's first entry)
+            unsigned h = ((unsigned)id * 2654435761u) >> shift;
+            int probes = 0;
+            while (true) {
+                const int old = atomicCAS(&keys[h], -1, id);
+                if (old == -1) { atomicAdd(&s_new, 1); break; }
+                if (old == id) break;
+                h = (h + 1) & (hs - 1);
+                if (++probes > 256 && hs < CS_HS) { s_over = 1; break; }   // (the full table always has a free slot)
+            }
+        }
+        __syncthreads();
+        const bool redo = hs < CS_HS && (s_over || s_new > 1024);          // block-uniform
+        __syncthreads();
+        if (!redo) break;
+        hs = CS_HS;
+        shift = 18;
+    }
+    for (int i0 = 0; i0 < hs; i0 += 1024) {                                // compact the occupied slots
+        const int key = keys[i0 + tid];
+        const unsigned long long m = __ballot(key >= 0);
+        if (lane == 0) s_wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wv; ++w) before += s_wcnt[w];
+        if (key >= 0) dense[before + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += s_wcnt[w]; s_base += tot; }
+        __syncthreads();
+    }
+    return s_base;
+}
+
+// pass 1: padded union size of every block (a multiple of 32 union rows, at least one step)
+__global__ void __launch_bounds__(1024)
+cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int64_t *__restrict__ padded_cnt, int32_t *__restrict__ bu_n) {
+    extern __shared__ int s_mem[];
+    int *keys = s_mem, *dense = s_mem + CS_HS;
+    const int64_t b = blockIdx.x, r0 = b * CS_BR;
+    const int rows = (int)((nv - r0) < CS_BR ? (nv - r0) : CS_BR);
+    const int U = cs_union(nbr + r0 * k, rows * k, keys, dense);
+    if (threadIdx.x == 0) { padded_cnt[b] = (int64_t)((U + CS_KS - 1) / CS_KS) * CS_KS; bu_n[b] = U; }
+}
+
+// pass 2: the block's union rows in (first group, last group, group set, id) order, one bit per (step, group) that says
+// whether the 16 x 32 weight fragment holds a non-zero, and the ELL weights scattered into MFMA fragment order:
+// wa[(step * 8 + group) * 64 + lane][8], lane = (k >> 3) * 16 + m  (k = union row within the step, m = row within the group).
+__global__ void __launch_bounds__(1024)
+cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, const int64_t *__restrict__ bu_off,
+               int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
+    extern __shared__ int s_mem[];                           // A[16384] | B[16384] | npos u16 [br*k]
+    int *A = s_mem, *B = s_mem + CS_HS;
+    unsigned short *npos = reinterpret_cast<unsigned short *>(s_mem + CS_HS + CS_MAXID);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x, r0 = b * CS_BR;
+    const int rows = (int)((nv - r0) < CS_BR ? (nv - r0) : CS_BR);
+    const int n = rows * k;
+    const int32_t *nb = nbr + r0 * k;
+    const int U = cs_union(nb, n, A, B);
+    int np2 = 1;
+    while (np2 < U) np2 <<= 1;
+    for (int i = U + tid; i < np2; i += 1024) B[i] = INT32_MAX;
+    __syncthreads();
+    cs_bitonic(B, np2, tid, 1024);                            // B[0 .. U): the ids, ascending
+    // group set of every union row
+    for (int i = tid; i < U; i += 1024) A[i] = 0;
+    __syncthreads();
+    for (int t = tid; t < n; t += 1024) {
+        const int id = nb[t];
+        int lo = 0, hi = U - 1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (B[mid] < id) lo = mid + 1; else hi = mid; }
+        atomicOr(&A[lo], 1 << ((t / k) >> 4));
+    }
+    __syncthreads();
+    // order key: first group | last group | group set | index among the sorted ids (deterministic)
+    for (int i = tid; i < np2; i += 1024) {
+        int key = INT32_MAX;
+        if (i < U) {
+            const int m = A[i];
+            const int first = __ffs(m) - 1, last = 31 - __clz(m);
+            key = (first << 28) | (last << 25) | (m << 14) | i;      // 3 + 3 + 8 + 14 bits (bit 31 stays clear)
+        }
+        A[i] = key;
+    }
+    __syncthreads();
+    cs_bitonic(A, np2, tid, 1024);
+    const int64_t o = bu_off[b];
+    const int Up = (int)(bu_off[b + 1] - o);
+    for (int p = tid; p < Up; p += 1024) {
+        const int src = p < U ? (A[p] & 0x3FFF) : (A[0] & 0x3FFF);   // padding repeats the first row (its weights stay zero)
+        bu_row[o + p] = B[src];
+        if (p < U) npos[src] = (unsigned short)p;
+    }
+    const int64_t ks0 = o / CS_KS;
+    __shared__ unsigned s_mask[CS_MAXNK / CS_KS];
+    for (int t = tid; t < Up / CS_KS; t += 1024) {
+        unsigned m = 0;
+        for (int p = t * CS_KS; p < (t + 1) * CS_KS && p < U; ++p) m |= (unsigned)(A[p] >> 14) & 0xFFu;
+        bu_mask[ks0 + t] = m;
+        s_mask[t] = m;
+    }
+    __syncthreads();
+    // zero the block's non-empty fragments (the only ones the apply kernel fetches), then scatter into them: the
+    // barrier orders this workgroup's zero stores before its element stores (both through the same L2)
+    for (int i = tid; i < (Up / CS_KS) * CS_NG * 64; i += 1024) {
+        const int f = i >> 6;
+        if ((s_mask[f >> 3] >> (f & 7)) & 1u) {
+            const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<f16x8 *>(wa_hi + (ks0 * CS_NG * 64 + i) * 8) = z;
+            *reinterpret_cast<f16x8 *>(wa_lo + (ks0 * CS_NG * 64 + i) * 8) = z;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += 1024) {
+        const int rl = t / k;
+        const int id = nb[t];
+        int lo = 0, hi = U - 1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (B[mid] < id) lo = mid + 1; else hi = mid; }
+        const int p = npos[lo];
+        const int64_t ks = ks0 + p / CS_KS;
+        const int kk = p % CS_KS;
+        const int64_t idx = ((ks * CS_NG + (rl >> 4)) * 64 + (kk >> 3) * 16 + (rl & 15)) * 8 + (kk & 7);
+        const float v = w[r0 * k + t] * CS_WSCALE;
+        const _Float16 h = (_Float16)v;
+        wa_hi[idx] = h;
+        wa_lo[idx] = (_Float16)(v - (float)h);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ apply
+// One 512-thread workgroup = 128 rows x 256 columns (grid = row blocks x 2 column halves, the halves of a row block
+// adjacent on one XCD); wave wv owns columns 32 wv .. 32 wv + 31 of the half for all 128 rows (16 accumulator tiles).
+// A 3-deep ring of 48-KiB stages is filled by LDS-DMA two steps ahead (96 KiB in flight per CU); wave wv stages union
+// rows 4 wv .. 4 wv + 3 of a step (two 1-KiB instructions per plane, two rows each) and the weight fragment of group wv.
+// The image is XOR-swizzled through the DMA source addresses exactly as in pool_mfma.hip (physical 16-byte chunk c of
+// row r holds logical chunk c ^ 2 t(r), t(r) = (r & 3) | ((r >> 3) & 1) << 2), which makes the transposed fragment
+// reads (ds_read_b64_tr_b16) conflict-free.  Synchronisation is hand-counted: LDS reads are inline asm with their own
+// lgkmcnt waits (a compiler-visible LDS read would wait for every outstanding LDS-DMA), the hand-over is
+// `s_waitcnt vmcnt(6); s_barrier` (6 = the DMA instructions of the younger stage; vector memory operations complete in
+// issue order and the loop issues no other).  Row ids and fragment masks are scalar loads issued one step ahead.
+template <bool STAMP>
+__global__ void __launch_bounds__(512, 2)
+cs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
+               const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
+               const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
+               _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
+               int64_t per_xcd, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
+    if constexpr (STAMP) { st_t0 = cs_now(); st_r0 = cs_real(); }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);    // XCD-contiguous order
+    const int64_t b = lb >> 1;
+    const int col0 = (int)(lb & 1) * CS_NC;
+    if (b >= nblocks) return;
+    const int64_t ub0 = bu_off[b];
+    const int n = (int)((bu_off[b + 1] - ub0) / CS_KS);                            // steps (>= 1)
+    const int64_t ks0 = ub0 / CS_KS;
+
+    // ---- DMA roles
+    const int du = lane >> 5, dc = lane & 31;
+    const int swz = (wv >> 1) & 1;
+    const int t0 = du | (swz << 2), t1 = (2 + du) | (swz << 2);                     // t(row) of rows 4 wv + du, 4 wv + 2 + du
+    const int64_t dsrc0 = col0 + ((dc ^ (2 * t0)) * 8);
+    const int64_t dsrc1 = col0 + ((dc ^ (2 * t1)) * 8);
+    const int32_t *idg = bu_row + ub0 + 4 * wv;                                    // this wave's row ids, step 0
+    const uint32_t *mkg = bu_mask + ks0;
+    const _Float16 *wah = wa_hi + (ks0 * CS_NG + wv) * 512;
+    const _Float16 *wal = wa_lo + (ks0 * CS_NG + wv) * 512;
+    auto issue = [&](i32x4 id, unsigned mk, int k, int slot) {
+        unsigned char *dst = smem_raw + slot * CS_STAGE;
+        const int ida = du ? id.y : id.x, idb = du ? id.w : id.z;
+        const int64_t s0 = (int64_t)ida * ld_x + dsrc0, s1 = (int64_t)idb * ld_x + dsrc1;
+        if (!(ablate & 2)) {                               // tuning aid: bit 1 skips the row gather
+            cs_glds16(x_hi + s0, dst + (4 * wv) * CS_RB);
+            cs_glds16(x_lo + s0, dst + CS_PLANE + (4 * wv) * CS_RB);
+            cs_glds16(x_hi + s1, dst + (4 * wv) * CS_RB + 1024);
+            cs_glds16(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
+        }
+        if (!(ablate & 8)) {                               // tuning aid: bit 3 skips the weight fragments
+            // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line) to keep the DMA count fixed
+            const int lo = ((mk >> wv) & 1u) ? lane * 8 : 0;
+            cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
+            cs_glds16(wal + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + CS_WPL + wv * 1024);
+        }
+    };
+    auto load_ids = [&](int k) { return *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS); };
+
+    // ---- read roles
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+    uint32_t addr[2];
+    {
+        const uint32_t rowb = (uint32_t)(8 * g + q) * CS_RB + (uint32_t)(wv * CS_WC * 2) + (uint32_t)(p * 8);
+        const uint32_t t = (uint32_t)(q | ((g & 1) << 2));
+        addr[0] = lds0 + (rowb ^ (t << 5));
+        addr[1] = lds0 + ((rowb + 32u) ^ (t << 5));
+    }
+    const uint32_t addr_w = lds0 + CS_OFF_W + lane * 16;
+
+    f32x4 acc[CS_NG * 2];
+#pragma unroll
+    for (int i = 0; i < CS_NG * 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: stages 0 and 1 in flight (a one-step block stages its only step twice)
+    unsigned mA, mB, mC;
+    i32x4 idv;
+    {
+        const int k1 = n > 1 ? 1 : 0, k2 = n > 2 ? 2 : n - 1;
+        const i32x4 i0 = load_ids(0), i1 = load_ids(k1);
+        mA = mkg[0];
+        mB = mkg[k1];
+        issue(i0, mA, 0, 0);
+        issue(i1, mB, k1, 1);
+        idv = load_ids(k2);
+        mC = mkg[k2];
+        asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mC));   // (waited for here, not inside the loop)
+        cs_handover<CS_DMA>();
+    }
+    if constexpr (STAMP) st_pro = cs_now();
+    // Software pipeline (the fragment reads of all eight waves leave the barrier together and take ~500 cycles to come back;
+    // an MFMA batch in front of each wait hides them):
+    //   step s:  reads {staged rows, weight fragments of groups 0-3} of stage s      | waves 0-3: DMA of stage s + 2
+    //            MFMA batch "groups 4-7" of stage s - 1 (fragments read in step s - 1, rows kept in fp)
+    //            wait; reads {weight fragments of groups 4-7} of stage s; next step's scalars (s_load)
+    //            MFMA batch "groups 0-3" of stage s                                  | waves 4-7: DMA of stage s + 2
+    //            wait (every LDS read of stage s has landed in registers); hand-over
+    // Waves 0-3 issue their DMA first and waves 4-7 last, so that the two waves of a SIMD alternate between DMA issue
+    // (which stalls on the memory pipeline's back-pressure) and matrix work.
+    s16x4 fb[2][2][2];
+    f16x8 ah0[4], al0[4], ah1[4], al1[4], bhp[2], blp[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ah0[i] = al0[i] = ah1[i] = al1[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { bhp[u] = blp[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    unsigned mP = 0;                                         // fragment mask of the previous step (its groups 4-7 are pending)
+    auto mfma_hi = [&](unsigned m, const f16x8 (&bh)[2], const f16x8 (&bl)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            if (__builtin_expect((m >> (4 + mt)) & 1u, 1)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bl[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1[mt], bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+            }
+    };
+    const bool late = !(ablate & 32) && wv >= 4;            // tuning aid: bit 5 makes every wave issue first
+    const bool do_reads = !(ablate & 1);                     // tuning aid: bit 0 skips reads + MFMAs
+    for (int s0 = 0; s0 < n; s0 += CS_NST) {
+#pragma unroll
+        for (int J = 0; J < CS_NST; ++J) {
+            const int s = s0 + J;
+            if (s < n) {
+                uint64_t st_a = 0, st_b = 0;
+                if constexpr (STAMP) st_a = cs_now();
+                const uint32_t a0 = addr[0] + J * CS_STAGE, a1 = addr[1] + J * CS_STAGE, aw = addr_w + J * CS_STAGE;
+                const unsigned m = mA;
+                if (do_reads) {
+                    // staged rows: fb[col block][plane][rows 8g+q | 8g+q+4]; weight fragments of groups 0-3
+                    cs_tr<0>(fb[0][0][0], a0);
+                    cs_tr<4 * CS_RB>(fb[0][0][1], a0);
+                    cs_tr<CS_PLANE>(fb[0][1][0], a0);
+                    cs_tr<CS_PLANE + 4 * CS_RB>(fb[0][1][1], a0);
+                    cs_tr<0>(fb[1][0][0], a1);
+                    cs_tr<4 * CS_RB>(fb[1][0][1], a1);
+                    cs_tr<CS_PLANE>(fb[1][1][0], a1);
+                    cs_tr<CS_PLANE + 4 * CS_RB>(fb[1][1][1], a1);
+                    if (m & 1u) { cs_rd128<0 * 1024>(ah0[0], aw); cs_rd128<CS_WPL + 0 * 1024>(al0[0], aw); }
+                    if (m & 2u) { cs_rd128<1 * 1024>(ah0[1], aw); cs_rd128<CS_WPL + 1 * 1024>(al0[1], aw); }
+                    if (m & 4u) { cs_rd128<2 * 1024>(ah0[2], aw); cs_rd128<CS_WPL + 2 * 1024>(al0[2], aw); }
+                    if (m & 8u) { cs_rd128<3 * 1024>(ah0[3], aw); cs_rd128<CS_WPL + 3 * 1024>(al0[3], aw); }
+                }
+                if (!late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
+                if constexpr (STAMP) if (ablate & 64) st_issue += cs_now() - st_a;
+                if (do_reads) {
+                    mfma_hi(mP, bhp, blp);                  // groups 4-7 of the previous step
+                    cs_wait_b(fb);
+                    cs_wait_a(ah0, al0);
+                }
+                // scalars of the stage issued in the next step (clamped: never past the block's padded union); they are
+                // waited for right before the barrier, a whole MFMA batch later
+                const int kn = s + 3 < n ? s + 3 : n - 1;
+                const i32x4 idn = load_ids(kn);
+                const unsigned mN = mkg[kn];
+                if (do_reads) {
+                    if (m & 16u) { cs_rd128<4 * 1024>(ah1[0], aw); cs_rd128<CS_WPL + 4 * 1024>(al1[0], aw); }
+                    if (m & 32u) { cs_rd128<5 * 1024>(ah1[1], aw); cs_rd128<CS_WPL + 5 * 1024>(al1[1], aw); }
+                    if (m & 64u) { cs_rd128<6 * 1024>(ah1[2], aw); cs_rd128<CS_WPL + 6 * 1024>(al1[2], aw); }
+                    if (m & 128u) { cs_rd128<7 * 1024>(ah1[3], aw); cs_rd128<CS_WPL + 7 * 1024>(al1[3], aw); }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { bhp[u] = cs_cat(fb[u][0][0], fb[u][0][1]); blp[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        if (__builtin_expect((m >> mt) & 1u, 1)) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], blp[u], acc[mt * 2 + u], 0, 0, 0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
+                        }
+                }
+                if (late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
+                // every LDS read of this stage is in registers before the barrier lets its slot be refilled, and the scalar
+                // loads are waited for HERE, so that no compiler-placed lgkmcnt(0) sits inside the next step
+                cs_wait_a(ah1, al1);
+                asm volatile("" ::"s"(idn.x), "s"(idn.y), "s"(idn.z), "s"(idn.w), "s"(mN));
+                if constexpr (STAMP) { st_b = cs_now(); st_work += st_b - st_a; }
+                if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
+                if constexpr (STAMP) st_wait += cs_now() - st_b;
+                mP = m; mA = mB; mB = mC; mC = mN; idv = idn;
+            }
+        }
+    }
+    if (do_reads) mfma_hi(mP, bhp, blp);                     // groups 4-7 of the last step
+    if (ablate & 4) return;                                // tuning aid: bit 2 skips the epilogue
+    uint64_t st_e0 = 0;
+    if constexpr (STAMP) st_e0 = cs_now();
+    // ---- epilogue through LDS (the ring is drained: the last hand-over waited for vmcnt(0)).  The split planes carry
+    // x * s (s = the power of two of gp_pow2_scale); pooling is linear, so the planes written for the next application stay
+    // in that domain and only the fp32 output is multiplied by out_scale = 1/s.
+    const float inv = 1.f / CS_WSCALE;
+    float *stg = reinterpret_cast<float *>(smem_raw) + wv * (CS_BR * CS_EP);
+    const int fl = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < CS_NG; ++mt)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(mt * 16 + fq * 4 + r) * CS_EP + cb * 16 + fl] = acc[mt * 2 + cb][r] * inv;
+    gp_wave_sync();
+    const int64_t row0 = b * CS_BR;
+    const int colw = col0 + wv * CS_WC;
+    // lane -> 8 consecutive columns of row it * 16 + (lane >> 2): every store instruction writes 16 rows x 64 bytes
+    const int er = lane >> 2, ec = (lane & 3) * 8;
+    const float so = (y_f32 && out_scale) ? out_scale[0] : 1.f;
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {                        // two halves of 64 rows: bounds the live registers
+        float4 v[4][2];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float *sp = stg + (h8 * 64 + it * 16 + er) * CS_EP + ec;
+            v[it][0] = *reinterpret_cast<const float4 *>(sp);
+            v[it][1] = *reinterpret_cast<const float4 *>(sp + 4);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int64_t grow = row0 + h8 * 64 + it * 16 + er;
+            if (grow < nv && !(ablate & 16)) {             // tuning aid: bit 4 skips the output stores
+                const float xv[8] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w, v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
+                if (y_hi) {
+                    f16x8 h, l;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { h[i] = (_Float16)xv[i]; l[i] = (_Float16)(xv[i] - (float)h[i]); }
+                    *reinterpret_cast<f16x8 *>(y_hi + grow * ld_y + colw + ec) = h;
+                    *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + colw + ec) = l;
+                }
+                if (y_f32) {
+                    float *yp = y_f32 + grow * ld_yf + colw + ec;
+                    *reinterpret_cast<float4 *>(yp) = make_float4(xv[0] * so, xv[1] * so, xv[2] * so, xv[3] * so);
+                    *reinterpret_cast<float4 *>(yp + 4) = make_float4(xv[4] * so, xv[5] * so, xv[6] * so, xv[7] * so);
+                }
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t3 = cs_now(), r3 = cs_real();
+        if (lane == 0 && stamp) {
+            uint64_t *o = stamp + ((int64_t)blockIdx.x * CS_NW + wv) * 10;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_work; o[4] = st_wait; o[5] = st_issue;
+            o[6] = t3 - st_e0; o[7] = t3 - st_t0; o[8] = (uint64_t)n; o[9] = xcc;
+        }
+    }
+}
+
+size_t cs_scan_tmp(int64_t n) {
+    size_t t = 0;
+    (void)rocprim::exclusive_scan(nullptr, t, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0);
+    return t;
+}
+int cs_np2(int64_t n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv) {
+    if (nv <= 0) return 0;
+    int64_t nb = (nv + CS_BR - 1) / CS_BR;
+    GpCarver cv(nullptr, 0);
+    cv.take<int64_t>(nb + 1);
+    cv.take<char>(cs_scan_tmp(nb + 1));
+    return cv.off;
+}
+
+// pass 1: bu_off i64 [nblocks+1] (padded union rows before each 128-row block; multiples of 32), bu_n i32 [nblocks]
+extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int64_t *bu_off, int32_t *bu_n, void *workspace,
+                                size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(nbr && bu_off && bu_n && workspace && nv > 0 && k > 0, "gp_pool_cs_count: null/empty argument");
+    GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_count: k=%d too large (128*k <= %d)", k, CS_MAXNK);
+    int64_t nb = (nv + CS_BR - 1) / CS_BR;
+    GpCarver cv(workspace, workspace_bytes);
+    int64_t *cnt = cv.take<int64_t>(nb + 1);
+    size_t tb = cs_scan_tmp(nb + 1);
+    char *tmp = cv.take<char>(tb);
+    if (!cv.ok()) { gp_set_error("gp_pool_cs_count: workspace too small"); return GP_ENOMEM; }
+    hipStream_t s = gp_stream(stream_);
+    GP_CHECK_HIP(hipMemsetAsync(cnt + nb, 0, sizeof(int64_t), s));
+    size_t sm = (size_t)(CS_HS + cs_np2((int64_t)CS_BR * k)) * sizeof(int);
+    GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (CS_HS + CS_MAXID) * (int)sizeof(int)));
+    cs_count_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, cnt, bu_n);
+    GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, cnt, bu_off, (int64_t)0, (size_t)(nb + 1), rocprim::plus<int64_t>(), s));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// pass 2: bu_row i32 [total], bu_mask u32 [total/32], wa_hi / wa_lo f16 [total/32 * 8 * 512] (only the fragments whose
+// mask bit is set are defined -- and read)
+extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, const int64_t *bu_off, int64_t total_rows,
+                               int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream_) {
+    GP_CHECK_ARG(nbr && w && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
+                 "gp_pool_cs_fill: bad argument");
+    GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_fill: k=%d too large (128*k <= %d)", k, CS_MAXNK);
+    int64_t nb = (nv + CS_BR - 1) / CS_BR;
+    hipStream_t s = gp_stream(stream_);
+    const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
+    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
+    GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_max));
+    cs_fill_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
+                                                  static_cast<_Float16 *>(wa_lo));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// One application y = A x on pre-split operands (see gp_pool_mfma_apply for the operand conventions).  d must be 512.
+extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                                const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
+                                void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream_) {
+    GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0, "gp_pool_cs_apply: null/empty argument");
+    GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply: d=%d (kernel specialised for %d columns)", d, CS_D);
+    GP_CHECK_ARG((y_hi && y_lo) || y_f32, "gp_pool_cs_apply: no output requested");
+    GP_CHECK_ARG(ld_x % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0, "gp_pool_cs_apply: x rows must be 16-byte aligned");
+    GP_CHECK_ARG(!y_hi || (ld_y % 8 == 0 && (uintptr_t)y_hi % 16 == 0 && (uintptr_t)y_lo % 16 == 0 && y_hi != x_hi && y_lo != x_lo),
+                 "gp_pool_cs_apply: y rows must be 16-byte aligned and must not alias x");
+    GP_CHECK_ARG(!y_f32 || (ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0), "gp_pool_cs_apply: fp32 output rows must be 16-byte aligned");
+    hipStream_t s = gp_stream(stream_);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_SMEM));
+        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_SMEM));
+        attr_set = true;
+    }
+    const int64_t nb = (nv + CS_BR - 1) / CS_BR;
+    const int64_t per_xcd = (nb * (CS_D / CS_NC) + 7) / 8;
+    uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
+#define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
+                static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale, stamp
+    if (stamp) cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    else cs_pool_kernel<false><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+#undef CS_ARGS
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}

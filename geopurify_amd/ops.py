@@ -424,6 +424,50 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None
     return out_f32 if out_f32 is not None else out_split
 
 
+class PoolCs:
+    """Column-sliced matrix-core pooling operator (gp_pool_cs_*): 128-row blocks, fragment masks."""
+
+    def __init__(self, bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total):
+        self.bu_off, self.bu_n, self.bu_row, self.bu_mask = bu_off, bu_n, bu_row, bu_mask
+        self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
+        self.block_rows = 128
+
+
+def pool_cs_build(nbr, w):
+    """One host sync (total padded union rows, to size the arrays)."""
+    lib = _lib.load()
+    nv, k = nbr.shape
+    dev = nbr.device
+    nb = (nv + 127) // 128
+    ws = _ws(lib.gp_pool_cs_workspace_bytes(nv), dev)
+    bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+    bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
+    check(lib.gp_pool_cs_count(_ptr(nbr), nv, int(k), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(), _stream()),
+          "gp_pool_cs_count")
+    total = int(bu_off[nb].item())                                                            # the one host sync
+    bu_row = torch.empty(total, dtype=torch.int32, device=dev)
+    bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
+    wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
+    wa_lo = torch.empty_like(wa_hi)
+    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
+                              _ptr(wa_lo), _stream()), "gp_pool_cs_fill")
+    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total)
+
+
+def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None):
+    """x_split / out_split: (hi, lo) f16 [Nv, >=d] pairs; out_f32 fp32 [Nv, >=d]; at least one output.
+    out_scale: device scalar multiplied into out_f32 (1/s of a pow2_scale()-scaled x_split)."""
+    lib = _lib.load()
+    xh, xl = x_split
+    assert xh.stride(0) == xl.stride(0)
+    yh, yl = out_split if out_split is not None else (None, None)
+    check(lib.gp_pool_cs_apply(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
+                               _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
+                               _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()),
+          "gp_pool_cs_apply")
+    return out_f32 if out_f32 is not None else out_split
+
+
 def pool_mfma_apply_persistent(x_split, op, d, out_split=None, out_f32=None, out_scale=None, dynamic=True):
     """Persistent matrix-core pooling (one workgroup per CU).  Outputs need op.rows_padded rows; exactly one output form.
     dynamic: workgroups claim tiles from op.queue (False: static tile lists, the slower tuning reference)."""

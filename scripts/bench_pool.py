@@ -62,7 +62,13 @@ for R in (8,):
     print(f"tiles R={R}: build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
-variants += [("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
+cs = ops.pool_cs_build(nbr, w); torch.cuda.synchronize()
+t0 = time.time(); cs = ops.pool_cs_build(nbr, w); torch.cuda.synchronize()
+_bm = cs.bu_mask.cpu().numpy().astype(np.int64) & 0xFF
+print(f"cs BR=128: union rows/row (padded) {cs.total / Nv:.2f}  non-empty fragments {np.unpackbits(_bm.astype(np.uint8)[:, None], axis=1).mean():.3f}"
+      f"  build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
+variants += [("cs128 column-sliced (split out)", ("cs", 0)), ("cs128 column-sliced (fp32 out)", ("cs32", 0)),
+             ("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
              ("mfma64 column-sliced waves (split out)", ("mfmacs", 64, 0, 0)),
              ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0)),
              ("persist64 (split out)", ("persist", 64, 0, 0)), ("persist64 (fp32 out)", ("persist32", 64, 0, 0)),
@@ -81,6 +87,10 @@ for rnd in range(3):
     for name, v in variants:
         if v is None:
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
+        elif v[0] == "cs":
+            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
+        elif v[0] == "cs32":
+            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
         elif v[0] == "mfma":
             lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
@@ -107,6 +117,10 @@ for rnd in range(3):
 for name, ts in res.items():
     t = min(ts)
     print(f"{name:32s} min {t:7.3f} ms  med {np.median(ts):7.3f} ms  -> {bytes_alg / t / 1e6:7.1f} GB/s algorithmic ({bytes_alg / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+yc = torch.empty((Nv, D), device="cuda"); ye = torch.empty((Nv, D), device="cuda")
+ops.pool_cs_apply(xs, cs, D, out_f32=yc)
+ops.pool_ell(X, nbr, w, D, ye)
+print("cs128 vs ELL max |diff|:", float((yc - ye).abs().max()), flush=True)
 # the column-sliced wave mapping computes the same sums in the same order per element: identical outputs
 ya = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
 yb = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))

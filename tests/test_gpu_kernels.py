@@ -709,6 +709,122 @@ def test_pool_mfma_matches_ell_and_oracle(ops, n_vox, BR):
     assert ((y2[0].float() + y2[1].float()) - o2).abs().max() < 1e-6
 
 
+def _cs_dense_block(op, b, K, nbc, wc, Nv):
+    """Dense [128, padded union] weight block of row block b rebuilt from the fragment arrays (non-empty fragments only) and
+    from the ELL lists; also checks the union rows and the (step, group) masks."""
+    bo, bn, br, bm = (t.cpu().numpy() for t in (op.bu_off, op.bu_n, op.bu_row, op.bu_mask))
+    wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, 8, 64, 8) / 1024.0
+    rows = np.arange(b * 128, min(b * 128 + 128, Nv))
+    u = br[bo[b]:bo[b] + bn[b]]
+    assert len(set(u)) == len(u) and set(u) == set(nbc[rows].reshape(-1))
+    assert (br[bo[b] + bn[b]:bo[b + 1]] == u[0]).all()
+    dense = np.zeros((128, bo[b + 1] - bo[b]), np.float64)
+    pos = {v: i for i, v in enumerate(u)}
+    for r_i, row in enumerate(rows):
+        for j in range(K):
+            dense[r_i, pos[nbc[row, j]]] = wc[row, j]
+    steps = (bo[b + 1] - bo[b]) // 32
+    got = np.zeros_like(dense)
+    for s_ in range(steps):
+        m = int(bm[bo[b] // 32 + s_]) & 0xFFFFFFFF
+        for gq in range(8):
+            nz = np.abs(dense[gq * 16:gq * 16 + 16, s_ * 32:s_ * 32 + 32]).max() > 0
+            assert bool((m >> gq) & 1) == bool(nz), (b, s_, gq, m)
+            if not nz:
+                continue                                               # an empty fragment is undefined memory: never read
+            for lane in range(64):
+                got[gq * 16 + lane % 16, s_ * 32 + (lane // 16) * 8:s_ * 32 + (lane // 16) * 8 + 8] = wa[bo[b] // 32 + s_, gq, lane]
+    assert np.abs(got - dense).max() < 1e-7
+    # order of the union rows: (first group, last group, group set, id) ascending
+    use = (dense[:, :len(u)] != 0).reshape(8, 16, -1).any(1)           # [group, union row]
+    keys = []
+    for i in range(len(u)):
+        gs = np.flatnonzero(use[:, i])
+        keys.append((gs[0], gs[-1], int((use[:, i] * (1 << np.arange(8))).sum()), u[i]))
+    assert keys == sorted(keys)
+
+
+@pytest.mark.parametrize("n_vox", [2500, 2531])
+def test_pool_cs_matches_ell_and_oracle(ops, n_vox):
+    """Column-sliced matrix-core pooling (128-row blocks, union rows grouped by the 16-row groups that use them, empty
+    weight fragments skipped) against the ELL gather and the oracle (models/affinity_module.py:1575-1587)."""
+    rng = np.random.default_rng(14)
+    c = surface_voxels(rng, n_vox)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, K, D = len(c), 96, 512
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    E = F.normalize(torch.randn(Nv, 128), dim=1)
+    w = ops.affinity_softmax(dev(E), nbr, 20.0)
+    op = ops.pool_cs_build(nbr, w)
+    nbc, wc = nbr.cpu().numpy(), w.cpu().numpy()
+    bo = op.bu_off.cpu().numpy()
+    assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0 and (np.diff(bo) >= 32).all()
+    nb = len(bo) - 1
+    for b in (0, nb // 2, nb - 1):
+        _cs_dense_block(op, b, K, nbc, wc, Nv)
+    bm = op.bu_mask.cpu().numpy().astype(np.int64) & 0xFF
+    fill = np.unpackbits(bm.astype(np.uint8)[:, None], axis=1).mean()
+    assert 0.2 < fill < 0.9, fill                                      # the grouping leaves a good part of the fragments empty
+    X = torch.randn(Nv, 544)
+    Xd = dev(X)
+    T = 5
+    sp = [ops.split_f16(Xd, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))]
+    out = torch.empty((Nv, D), device="cuda")
+    b_ = [torch.empty((Nv, D), device="cuda") for _ in range(2)]
+    cb = Xd
+    for t in range(T):
+        last = t == T - 1
+        ops.pool_cs_apply(sp[t % 2], op, D, out_split=None if last else sp[(t + 1) % 2], out_f32=out if last else None)
+        ops.pool_ell(cb, nbr, w, D, b_[t % 2]); cb = b_[t % 2]
+    assert (out - cb).abs().max() < 2e-5                               # tolerance: fp32-class split arithmetic
+    ref = o_aff.pool_gather(X[:, :D], nbr.cpu().long(), w.cpu(), T)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    y2 = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+    o2 = torch.empty((Nv, D), device="cuda")
+    ops.pool_cs_apply(sp[0], op, D, out_split=y2, out_f32=o2)
+    assert ((y2[0].float() + y2[1].float()) - o2).abs().max() < 1e-6
+    # bitwise reproducible: the same operator applied twice gives the same bits
+    o3 = torch.empty((Nv, D), device="cuda")
+    ops.pool_cs_apply(sp[0], op, D, out_f32=o3)
+    assert torch.equal(o2, o3)
+
+
+@pytest.mark.parametrize("n_vox,K", [(130, 96), (70, 32), (257, 32), (65, 8), (129, 1)])
+def test_pool_cs_tiny_voxel_sets(ops, n_vox, K):
+    """edge shapes: a single (partial) row block, one-step blocks, K far from 96."""
+    rng = np.random.default_rng(15)
+    c = surface_voxels(rng, n_vox)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, D = len(c), 512
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    w = ops.affinity_softmax(dev(F.normalize(torch.randn(Nv, 128), dim=1)), nbr, 20.0)
+    op = ops.pool_cs_build(nbr, w)
+    X = torch.randn(Nv, D)
+    out = torch.empty((Nv, D), device="cuda")
+    ops.pool_cs_apply(ops.split_f16(dev(X)), op, D, out_f32=out)
+    ref = o_aff.pool_gather(X, nbr.cpu().long(), w.cpu(), 1)
+    assert (out.cpu().double() - ref).abs().max() < 1e-5
+
+
+def test_pool_cs_operator_with_non_local_neighbours(ops):
+    """Neighbour lists that are NOT local (random ids): a 128-row block's union has thousands of distinct ids (the builder's
+    full-size hash table, sorts of 8192 keys); the operator still equals the ELL gather."""
+    rng = np.random.default_rng(77)
+    Nv, K, D = 5000, 96, 512
+    nbr = dev(torch.from_numpy(np.stack([rng.choice(Nv, K, replace=False) for _ in range(Nv)])).to(torch.int32))
+    w = torch.softmax(torch.randn(Nv, K), dim=1)
+    op = ops.pool_cs_build(nbr, dev(w))
+    bn = op.bu_n.cpu().numpy()
+    assert bn[:-1].min() > 2048
+    _cs_dense_block(op, len(bn) - 1, K, nbr.cpu().numpy(), w.numpy(), Nv)
+    X = torch.randn(Nv, D)
+    out = torch.empty((Nv, D), device="cuda")
+    ops.pool_cs_apply(ops.split_f16(dev(X), D), op, D, out_f32=out)
+    ref = torch.empty((Nv, D), device="cuda")
+    ops.pool_ell(dev(X), nbr, dev(w), D, ref)
+    assert (out - ref).abs().max() < 1e-5
+
+
 def test_nn1_masked_grid_path_equals_bruteforce(ops):
     """>= 32768 points take the grid-accelerated search; must equal the brute force (incl. far queries)."""
     from geopurify_amd import _lib
