@@ -258,7 +258,7 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
 // ------------------------------------------------------------------------------------------------ apply
 // One 512-thread workgroup = 128 rows x 256 columns (grid = row blocks x 2 column halves, the halves of a row block
 // adjacent on one XCD); wave wv owns columns 32 wv .. 32 wv + 31 of the half for all 128 rows (16 accumulator tiles).
-// A 3-deep ring of 48-KiB stages is filled by LDS-DMA two steps ahead (96 KiB in flight per CU); wave wv stages union
+// A ring of three 48-KiB stages is filled by LDS-DMA up to three steps ahead (see the loop); wave wv stages union
 // rows 4 wv .. 4 wv + 3 of a step (two 1-KiB instructions per plane, two rows each) and the weight fragment of group wv.
 // The image is XOR-swizzled through the DMA source addresses exactly as in pool_mfma.hip (physical 16-byte chunk c of
 // row r holds logical chunk c ^ 2 t(r), t(r) = (r & 3) | ((r >> 3) & 1) << 2), which makes the transposed fragment
@@ -331,63 +331,75 @@ cs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
 #pragma unroll
     for (int i = 0; i < CS_NG * 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stages 0 and 1 in flight (a one-step block stages its only step twice)
-    unsigned mA, mB, mC;
+    // ---- prologue: stages 0, 1 and 2 in flight (blocks with fewer steps stage their last step again: harmless)
+    unsigned mA, mB, mC, mD;
     i32x4 idv;
     {
-        const int k1 = n > 1 ? 1 : 0, k2 = n > 2 ? 2 : n - 1;
-        const i32x4 i0 = load_ids(0), i1 = load_ids(k1);
+        const int k1 = n > 1 ? 1 : 0, k2 = n > 2 ? 2 : n - 1, k3 = n > 3 ? 3 : n - 1;
+        const i32x4 i0 = load_ids(0), i1 = load_ids(k1), i2 = load_ids(k2);
         mA = mkg[0];
         mB = mkg[k1];
+        mC = mkg[k2];
         issue(i0, mA, 0, 0);
         issue(i1, mB, k1, 1);
-        idv = load_ids(k2);
-        mC = mkg[k2];
-        asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mC));   // (waited for here, not inside the loop)
-        cs_handover<CS_DMA>();
+        issue(i2, mC, k2, 2);
+        idv = load_ids(k3);
+        mD = mkg[k3];
+        asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mD));   // (waited for here, not inside the loop)
+        cs_handover<2 * CS_DMA>();
     }
     if constexpr (STAMP) st_pro = cs_now();
-    // Software pipeline (the fragment reads of all eight waves leave the barrier together and take ~500 cycles to come back;
-    // an MFMA batch in front of each wait hides them):
-    //   step s:  reads {staged rows, weight fragments of groups 0-3} of stage s      | waves 0-3: DMA of stage s + 2
-    //            MFMA batch "groups 4-7" of stage s - 1 (fragments read in step s - 1, rows kept in fp)
-    //            wait; reads {weight fragments of groups 4-7} of stage s; next step's scalars (s_load)
-    //            MFMA batch "groups 0-3" of stage s                                  | waves 4-7: DMA of stage s + 2
-    //            wait (every LDS read of stage s has landed in registers); hand-over
-    // Waves 0-3 issue their DMA first and waves 4-7 last, so that the two waves of a SIMD alternate between DMA issue
-    // (which stalls on the memory pipeline's back-pressure) and matrix work.
+    // The gather is latency-bound by the bytes a CU keeps in flight (~1.5 us issue -> landed under load), and LDS is both the
+    // landing zone and the operand store.  So a stage's operands go to REGISTERS at the top of its step, a barrier releases
+    // the slot at once and the stage three steps ahead is issued into it: ~2.7 stages (110 KiB) in flight instead of 2.
+    //   step s:  reads {staged rows, all weight fragments} of stage s
+    //            MFMA batch "groups 4-7" of stage s - 1 (operands read in step s - 1) -- hides the read latency
+    //            wait; barrier 1 (slot s % 3 is free); DMA of stage s + 3 into it; next step's scalars (s_load)
+    //            MFMA batch "groups 0-3" of stage s
+    //            wait for stage s + 1; barrier 2
+    // Two operand sets alternate (P[0], P[1]): set s & 1 holds the staged rows and the fragments of groups 4-7 of stage s.
+    struct CsSet { f16x8 ah[4], al[4], bh[2], bl[2]; };
+    CsSet P[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) P[e].ah[i] = P[e].al[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) P[e].bh[u] = P[e].bl[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     s16x4 fb[2][2][2];
-    f16x8 ah0[4], al0[4], ah1[4], al1[4], bhp[2], blp[2];
+    f16x8 ah0[4], al0[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ah0[i] = al0[i] = ah1[i] = al1[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { bhp[u] = blp[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    for (int i = 0; i < 4; ++i) ah0[i] = al0[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     unsigned mP = 0;                                         // fragment mask of the previous step (its groups 4-7 are pending)
-    auto mfma_hi = [&](unsigned m, const f16x8 (&bh)[2], const f16x8 (&bl)[2]) {
+    auto mfma_hi = [&](unsigned m, const CsSet &S) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
             if (__builtin_expect((m >> (4 + mt)) & 1u, 1)) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(S.ah[mt], S.bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bl[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(S.ah[mt], S.bl[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1[mt], bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(S.al[mt], S.bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
             }
     };
-    const bool late = !(ablate & 32) && wv >= 4;            // tuning aid: bit 5 makes every wave issue first
     const bool do_reads = !(ablate & 1);                     // tuning aid: bit 0 skips reads + MFMAs
-    for (int s0 = 0; s0 < n; s0 += CS_NST) {
+    constexpr int UNR = 2 * CS_NST;                          // slots x operand sets
+    for (int s0 = 0; s0 < n; s0 += UNR) {
 #pragma unroll
-        for (int J = 0; J < CS_NST; ++J) {
-            const int s = s0 + J;
+        for (int JJ = 0; JJ < UNR; ++JJ) {
+            const int s = s0 + JJ;
+            const int J = JJ % CS_NST;
+            CsSet &C = P[JJ & 1];
+            const CsSet &Q = P[(JJ & 1) ^ 1];
             if (s < n) {
                 uint64_t st_a = 0, st_b = 0;
                 if constexpr (STAMP) st_a = cs_now();
                 const uint32_t a0 = addr[0] + J * CS_STAGE, a1 = addr[1] + J * CS_STAGE, aw = addr_w + J * CS_STAGE;
                 const unsigned m = mA;
                 if (do_reads) {
-                    // staged rows: fb[col block][plane][rows 8g+q | 8g+q+4]; weight fragments of groups 0-3
+                    // staged rows: fb[col block][plane][rows 8g+q | 8g+q+4]; then the weight fragments
                     cs_tr<0>(fb[0][0][0], a0);
                     cs_tr<4 * CS_RB>(fb[0][0][1], a0);
                     cs_tr<CS_PLANE>(fb[0][1][0], a0);
@@ -400,50 +412,48 @@ cs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
                     if (m & 2u) { cs_rd128<1 * 1024>(ah0[1], aw); cs_rd128<CS_WPL + 1 * 1024>(al0[1], aw); }
                     if (m & 4u) { cs_rd128<2 * 1024>(ah0[2], aw); cs_rd128<CS_WPL + 2 * 1024>(al0[2], aw); }
                     if (m & 8u) { cs_rd128<3 * 1024>(ah0[3], aw); cs_rd128<CS_WPL + 3 * 1024>(al0[3], aw); }
-                }
-                if (!late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
-                if constexpr (STAMP) if (ablate & 64) st_issue += cs_now() - st_a;
-                if (do_reads) {
-                    mfma_hi(mP, bhp, blp);                  // groups 4-7 of the previous step
+                    if (m & 16u) { cs_rd128<4 * 1024>(C.ah[0], aw); cs_rd128<CS_WPL + 4 * 1024>(C.al[0], aw); }
+                    if (m & 32u) { cs_rd128<5 * 1024>(C.ah[1], aw); cs_rd128<CS_WPL + 5 * 1024>(C.al[1], aw); }
+                    if (m & 64u) { cs_rd128<6 * 1024>(C.ah[2], aw); cs_rd128<CS_WPL + 6 * 1024>(C.al[2], aw); }
+                    if (m & 128u) { cs_rd128<7 * 1024>(C.ah[3], aw); cs_rd128<CS_WPL + 7 * 1024>(C.al[3], aw); }
+                    mfma_hi(mP, Q);                         // groups 4-7 of the previous step
                     cs_wait_b(fb);
                     cs_wait_a(ah0, al0);
+                    cs_wait_a(C.ah, C.al);
                 }
+                asm volatile("s_barrier" ::: "memory");   // every wave holds its operands of stage s: the slot is free
+                if (s + 3 < n) issue(idv, mD, s + 3, J);
+                if constexpr (STAMP) if (ablate & 64) st_issue += cs_now() - st_a;
                 // scalars of the stage issued in the next step (clamped: never past the block's padded union); they are
-                // waited for right before the barrier, a whole MFMA batch later
-                const int kn = s + 3 < n ? s + 3 : n - 1;
+                // waited for right before barrier 2, a whole MFMA batch later
+                const int kn = s + 4 < n ? s + 4 : n - 1;
                 const i32x4 idn = load_ids(kn);
                 const unsigned mN = mkg[kn];
                 if (do_reads) {
-                    if (m & 16u) { cs_rd128<4 * 1024>(ah1[0], aw); cs_rd128<CS_WPL + 4 * 1024>(al1[0], aw); }
-                    if (m & 32u) { cs_rd128<5 * 1024>(ah1[1], aw); cs_rd128<CS_WPL + 5 * 1024>(al1[1], aw); }
-                    if (m & 64u) { cs_rd128<6 * 1024>(ah1[2], aw); cs_rd128<CS_WPL + 6 * 1024>(al1[2], aw); }
-                    if (m & 128u) { cs_rd128<7 * 1024>(ah1[3], aw); cs_rd128<CS_WPL + 7 * 1024>(al1[3], aw); }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { bhp[u] = cs_cat(fb[u][0][0], fb[u][0][1]); blp[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
+                    for (int u = 0; u < 2; ++u) { C.bh[u] = cs_cat(fb[u][0][0], fb[u][0][1]); C.bl[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
                         if (__builtin_expect((m >> mt) & 1u, 1)) {
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], C.bh[u], acc[mt * 2 + u], 0, 0, 0);
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], blp[u], acc[mt * 2 + u], 0, 0, 0);
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], C.bl[u], acc[mt * 2 + u], 0, 0, 0);
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0[mt], C.bh[u], acc[mt * 2 + u], 0, 0, 0);
                         }
                 }
-                if (late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
-                // every LDS read of this stage is in registers before the barrier lets its slot be refilled, and the scalar
-                // loads are waited for HERE, so that no compiler-placed lgkmcnt(0) sits inside the next step
-                cs_wait_a(ah1, al1);
+                // the scalar loads are waited for HERE, so that no compiler-placed lgkmcnt(0) sits inside the next step
                 asm volatile("" ::"s"(idn.x), "s"(idn.y), "s"(idn.z), "s"(idn.w), "s"(mN));
                 if constexpr (STAMP) { st_b = cs_now(); st_work += st_b - st_a; }
-                if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
+                // stage s + 1 has landed once at most the DMA of stages s + 2 and s + 3 is outstanding
+                if (s + 3 < n) cs_handover<2 * CS_DMA>(); else if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
                 if constexpr (STAMP) st_wait += cs_now() - st_b;
-                mP = m; mA = mB; mB = mC; mC = mN; idv = idn;
+                mP = m; mA = mB; mB = mC; mC = mD; mD = mN; idv = idn;
             }
         }
     }
-    if (do_reads) mfma_hi(mP, bhp, blp);                     // groups 4-7 of the last step
+    if (do_reads) { if ((n - 1) & 1) mfma_hi(mP, P[1]); else mfma_hi(mP, P[0]); }   // groups 4-7 of the last step
     if (ablate & 4) return;                                // tuning aid: bit 2 skips the epilogue
     uint64_t st_e0 = 0;
     if constexpr (STAMP) st_e0 = cs_now();
@@ -504,6 +514,283 @@ cs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_work; o[4] = st_wait; o[5] = st_issue;
             o[6] = t3 - st_e0; o[7] = t3 - st_t0; o[8] = (uint64_t)n; o[9] = xcc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ engine
+// Producer / consumer form of the same operator ("engine"): ONE persistent 512-thread workgroup per CU.
+//   waves 4-7 = loaders: nothing but LDS-DMA.  They fill a ring of four 32-KiB slots (32 union rows x 128 columns x
+//               {hi, lo} + the step's 8 x {hi, lo} weight fragments) as fast as slots come free -- up to three stages
+//               (96 KiB) in flight per CU, across tile boundaries -- and absorb the memory pipeline's back-pressure;
+//   waves 0-3 = consumers (one per SIMD): wave cw owns all 128 rows x 32 columns of the tile (16 accumulator tiles),
+//               copies a landed stage's operands into registers, releases the slot AT ONCE and only then multiplies.
+// A tile is (128-row block, 128-column quarter); tiles of an XCD label are handed out in order, so that the label's
+// 32 workgroups work on 8 neighbouring row blocks (a 1 024-row window: its union rows fit the XCD's 4-MiB L2, which the
+// 2 048-row window of cs_pool_kernel does not -- 41 % instead of 68 % L2 hits, 1.28 GB instead of 1.03 GB from memory).
+// There is no s_barrier: slot hand-over goes through two monotonic LDS counters per slot (full: +1 per loader once its
+// DMA has landed, s_waitcnt vmcnt; free: +1 per consumer once its operand reads have landed, s_waitcnt lgkmcnt), which the
+// other side polls.  Consumers issue no LDS-DMA, so their epilogue (wave-private LDS staging, stores) is plain code and
+// overlaps the loaders' work on the next tile.
+constexpr int EG_NC = 128;                          // columns per tile
+constexpr int EG_RB = EG_NC * 2;                    // bytes per staged row and plane
+constexpr int EG_PLANE = CS_KS * EG_RB;             // 8 KiB
+constexpr int EG_OFF_W = 2 * EG_PLANE;              // 16 KiB
+constexpr int EG_SLOT = EG_OFF_W + 2 * CS_WPL;      // 32 KiB
+constexpr int EG_NSLOT = 4;
+constexpr int EG_OFF_FLAG = EG_NSLOT * EG_SLOT;     // {full, fragment mask} x 4 | free[4] (uint32)
+constexpr int EG_OFF_STG = EG_OFF_FLAG + 256;       // epilogue staging: 4 waves x 32 rows x CS_EP floats
+constexpr int EG_STG_WAVE = 32 * CS_EP * 4;
+constexpr size_t EG_SMEM = (size_t)EG_OFF_STG + 4 * EG_STG_WAVE;
+constexpr int EG_DMA = 8;                           // LDS-DMA instructions per loader and stage: 4 x rows, 4 x weights
+
+__device__ __forceinline__ void eg_wait_ge(uint32_t flag_addr, uint32_t target) {
+    for (;;) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
+        if ((int32_t)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void eg_signal(uint32_t flag_addr) {
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t one = 1;
+        asm volatile("ds_add_u32 %0, %1" ::"v"(flag_addr), "v"(one) : "memory");
+    }
+}
+
+template <bool STAMP>
+__global__ void __launch_bounds__(512, 2)
+cs_engine_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
+                 const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
+                 const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
+                 _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
+                 int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+    if (tid < 12) reinterpret_cast<uint32_t *>(smem_raw + EG_OFF_FLAG)[tid] = 0u;
+    __syncthreads();
+    // ---- this workgroup's tiles: label q = blockIdx & 7 owns the contiguous tile range [lo, hi); workgroup wi of the label
+    //      takes tiles lo + wi, lo + wi + W, ...   (tile = 4 * row block + column quarter)
+    const int64_t T = nblocks * (CS_D / EG_NC);
+    const int label = blockIdx.x & 7, wi = blockIdx.x >> 3, W = (int)(gridDim.x >> 3);
+    const int64_t t_lo = label * T / 8, t_hi = (label + 1) * T / 8;
+    uint64_t st_t0 = 0, st_poll = 0, st_work = 0, st_epi = 0, st_steps = 0;
+    if constexpr (STAMP) st_t0 = cs_now();
+
+    if (wv >= 4) {
+        // ================================================================ loaders
+        // Loader l owns ring slot l and stages l, l + 4, l + 8, ... of the workgroup's stage sequence (all steps of all its tiles
+        // in order): it waits until the consumers have released the slot, issues the WHOLE stage (16 x 1 KiB of rows, the
+        // non-empty weight fragments), writes the stage's fragment mask next to the slot's counter, loads the scalars of its
+        // next stage while the DMA is in flight, waits for its own DMA (vmcnt(0): nothing else is in its queue) and signals.
+        // Four loaders = up to four stages between issue and release, and the per-stage latency chain (scalar loads, poll,
+        // issue, landing) runs four stages wide instead of once per stage.
+        const int l = wv - 4;
+        const int du = lane >> 4, dc = lane & 15;
+        const int dsw0 = (dc ^ (2 * du)) * 8, dsw1 = (dc ^ (2 * (du | 4))) * 8;  // source column of this lane's chunk: rows 0-7 / 8-15 (mod 16)
+        int64_t t = t_lo + wi;
+        if (t >= t_hi) return;
+        int64_t ub0 = bu_off[t >> 2];
+        int n = (int)((bu_off[(t >> 2) + 1] - ub0) / CS_KS);
+        int k = l;                                                            // this loader's next stage = step k of tile t (k may run past n)
+        uint32_t j = 0;                                                       // uses of the slot so far
+        for (;;) {
+            while (k >= n) {                                                  // on to the tile that holds the stage
+                k -= n;
+                t += W;
+                if (t >= t_hi) break;
+                ub0 = bu_off[t >> 2];
+                n = (int)((bu_off[(t >> 2) + 1] - ub0) / CS_KS);
+            }
+            if (t >= t_hi) break;
+            const int col0 = (int)(t & 3) * EG_NC;
+            const int32_t *idg = bu_row + ub0 + (int64_t)k * CS_KS;
+            i32x4 id[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) id[i] = *reinterpret_cast<const i32x4 *>(idg + 4 * i);
+            const unsigned mk = bu_mask[ub0 / CS_KS + k];
+            eg_wait_ge(lds0 + EG_OFF_FLAG + 32 + l * 4, 4u * j);                // free[l]: the slot's previous stage is consumed
+            unsigned char *dst = smem_raw + l * EG_SLOT;
+            if (!(ablate & 2)) {                                              // tuning aid: bit 1 skips the row gather
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                                 // rows 4 i .. 4 i + 3
+                    const int idr = du == 0 ? id[i].x : du == 1 ? id[i].y : du == 2 ? id[i].z : id[i].w;
+                    const int64_t so = (int64_t)idr * ld_x + col0 + (((i >> 1) & 1) ? dsw1 : dsw0);
+                    cs_glds16(x_hi + so, dst + (4 * i) * EG_RB);
+                    cs_glds16(x_lo + so, dst + EG_PLANE + (4 * i) * EG_RB);
+                }
+            }
+            const int64_t wk = (ub0 / CS_KS + k) * (CS_NG * 512) + lane * 8;
+#pragma unroll
+            for (int gq = 0; gq < CS_NG; ++gq)
+                if ((mk >> gq) & 1u) {                                        // empty fragments are neither fetched nor read
+                    cs_glds16(wa_hi + wk + gq * 512, dst + EG_OFF_W + gq * 1024);
+                    cs_glds16(wa_lo + wk + gq * 512, dst + EG_OFF_W + CS_WPL + gq * 1024);
+                }
+            if (lane == 0) {
+                const uint32_t ma = lds0 + EG_OFF_FLAG + l * 8 + 4;
+                asm volatile("ds_write_b32 %0, %1" ::"v"(ma), "v"(mk) : "memory");
+            }
+            k += 4;
+            ++j;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            eg_signal(lds0 + EG_OFF_FLAG + l * 8);                              // full[l]
+        }
+        return;
+    }
+    // ==================================================================== consumers
+    const int cw = wv;
+    const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    uint32_t addr[2];
+    {
+        const uint32_t rowb = (uint32_t)(8 * gq + q) * EG_RB + (uint32_t)(cw * CS_WC * 2) + (uint32_t)(p * 8);
+        const uint32_t t5 = (uint32_t)(q | ((gq & 1) << 2)) << 5;
+        addr[0] = lds0 + (rowb ^ t5);
+        addr[1] = lds0 + ((rowb + 32u) ^ t5);
+    }
+    const uint32_t addr_w = lds0 + EG_OFF_W + lane * 16;
+    const float inv = 1.f / CS_WSCALE;
+    const float so = (y_f32 && out_scale) ? out_scale[0] : 1.f;
+    float *stg = reinterpret_cast<float *>(smem_raw + EG_OFF_STG + cw * EG_STG_WAVE);
+    const int fl = lane & 15, fq = lane >> 4;
+    const int er = lane >> 2, ec = (lane & 3) * 8;
+    const bool do_mma = !(ablate & 1);
+    uint32_t g = 0;
+    s16x4 fb[2][2][2];
+    f16x8 ah[8], al[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ah[i] = al[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t ub0_n = 0;
+    int n_n = 0;
+    {
+        const int64_t t = t_lo + wi;
+        if (t < t_hi) {
+            ub0_n = bu_off[t >> 2];
+            n_n = (int)((bu_off[(t >> 2) + 1] - ub0_n) / CS_KS);
+        }
+    }
+    for (int64_t t = t_lo + wi; t < t_hi; t += W) {
+        const int64_t b = t >> 2;
+        const int col0 = (int)(t & 3) * EG_NC;
+        const int64_t ub0 = ub0_n;
+        const int n = n_n;
+        f32x4 acc[CS_NG * 2];
+#pragma unroll
+        for (int i = 0; i < CS_NG * 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t + W < t_hi) {                                  // next tile's descriptor and first mask (scalar loads, used a tile later)
+            const int64_t bn = (t + W) >> 2;
+            ub0_n = bu_off[bn];
+            n_n = (int)((bu_off[bn + 1] - ub0_n) / CS_KS);
+        }
+        for (int k = 0; k < n; ++k, ++g) {
+            const uint32_t slot = g & 3u;
+            uint64_t st_a = 0, st_b = 0;
+            if constexpr (STAMP) st_a = cs_now();
+            unsigned m;                                                                    // the stage's fragment mask rides next to the counter
+            for (;;) {                                                                     // full[slot]: the slot's loader has signalled this stage
+                int2 fm;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(fm) : "v"(lds0 + EG_OFF_FLAG + slot * 8) : "memory");
+                m = (unsigned)__builtin_amdgcn_readfirstlane(fm.y);
+                if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane(fm.x) - ((g >> 2) + 1u)) >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (STAMP) { st_b = cs_now(); st_poll += st_b - st_a; }
+            const uint32_t so_ = slot * EG_SLOT;
+            const uint32_t a0 = addr[0] + so_, a1 = addr[1] + so_, aw = addr_w + so_;
+            if (!(ablate & 256)) {                           // tuning aid: bit 8 skips the staged-row reads
+            cs_tr<0>(fb[0][0][0], a0);
+            cs_tr<4 * EG_RB>(fb[0][0][1], a0);
+            cs_tr<EG_PLANE>(fb[0][1][0], a0);
+            cs_tr<EG_PLANE + 4 * EG_RB>(fb[0][1][1], a0);
+            cs_tr<0>(fb[1][0][0], a1);
+            cs_tr<4 * EG_RB>(fb[1][0][1], a1);
+            cs_tr<EG_PLANE>(fb[1][1][0], a1);
+            cs_tr<EG_PLANE + 4 * EG_RB>(fb[1][1][1], a1);
+            }
+            if (ablate & 512) m = 0;                         // tuning aid: bit 9 skips the weight-fragment reads (and their MFMAs)
+            if (m & 1u) { cs_rd128<0 * 1024>(ah[0], aw); cs_rd128<CS_WPL + 0 * 1024>(al[0], aw); }
+            if (m & 2u) { cs_rd128<1 * 1024>(ah[1], aw); cs_rd128<CS_WPL + 1 * 1024>(al[1], aw); }
+            if (m & 4u) { cs_rd128<2 * 1024>(ah[2], aw); cs_rd128<CS_WPL + 2 * 1024>(al[2], aw); }
+            if (m & 8u) { cs_rd128<3 * 1024>(ah[3], aw); cs_rd128<CS_WPL + 3 * 1024>(al[3], aw); }
+            if (m & 16u) { cs_rd128<4 * 1024>(ah[4], aw); cs_rd128<CS_WPL + 4 * 1024>(al[4], aw); }
+            if (m & 32u) { cs_rd128<5 * 1024>(ah[5], aw); cs_rd128<CS_WPL + 5 * 1024>(al[5], aw); }
+            if (m & 64u) { cs_rd128<6 * 1024>(ah[6], aw); cs_rd128<CS_WPL + 6 * 1024>(al[6], aw); }
+            if (m & 128u) { cs_rd128<7 * 1024>(ah[7], aw); cs_rd128<CS_WPL + 7 * 1024>(al[7], aw); }
+            cs_wait_b(fb);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(ah[4]), "+v"(ah[5]), "+v"(ah[6]), "+v"(ah[7]),
+                           "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]), "+v"(al[4]), "+v"(al[5]), "+v"(al[6]), "+v"(al[7]));
+            eg_signal(lds0 + EG_OFF_FLAG + 32 + slot * 4);                                  // free[slot]: the operands are in registers
+            if (do_mma) {
+                f16x8 bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { bh[u] = cs_cat(fb[u][0][0], fb[u][0][1]); bl[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
+#pragma unroll
+                for (int mt = 0; mt < CS_NG; ++mt)
+                    if (__builtin_expect((m >> mt) & 1u, 1)) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[u], acc[mt * 2 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl[u], acc[mt * 2 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[u], acc[mt * 2 + u], 0, 0, 0);
+                    }
+            }
+            if constexpr (STAMP) { st_work += cs_now() - st_b; ++st_steps; }
+        }
+        if (ablate & 4) continue;                            // tuning aid: bit 2 skips the epilogue
+        // ---- epilogue: 32 rows at a time through the wave's private staging area; every store instruction writes 16 rows x 64 bytes
+        uint64_t st_e = 0;
+        if constexpr (STAMP) st_e = cs_now();
+        const int64_t row0 = b * CS_BR;
+        const int colw = col0 + cw * CS_WC;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[(mt * 16 + fq * 4 + r) * CS_EP + cb * 16 + fl] = acc[(ch * 2 + mt) * 2 + cb][r] * inv;
+            gp_wave_sync();
+            float4 v[2][2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const float *sp = stg + (it * 16 + er) * CS_EP + ec;
+                v[it][0] = *reinterpret_cast<const float4 *>(sp);
+                v[it][1] = *reinterpret_cast<const float4 *>(sp + 4);
+            }
+            gp_wave_sync();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int64_t grow = row0 + ch * 32 + it * 16 + er;
+                if (grow < nv && !(ablate & 16)) {
+                    const float xv[8] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w, v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
+                    if (y_hi) {
+                        f16x8 h, lo8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { h[i] = (_Float16)xv[i]; lo8[i] = (_Float16)(xv[i] - (float)h[i]); }
+                        *reinterpret_cast<f16x8 *>(y_hi + grow * ld_y + colw + ec) = h;
+                        *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + colw + ec) = lo8;
+                    }
+                    if (y_f32) {
+                        float *yp = y_f32 + grow * ld_yf + colw + ec;
+                        *reinterpret_cast<float4 *>(yp) = make_float4(xv[0] * so, xv[1] * so, xv[2] * so, xv[3] * so);
+                        *reinterpret_cast<float4 *>(yp + 4) = make_float4(xv[4] * so, xv[5] * so, xv[6] * so, xv[7] * so);
+                    }
+                }
+            }
+        }
+        if constexpr (STAMP) st_epi += cs_now() - st_e;
+    }
+    if constexpr (STAMP) {
+        const uint64_t t3 = cs_now();
+        if (lane == 0 && stamp) {
+            uint64_t *o = stamp + ((int64_t)blockIdx.x * 4 + cw) * 10;
+            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = st_work; o[4] = st_poll; o[5] = 0; o[6] = st_epi; o[7] = t3 - st_t0; o[8] = st_steps; o[9] = 0;
         }
     }
 }
@@ -590,6 +877,27 @@ extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x
 #define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
                 static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale, stamp
+    if (g_gp_knobs[11] == 8) {                            // the producer / consumer engine (persistent, one workgroup per CU)
+        static bool eattr = false;
+        static int n_cu = 0;
+        if (!eattr) {
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_engine_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EG_SMEM));
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_engine_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EG_SMEM));
+            int dev = 0;
+            GP_CHECK_HIP(hipGetDevice(&dev));
+            GP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+            eattr = true;
+        }
+        const unsigned grid = (unsigned)((n_cu >= 8 ? n_cu / 8 : 1) * 8);
+#define EG_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
+                static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, g_gp_knobs[4], out_scale, stamp
+        if (stamp) cs_engine_kernel<true><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
+        else cs_engine_kernel<false><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
+#undef EG_ARGS
+        GP_CHECK_LAUNCH();
+        return GP_OK;
+    }
     if (stamp) cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
     else cs_pool_kernel<false><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
 #undef CS_ARGS

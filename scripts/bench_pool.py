@@ -68,6 +68,7 @@ _bm = cs.bu_mask.cpu().numpy().astype(np.int64) & 0xFF
 print(f"cs BR=128: union rows/row (padded) {cs.total / Nv:.2f}  non-empty fragments {np.unpackbits(_bm.astype(np.uint8)[:, None], axis=1).mean():.3f}"
       f"  build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
 variants += [("cs128 column-sliced (split out)", ("cs", 0)), ("cs128 column-sliced (fp32 out)", ("cs32", 0)),
+             ("engine cs128 x 128c (split out)", ("eng", 0)), ("engine cs128 x 128c (fp32 out)", ("eng32", 0)),
              ("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
              ("mfma64 column-sliced waves (split out)", ("mfmacs", 64, 0, 0)),
              ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0)),
@@ -89,6 +90,14 @@ for rnd in range(3):
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
         elif v[0] == "cs":
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
+        elif v[0] == "eng":
+            lib.gp_debug_set(11, 8)
+            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
+            lib.gp_debug_set(11, 0)
+        elif v[0] == "eng32":
+            lib.gp_debug_set(11, 8)
+            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
+            lib.gp_debug_set(11, 0)
         elif v[0] == "cs32":
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
         elif v[0] == "mfma":
@@ -121,6 +130,12 @@ yc = torch.empty((Nv, D), device="cuda"); ye = torch.empty((Nv, D), device="cuda
 ops.pool_cs_apply(xs, cs, D, out_f32=yc)
 ops.pool_ell(X, nbr, w, D, ye)
 print("cs128 vs ELL max |diff|:", float((yc - ye).abs().max()), flush=True)
+lib.gp_debug_set(11, 8)
+yg = torch.empty((Nv, D), device="cuda")
+ops.pool_cs_apply(xs, cs, D, out_f32=yg)
+lib.gp_debug_set(11, 0)
+torch.cuda.synchronize()
+print("engine vs ELL max |diff|:", float((yg - ye).abs().max()), " engine == cs128 bitwise:", bool(torch.equal(yg, yc)), flush=True)
 # the column-sliced wave mapping computes the same sums in the same order per element: identical outputs
 ya = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
 yb = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
