@@ -152,7 +152,7 @@ class PoolTimer:
 
     def wrap(self, ops):
         timer = self
-        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply", "pool_mfma_apply_persistent"):
+        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply", "pool_mfma_apply_persistent", "pool_cs_apply"):
             orig = getattr(ops, name)
 
             def timed(*a, _orig=orig, _name=name, **k):
@@ -171,6 +171,13 @@ class PoolTimer:
 
     def mean_ms(self):
         return float(np.mean([a.elapsed_time(b) for a, b, _ in self.events])) if self.events else float("nan")
+
+    def percentiles(self, qs=(10, 50, 90)):
+        """launch-duration percentiles (ms) over the recorded launches: the pooling figure moves with clock and cache state,
+        a single mean hides that"""
+        if not self.events:
+            return [float("nan")] * len(qs)
+        return [float(v) for v in np.percentile([a.elapsed_time(b) for a, b, _ in self.events], qs)]
 
     def totals(self):
         """(sum of launch times in ms, sum of voxel rows) over the recorded launches: scenes of different sizes (config V)
@@ -508,13 +515,20 @@ def main():
         n_launch = max(len(pool_timer.events), 1)
         pool_ms = tot_ms / n_launch                       # mean launch duration and mean algorithmic bytes per launch over the
         pool_bytes_mean = tot_rows / n_launch * per_row   # timed launches (scenes differ in size): achieved = their ratio
+        p10, p50, p90 = pool_timer.percentiles()
         # the same launches with nothing else on the GPU (with --streams 2 the timed region overlaps the pooling
-        # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth)
-        pool_timer.events, pool_timer.enabled = [], True
+        # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth): one warm pass
+        # (operator build, allocator, clocks), then three timed passes; the median pass is reported
         hp._pool(*hp._last_pool_inputs)
         torch.cuda.synchronize()
-        pool_timer.enabled = False
-        pool_ms_alone = pool_timer.mean_ms()
+        alone = []
+        for _ in range(3):
+            pool_timer.events, pool_timer.enabled = [], True
+            hp._pool(*hp._last_pool_inputs)
+            torch.cuda.synchronize()
+            pool_timer.enabled = False
+            alone.append(pool_timer.mean_ms())
+        pool_ms_alone = float(np.median(alone))
         pool_bytes = Nv * per_row
         achieved = tot_rows * per_row / (tot_ms * 1e-3) / 1e9      # all timed launches, each priced by its own voxel count
         # per-stage breakdown from a ONE-stream side pass (stage marks are meaningless while two scenes interleave)
@@ -549,11 +563,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], int(round(tot_rows / n_launch))),
                          "algorithmic_bytes_per_launch": int(round(pool_bytes_mean)), "avg_launch_ms": round(pool_ms, 5),
                          "launches": n_launch,
+                         "launch_ms_p10": round(p10, 5), "launch_ms_p50": round(p50, 5), "launch_ms_p90": round(p90, 5),
                          "avg_launch_ms_isolated": round(pool_ms_alone, 4),
+                         "isolated_passes_ms": [round(a, 4) for a in alone],
                          "frac_isolated": round(pool_bytes / (pool_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "achieved = algorithmic_bytes_per_launch / avg_launch_ms, both means over the launches of the timed "
                                  "region (HIP events around every launch); _isolated: the last scene's launches (Nv in config.workload) "
-                                 "repeated with nothing else on the GPU"},
+                                 "repeated with nothing else on the GPU (one warm pass, then the median of three passes)"},
             "roofline_conv": conv_roofline(conv_timer),
             "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",

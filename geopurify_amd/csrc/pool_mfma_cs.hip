@@ -258,7 +258,7 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
 // ------------------------------------------------------------------------------------------------ apply
 // One 512-thread workgroup = 128 rows x 256 columns (grid = row blocks x 2 column halves, the halves of a row block
 // adjacent on one XCD); wave wv owns columns 32 wv .. 32 wv + 31 of the half for all 128 rows (16 accumulator tiles).
-// A ring of three 48-KiB stages is filled by LDS-DMA up to three steps ahead (see the loop); wave wv stages union
+// A 3-deep ring of 48-KiB stages is filled by LDS-DMA two steps ahead (96 KiB in flight per CU); wave wv stages union
 // rows 4 wv .. 4 wv + 3 of a step (two 1-KiB instructions per plane, two rows each) and the weight fragment of group wv.
 // The image is XOR-swizzled through the DMA source addresses exactly as in pool_mfma.hip (physical 16-byte chunk c of
 // row r holds logical chunk c ^ 2 t(r), t(r) = (r & 3) | ((r >> 3) & 1) << 2), which makes the transposed fragment
@@ -331,75 +331,66 @@ cs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
 #pragma unroll
     for (int i = 0; i < CS_NG * 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stages 0, 1 and 2 in flight (blocks with fewer steps stage their last step again: harmless)
-    unsigned mA, mB, mC, mD;
+    // ---- prologue: stages 0 and 1 in flight (a one-step block stages its only step twice)
+    unsigned mA, mB, mC;
     i32x4 idv;
     {
-        const int k1 = n > 1 ? 1 : 0, k2 = n > 2 ? 2 : n - 1, k3 = n > 3 ? 3 : n - 1;
-        const i32x4 i0 = load_ids(0), i1 = load_ids(k1), i2 = load_ids(k2);
+        const int k1 = n > 1 ? 1 : 0, k2 = n > 2 ? 2 : n - 1;
+        const i32x4 i0 = load_ids(0), i1 = load_ids(k1);
         mA = mkg[0];
         mB = mkg[k1];
-        mC = mkg[k2];
         issue(i0, mA, 0, 0);
         issue(i1, mB, k1, 1);
-        issue(i2, mC, k2, 2);
-        idv = load_ids(k3);
-        mD = mkg[k3];
-        asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mD));   // (waited for here, not inside the loop)
-        cs_handover<2 * CS_DMA>();
+        idv = load_ids(k2);
+        mC = mkg[k2];
+        asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mC));   // (waited for here, not inside the loop)
+        cs_handover<CS_DMA>();
     }
     if constexpr (STAMP) st_pro = cs_now();
-    // The gather is latency-bound by the bytes a CU keeps in flight (~1.5 us issue -> landed under load), and LDS is both the
-    // landing zone and the operand store.  So a stage's operands go to REGISTERS at the top of its step, a barrier releases
-    // the slot at once and the stage three steps ahead is issued into it: ~2.7 stages (110 KiB) in flight instead of 2.
-    //   step s:  reads {staged rows, all weight fragments} of stage s
-    //            MFMA batch "groups 4-7" of stage s - 1 (operands read in step s - 1) -- hides the read latency
-    //            wait; barrier 1 (slot s % 3 is free); DMA of stage s + 3 into it; next step's scalars (s_load)
-    //            MFMA batch "groups 0-3" of stage s
-    //            wait for stage s + 1; barrier 2
-    // Two operand sets alternate (P[0], P[1]): set s & 1 holds the staged rows and the fragments of groups 4-7 of stage s.
-    struct CsSet { f16x8 ah[4], al[4], bh[2], bl[2]; };
-    CsSet P[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) P[e].ah[i] = P[e].al[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) P[e].bh[u] = P[e].bl[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    // Software pipeline (the fragment reads of all eight waves leave the barrier together and take ~500 cycles to come back;
+    // an MFMA batch in front of each wait hides part of that):
+    //   step s:  reads {staged rows, weight fragments of groups 0-3} of stage s      | waves 0-3: DMA of stage s + 2
+    //            MFMA batch "groups 4-7" of stage s - 1 (fragments read in step s - 1, rows kept in bhp / blp)
+    //            wait; reads {weight fragments of groups 4-7} of stage s; next step's scalars (s_load)
+    //            MFMA batch "groups 0-3" of stage s                                  | waves 4-7: DMA of stage s + 2
+    //            wait (every LDS read of stage s has landed in registers); hand-over
+    // Waves 0-3 issue their DMA first and waves 4-7 last, so that the two waves of a SIMD alternate between DMA issue
+    // (which stalls on the memory pipeline's back-pressure) and matrix work.
+    // Measured and left out (profiles/r03_pool_cs_variants.log): releasing a slot as soon as its operands are in registers
+    // (a second barrier per step, the stage THREE steps ahead issued into it: 0.259 instead of 0.232 ms -- the launch is bound by
+    // the bytes that reach HBM, 1.28 GB at 5.5 TB/s, not by the bytes in flight).
     s16x4 fb[2][2][2];
-    f16x8 ah0[4], al0[4];
+    f16x8 ah0[4], al0[4], ah1[4], al1[4], bhp[2], blp[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ah0[i] = al0[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) { ah0[i] = al0[i] = ah1[i] = al1[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { bhp[u] = blp[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
     unsigned mP = 0;                                         // fragment mask of the previous step (its groups 4-7 are pending)
-    auto mfma_hi = [&](unsigned m, const CsSet &S) {
+    auto mfma_hi = [&](unsigned m) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
             if (__builtin_expect((m >> (4 + mt)) & 1u, 1)) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(S.ah[mt], S.bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bhp[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(S.ah[mt], S.bl[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], blp[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(S.al[mt], S.bh[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1[mt], bhp[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
             }
     };
+    const bool late = !(ablate & 32) && wv >= 4;            // tuning aid: bit 5 makes every wave issue first
     const bool do_reads = !(ablate & 1);                     // tuning aid: bit 0 skips reads + MFMAs
-    constexpr int UNR = 2 * CS_NST;                          // slots x operand sets
-    for (int s0 = 0; s0 < n; s0 += UNR) {
+    for (int s0 = 0; s0 < n; s0 += CS_NST) {
 #pragma unroll
-        for (int JJ = 0; JJ < UNR; ++JJ) {
-            const int s = s0 + JJ;
-            const int J = JJ % CS_NST;
-            CsSet &C = P[JJ & 1];
-            const CsSet &Q = P[(JJ & 1) ^ 1];
+        for (int J = 0; J < CS_NST; ++J) {
+            const int s = s0 + J;
             if (s < n) {
                 uint64_t st_a = 0, st_b = 0;
                 if constexpr (STAMP) st_a = cs_now();
                 const uint32_t a0 = addr[0] + J * CS_STAGE, a1 = addr[1] + J * CS_STAGE, aw = addr_w + J * CS_STAGE;
                 const unsigned m = mA;
                 if (do_reads) {
-                    // staged rows: fb[col block][plane][rows 8g+q | 8g+q+4]; then the weight fragments
+                    // staged rows: fb[col block][plane][rows 8g+q | 8g+q+4]; weight fragments of groups 0-3
                     cs_tr<0>(fb[0][0][0], a0);
                     cs_tr<4 * CS_RB>(fb[0][0][1], a0);
                     cs_tr<CS_PLANE>(fb[0][1][0], a0);
@@ -412,48 +403,50 @@ cs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
                     if (m & 2u) { cs_rd128<1 * 1024>(ah0[1], aw); cs_rd128<CS_WPL + 1 * 1024>(al0[1], aw); }
                     if (m & 4u) { cs_rd128<2 * 1024>(ah0[2], aw); cs_rd128<CS_WPL + 2 * 1024>(al0[2], aw); }
                     if (m & 8u) { cs_rd128<3 * 1024>(ah0[3], aw); cs_rd128<CS_WPL + 3 * 1024>(al0[3], aw); }
-                    if (m & 16u) { cs_rd128<4 * 1024>(C.ah[0], aw); cs_rd128<CS_WPL + 4 * 1024>(C.al[0], aw); }
-                    if (m & 32u) { cs_rd128<5 * 1024>(C.ah[1], aw); cs_rd128<CS_WPL + 5 * 1024>(C.al[1], aw); }
-                    if (m & 64u) { cs_rd128<6 * 1024>(C.ah[2], aw); cs_rd128<CS_WPL + 6 * 1024>(C.al[2], aw); }
-                    if (m & 128u) { cs_rd128<7 * 1024>(C.ah[3], aw); cs_rd128<CS_WPL + 7 * 1024>(C.al[3], aw); }
-                    mfma_hi(mP, Q);                         // groups 4-7 of the previous step
+                }
+                if (!late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
+                if constexpr (STAMP) if (ablate & 64) st_issue += cs_now() - st_a;
+                if (do_reads) {
+                    mfma_hi(mP);                            // groups 4-7 of the previous step
                     cs_wait_b(fb);
                     cs_wait_a(ah0, al0);
-                    cs_wait_a(C.ah, C.al);
                 }
-                asm volatile("s_barrier" ::: "memory");   // every wave holds its operands of stage s: the slot is free
-                if (s + 3 < n) issue(idv, mD, s + 3, J);
-                if constexpr (STAMP) if (ablate & 64) st_issue += cs_now() - st_a;
                 // scalars of the stage issued in the next step (clamped: never past the block's padded union); they are
-                // waited for right before barrier 2, a whole MFMA batch later
-                const int kn = s + 4 < n ? s + 4 : n - 1;
+                // waited for right before the barrier, a whole MFMA batch later
+                const int kn = s + 3 < n ? s + 3 : n - 1;
                 const i32x4 idn = load_ids(kn);
                 const unsigned mN = mkg[kn];
                 if (do_reads) {
+                    if (m & 16u) { cs_rd128<4 * 1024>(ah1[0], aw); cs_rd128<CS_WPL + 4 * 1024>(al1[0], aw); }
+                    if (m & 32u) { cs_rd128<5 * 1024>(ah1[1], aw); cs_rd128<CS_WPL + 5 * 1024>(al1[1], aw); }
+                    if (m & 64u) { cs_rd128<6 * 1024>(ah1[2], aw); cs_rd128<CS_WPL + 6 * 1024>(al1[2], aw); }
+                    if (m & 128u) { cs_rd128<7 * 1024>(ah1[3], aw); cs_rd128<CS_WPL + 7 * 1024>(al1[3], aw); }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { C.bh[u] = cs_cat(fb[u][0][0], fb[u][0][1]); C.bl[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
+                    for (int u = 0; u < 2; ++u) { bhp[u] = cs_cat(fb[u][0][0], fb[u][0][1]); blp[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
                         if (__builtin_expect((m >> mt) & 1u, 1)) {
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], C.bh[u], acc[mt * 2 + u], 0, 0, 0);
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], C.bl[u], acc[mt * 2 + u], 0, 0, 0);
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], blp[u], acc[mt * 2 + u], 0, 0, 0);
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0[mt], C.bh[u], acc[mt * 2 + u], 0, 0, 0);
+                            for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
                         }
                 }
-                // the scalar loads are waited for HERE, so that no compiler-placed lgkmcnt(0) sits inside the next step
+                if (late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
+                // every LDS read of this stage is in registers before the barrier lets its slot be refilled, and the scalar
+                // loads are waited for HERE, so that no compiler-placed lgkmcnt(0) sits inside the next step
+                cs_wait_a(ah1, al1);
                 asm volatile("" ::"s"(idn.x), "s"(idn.y), "s"(idn.z), "s"(idn.w), "s"(mN));
                 if constexpr (STAMP) { st_b = cs_now(); st_work += st_b - st_a; }
-                // stage s + 1 has landed once at most the DMA of stages s + 2 and s + 3 is outstanding
-                if (s + 3 < n) cs_handover<2 * CS_DMA>(); else if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
+                if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
                 if constexpr (STAMP) st_wait += cs_now() - st_b;
-                mP = m; mA = mB; mB = mC; mC = mD; mD = mN; idv = idn;
+                mP = m; mA = mB; mB = mC; mC = mN; idv = idn;
             }
         }
     }
-    if (do_reads) { if ((n - 1) & 1) mfma_hi(mP, P[1]); else mfma_hi(mP, P[0]); }   // groups 4-7 of the last step
+    if (do_reads) mfma_hi(mP);                               // groups 4-7 of the last step
     if (ablate & 4) return;                                // tuning aid: bit 2 skips the epilogue
     uint64_t st_e0 = 0;
     if constexpr (STAMP) st_e0 = cs_now();

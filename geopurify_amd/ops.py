@@ -454,10 +454,13 @@ def pool_cs_build(nbr, w):
     return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total)
 
 
-def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None):
+def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, engine=False):
     """x_split / out_split: (hi, lo) f16 [Nv, >=d] pairs; out_f32 fp32 [Nv, >=d]; at least one output.
-    out_scale: device scalar multiplied into out_f32 (1/s of a pow2_scale()-scaled x_split)."""
+    out_scale: device scalar multiplied into out_f32 (1/s of a pow2_scale()-scaled x_split).
+    engine: the producer / consumer form of the kernel (same results)."""
     lib = _lib.load()
+    if engine:
+        lib.gp_debug_set(11, 8)
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
     yh, yl = out_split if out_split is not None else (None, None)
@@ -465,6 +468,8 @@ def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None):
                                _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()),
           "gp_pool_cs_apply")
+    if engine:
+        lib.gp_debug_set(11, 0)
     return out_f32 if out_f32 is not None else out_split
 
 

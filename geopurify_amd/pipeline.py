@@ -498,21 +498,42 @@ class HotPath:
 
     def _pool(self, X, nbr, w, Nv, D):
         """Row 12: num_iters applications of the row-stochastic affinity operator (affinity_module.py:1575-1587).
-        pool_mode: "auto" (matrix cores when the shape allows, else tiles, else ELL), "mfma", "tiles", "ell"."""
+        pool_mode: "auto" (matrix cores when the shape allows, else tiles, else ELL), "mfma_cs", "mfma_engine", "mfma",
+        "mfma_persist", "tiles", "ell"."""
         dev = X.device
         mode = self.pool_mode
         mfma_ok = D == 512 and self.pool_block_rows * self.K <= 16384 and self.num_iters >= 1
+        cs_ok = D == 512 and 128 * self.K <= 12288 and self.num_iters >= 1
         R = self.pool_tile_rows
         tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
         if mode == "auto":
-            mode = "mfma" if (mfma_ok and self.num_iters >= 3) else ("tiles" if tiles_ok else "ell")
+            mode = ("mfma_cs" if cs_ok else "mfma") if ((cs_ok or mfma_ok) and self.num_iters >= 3) else ("tiles" if tiles_ok else "ell")
         if mode in ("mfma", "mfma_persist") and not mfma_ok:
             raise ValueError(f"pool_mode='mfma' needs D == 512 and block_rows*K <= 16384 (D={D}, K={self.K})")
-        bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
+        if mode in ("mfma_cs", "mfma_engine") and not cs_ok:
+            raise ValueError(f"pool_mode='{mode}' needs D == 512 and K <= 96 (D={D}, K={self.K})")
         if self.num_iters == 0:
-            bufs[0].copy_(X[:, :D])
+            out = torch.empty((Nv, D), dtype=torch.float32, device=dev)
+            out.copy_(X[:, :D])
             self._pool_kernel = "none"
-            return bufs[0]
+            return out
+        if mode in ("mfma_cs", "mfma_engine"):
+            # column-sliced matrix-core pooling (default): 128-row blocks x 256-column halves, union rows grouped by the 16-row
+            # groups that use them, empty weight fragments skipped (pool_mfma_cs.hip).  "mfma_engine": the producer / consumer
+            # form of the same operator (persistent, 128-column tiles) -- same bits, same speed on MI355X (DESIGN.md section 6).
+            op = ops.pool_cs_build(nbr, w)
+            out = torch.empty((Nv, D), dtype=torch.float32, device=dev)
+            sc = ops.pow2_scale(X, D)
+            sp = [ops.split_f16(X, D, scale=sc[0:1]), tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))]
+            src = sp[0]
+            for t in range(self.num_iters):
+                last = t == self.num_iters - 1
+                dst = None if last else sp[(t + 1) % 2]
+                ops.pool_cs_apply(src, op, D, out_split=dst, out_f32=out if last else None, out_scale=sc[1:2] if last else None,
+                                  engine=mode == "mfma_engine")
+                src = dst
+            self._pool_kernel = "cs_engine_kernel" if mode == "mfma_engine" else "cs_pool_kernel"
+            return out
         if mode in ("mfma", "mfma_persist"):
             # matrix-core pooling: operands stay split (hi, lo) f16 between applications, fp32 only at the end.
             # "mfma" (default): one (64 rows x 128 columns) tile per workgroup, two workgroups per CU.
@@ -540,6 +561,7 @@ class HotPath:
             return out[:Nv]
         use_tiles = mode == "tiles" and tiles_ok
         tiles = ops.pool_tiles_build(nbr, w, R) if use_tiles else None
+        bufs = [torch.empty((Nv, D), dtype=torch.float32, device=dev) for _ in range(2)]
         cur = X
         for t in range(self.num_iters):
             if use_tiles:

@@ -116,7 +116,7 @@ def test_config_v_three_scannet_val_scene_sizes(golden_dir):
         assert batch.scene_coords.shape[0] == n and len(batch.views) >= 10
         F, text, scale = hp.lift_masks(batch, vlm)
         out = hp.refine(batch, F)
-        assert hp.stats["pool_kernel"] == "pool_mfma_kernel" and 0.6 * n < hp.stats["Nv"] <= n
+        assert hp.stats["pool_kernel"] == "cs_pool_kernel" and 0.6 * n < hp.stats["Nv"] <= n
         assert out.shape == (n, 512) and torch.isfinite(out).all()
         # pooling is a convex combination of voxel means of the lifted rows: every column stays inside the lifted range
         assert (out.amax(0) <= F.amax(0) + 1e-5).all() and (out.amin(0) >= F.amin(0) - 1e-5).all()

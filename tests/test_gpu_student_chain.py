@@ -77,7 +77,7 @@ def test_f16x3_student_chain_vs_fp64_oracle(env, hidden, chunk_rows):
     w_got = torch.gather(w.cpu(), 1, got.indices)
     w_exp = torch.gather(w_ref[perm.long().cpu()], 1, exp.indices)
     assert (w_got - w_exp).abs().max().item() <= 2e-6
-    hp = pl.HotPath(st, (8, 8), K=K, num_iters=T, device=dev, pool_mode="mfma")
+    hp = pl.HotPath(st, (8, 8), K=K, num_iters=T, device=dev, pool_mode="auto")      # the benchmarked pooling kernel
     Y = hp._pool(Xd, nbr, w, Nv, D)
     Y_ref = o_aff.pool_gather(X[:, :D], nbr_o, w_ref, T)[perm.long().cpu()]
     p_err = (Y.cpu().double() - Y_ref).abs().max().item()
@@ -148,7 +148,7 @@ def test_small_magnitude_inputs_keep_relative_accuracy(env):
     F = torch.zeros((Nv, 544), device="cuda")
     F[:, :512] = torch.from_numpy((rng.normal(0, 1, size=(Nv, 512)) * 1e-3).astype(np.float32)).cuda()
     ref_p = o_aff.pool_gather(F[:, :512].cpu(), nbr.long().cpu(), w.cpu(), T)
-    for mode in ("mfma", "mfma_persist"):
+    for mode in ("mfma_cs", "mfma_engine", "mfma", "mfma_persist"):
         hp = pl.HotPath(None, (8, 8), K=K, num_iters=T, device="cuda", pool_mode=mode)
         Y = hp._pool(F, nbr, w, Nv, 512)
         rel = (Y.cpu().double() - ref_p).abs().max().item() / ref_p.abs().max().item()
