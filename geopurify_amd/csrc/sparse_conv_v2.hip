@@ -728,7 +728,16 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     // tiles + partial stores), so a memory-bound neighbour only takes bandwidth from it.
     // chunk tables (host copies of the per-chunk tile / pair offsets) give EXACT tile counts; without them tile_count is an
     // upper bound and only the one-tile-per-workgroup kernels (which test tile_start[nseg] on the device) may run
-    const bool chunked = num_chunks >= 1 && chunk_tile_off_host && chunk_pair_off_host;
+    // (The round-2 fault -- a memory access fault in scripts/bench_conv.py and an abort in the unchunked case of
+    // test_f16x3_student_chain_vs_fp64_oracle -- was an experimental persistent phase 1 that walked tile_count tiles without
+    // that device-side test; it was removed in 27fdcb6.  Every kernel launched here tests `mt >= tile_start[nseg]`.)
+    // Half-specified chunking is an error, not a silent fall-back to the upper bound: the caller sized `partial` for chunks.
+    GP_CHECK_ARG((num_chunks >= 1) == (chunk_tile_off_host != nullptr) && (num_chunks >= 1) == (chunk_pair_off_host != nullptr),
+                 "gp_sparse_conv_f16x3: num_chunks=%d needs BOTH host chunk tables (tile and pair offsets), num_chunks=0 needs neither",
+                 num_chunks);
+    GP_CHECK_ARG(num_chunks < 1 || (chunk_rows >= TM && (int64_t)num_chunks * chunk_rows >= nv),
+                 "gp_sparse_conv_f16x3: %d chunks of %d rows do not cover nv=%lld", num_chunks, chunk_rows, (long long)nv);
+    const bool chunked = num_chunks >= 1;
     const int nchunk = chunked ? num_chunks : 1;
     // Measured and left out (round 2): a persistent phase 1 (one workgroup per CU, 3-deep ring for the gathered rows issued two
     // steps ahead, weight tiles one step ahead, split staging roles, rings and epilogue stores running through tile boundaries,

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *__restr
 }
 __global__ void bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
                                     const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean, const float *__restrict__ var,
-                                    float eps, const float *__restrict__ gamma, const float *__restrict__ sums, int64_t nv, int c,
+                                    float eps, const float *__restrict__ gamma, const float *__restrict__ sums, int64_t n_total, int64_t nv, int c,
                                     float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dz_out, int64_t ld_dz) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= nv * c) return;
@@ -116,7 +116,7 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d
     if (act && !(act[r * ld_a + col] > 0.f)) dz = 0.f;
     float invstd = 1.0f / sqrtf(var[col] + eps);
     float xhat = (y[r * ld_y + col] - mean[col]) * invstd;
-    float inv_n = 1.0f / (float)nv;
+    float inv_n = 1.0f / (float)n_total;
     dy[r * ld_dy + col] = gamma[col] * invstd * (dz - sums[col] * inv_n - xhat * sums[c + col] * inv_n);
     if (dz_out) dz_out[r * ld_dz + col] = dz;
 }
@@ -300,6 +300,63 @@ extern "C" int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, f
     return GP_OK;
 }
 
+// fp64 column sums for SyncBatchNorm (run/train.py:212-213 converts the student to MinkowskiSyncBatchNorm): the caller
+// all-reduces them over the ranks.  mean == NULL: out[col] = sum_r y[r][col]; else out[col] = sum_r (y[r][col] - mean[col])^2.
+__global__ void __launch_bounds__(256) cs_final_f64_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c,
+                                                           double *__restrict__ out) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (i < nq * c) {
+        const int q = i / c, col = i % c;
+        for (int64_t k = wv; k < nchunks; k += 4) s += partial[(k * nq + q) * c + col];
+    }
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && i < nq * c) out[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+extern "C" int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, double *out, void *workspace,
+                               size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(y && out && workspace && nv > 0 && c > 0, "gp_col_sums_f64: null/empty argument");
+    if (workspace_bytes < gp_col_stats_workspace_bytes(nv, c)) { gp_set_error("gp_col_sums_f64: workspace too small"); return GP_ENOMEM; }
+    hipStream_t s = gp_stream(stream_);
+    double *partial = static_cast<double *>(workspace);
+    int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
+    dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
+    if (mean) cs_var_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, mean, partial);
+    else cs_sum_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
+    cs_final_f64_kernel<<<(c + 63) / 64, 256, 0, s>>>(partial, nch, 1, c, out);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+// the two reduction vectors of the BatchNorm backward pass as fp64 sums: sums[0:c] = sum dz, sums[c:2c] = sum dz * xhat
+extern "C" int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
+                                  const float *mean, const float *var, float eps, int64_t nv, int32_t c, double *sums,
+                                  void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(dout && y && mean && var && sums && workspace && nv > 0 && c > 0, "gp_bn_bwd_sums_f64: null/empty argument");
+    if (workspace_bytes < gp_col_stats_workspace_bytes(nv, c)) { gp_set_error("gp_bn_bwd_sums_f64: workspace too small"); return GP_ENOMEM; }
+    hipStream_t s = gp_stream(stream_);
+    double *partial = static_cast<double *>(workspace);
+    int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
+    dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
+    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
+    cs_final_f64_kernel<<<(2 * c + 63) / 64, 256, 0, s>>>(partial, nch, 2, c, sums);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+// dy = gamma/sqrt(var+eps) * (dz - sums[col]/n_total - xhat * sums[c+col]/n_total) with caller-supplied (all-reduced) sums
+extern "C" int gp_bn_bwd_apply(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
+                               const float *mean, const float *var, float eps, const float *gamma, const float *sums, int64_t n_total,
+                               int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, void *stream_) {
+    GP_CHECK_ARG(dout && y && mean && var && gamma && sums && dy && nv > 0 && c > 0 && n_total >= nv, "gp_bn_bwd_apply: bad argument");
+    int64_t n = nv * c;
+    bn_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, gp_stream(stream_)>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma,
+                                                                                      sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
 // out = [relu]((y - mean) / sqrt(var + eps) * gamma + beta [+ residual]); optional split copy; optional running-stat update
 extern "C" int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, const float *var,
                                  const float *gamma, const float *beta, float eps, const float *residual, int64_t ld_res,
@@ -335,7 +392,7 @@ extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const fl
     bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
     cs_final_kernel<<<(2 * c + 63) / 64, 256, 0, s>>>(partial, nch, 2, c, 1.0, sums);
     int64_t n = nv * c;
-    bn_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, nv, c,
+    bn_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, nv, nv, c,
                                                                      dy, ld_dy, dz_out, ld_dz);
     GP_CHECK_HIP(hipMemcpyAsync(dbeta, sums, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));
     GP_CHECK_HIP(hipMemcpyAsync(dgamma, sums + c, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -198,7 +198,7 @@ class ConvPairs:
         self.pair_in, self.pair_pos, self.pair_off, self.tile_start = pair_in, pair_pos, seg_off, tile_start
         self.nseg, self.num_pairs, self.nv = nseg, num_pairs, nv
         self.partial = None
-        self.chunk_rows, self.num_chunks, self.chunk_tile_off, self.chunk_pair_off = 0, 1, None, None
+        self.chunk_rows, self.num_chunks, self.chunk_tile_off, self.chunk_pair_off = 0, 0, None, None   # 0 = not chunked
 
 
 def conv_pairs_build(nbr_map, chunk_rows=16384):
@@ -705,6 +705,41 @@ def col_stats(y, c=None):
     var = torch.empty(c, dtype=torch.float32, device=y.device)
     check(lib.gp_col_stats(_ptr(y), y.stride(0), nv, int(c), _ptr(mean), _ptr(var), _ptr(ws), ws.numel(), _stream()), "gp_col_stats")
     return mean, var
+
+
+def col_sums_f64(y, c=None, mean=None):
+    """fp64 column sums of y fp32 [nv, >=c] (mean None) or of (y - mean)^2: the SyncBatchNorm reduction vectors."""
+    lib = _lib.load()
+    nv = y.shape[0]
+    c = y.shape[1] if c is None else c
+    ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c), y.device)
+    out = torch.empty(c, dtype=torch.float64, device=y.device)
+    check(lib.gp_col_sums_f64(_ptr(y), y.stride(0), nv, int(c), _ptr(mean), _ptr(out), _ptr(ws), ws.numel(), _stream()), "gp_col_sums_f64")
+    return out
+
+
+def bn_bwd_sums_f64(dout, act, y, mean, var, eps):
+    """fp64 [2c]: sum dz | sum dz * xhat over this rank's rows (dz = dout masked by act > 0)."""
+    lib = _lib.load()
+    nv, c = y.shape[0], mean.shape[0]
+    ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c), y.device)
+    sums = torch.empty(2 * c, dtype=torch.float64, device=y.device)
+    check(lib.gp_bn_bwd_sums_f64(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y), y.stride(0),
+                                 _ptr(mean), _ptr(var), float(eps), nv, int(c), _ptr(sums), _ptr(ws), ws.numel(), _stream()),
+          "gp_bn_bwd_sums_f64")
+    return sums
+
+
+def bn_bwd_apply(dout, act, y, mean, var, eps, gamma, sums_f32, n_total, want_dz=False):
+    """dy (and dz) of the BatchNorm backward pass from reduction vectors taken over n_total rows (all ranks)."""
+    lib = _lib.load()
+    nv, c = y.shape[0], mean.shape[0]
+    dy = torch.empty((nv, c), dtype=torch.float32, device=y.device)
+    dz = torch.empty((nv, c), dtype=torch.float32, device=y.device) if want_dz else None
+    check(lib.gp_bn_bwd_apply(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y), y.stride(0),
+                              _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(sums_f32), int(n_total), nv, int(c), _ptr(dy), dy.stride(0),
+                              _ptr(dz), dz.stride(0) if dz is not None else 0, _stream()), "gp_bn_bwd_apply")
+    return (dy, dz) if want_dz else dy
 
 
 def bn_train_apply(y, mean, var, gamma, beta, eps, residual=None, relu=True, want_split=False, momentum=0.1,

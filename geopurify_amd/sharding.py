@@ -72,6 +72,53 @@ def allreduce_mean_gradients(grads, group=None):
     return grads
 
 
+def _world(group=None):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def sync_batch_stats(col_sums_fn, n_local, channels, device, group=None):
+    """SyncBatchNorm statistics (run/train.py:212-213: the reference converts the student to MinkowskiSyncBatchNorm, so a
+    BatchNorm layer normalises with the mean / biased variance of the rows of ALL ranks).  Two passes like the single-process
+    kernel (gp_col_stats), each followed by ONE small all-reduce of fp64 [C (+1)]:
+        col_sums_fn(None)  -> fp64 [C] sum of this rank's rows;   all-reduce with the row count  -> global mean
+        col_sums_fn(mean)  -> fp64 [C] sum of squared deviations from the GLOBAL mean; all-reduce -> global biased variance
+    Returns (mean fp32 [C], var fp32 [C], n_total).  Without a process group (or world size 1) the all-reduces are skipped."""
+    import torch.distributed as dist
+    multi = _world(group) > 1
+    t = torch.empty(channels + 1, dtype=torch.float64, device=device)
+    t[:channels] = col_sums_fn(None)
+    t[channels] = float(n_local)
+    if multi:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    n_total = int(round(float(t[channels].item())))
+    mean = (t[:channels] / n_total).float()
+    sq = col_sums_fn(mean).clone()
+    if multi:
+        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
+    var = (sq / n_total).float()
+    return mean, var, n_total
+
+
+def sync_running_stats(running_mean, running_var, mean, var, n_total, momentum):
+    """running <- (1 - m) running + m batch, the batch variance unbiased over the rows of all ranks (torch semantics)."""
+    unbiased = var * (n_total / (n_total - 1.0)) if n_total > 1 else var
+    running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+    running_var.mul_(1.0 - momentum).add_(unbiased, alpha=momentum)
+
+
+def sync_bwd_sums(local_sums_f64, group=None):
+    """The two reduction vectors of the BatchNorm backward pass (sum dz | sum dz * xhat, fp64 [2C]) over all ranks.
+    Returns (global sums fp32 [2C] for the dy formula, local sums fp32 [2C]): the affine gradients dgamma / dbeta stay LOCAL
+    sums -- they are averaged with every other gradient by allreduce_mean_gradients, as DDP does for SyncBatchNorm."""
+    import torch.distributed as dist
+    local = local_sums_f64.float()
+    g = local_sums_f64.clone()
+    if _world(group) > 1:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return g.float(), local
+
+
 def evaluate_sharded(num_scenes, scene_counts_fn, num_classes, device, rank=0, world_size=1, costs=None,
                      policy="contiguous"):
     """Run scene_counts_fn(scene_index, counts) for this rank's scenes, then all-reduce.

@@ -12,9 +12,10 @@ end, holding {'epoch', 'model_state_dict', 'optimizer_state_dict', 'tensorboard_
 Differences, on purpose: scenes, 2D-VLM outputs and the teacher's per-point features are synthetic (no datasets, X-Decoder
 or Sonata offline); with torch.distributed initialised every rank trains on its own scenes (the same number of steps per
 rank) and the student gradients are averaged by ONE bucketed all-reduce per step (sharding.allreduce_mean_gradients)
-instead of DistributedDataParallel hooks.  DEVIATION from the reference's multi-GPU recipe: run/train.py:212-213 converts
-the student to MinkowskiSyncBatchNorm (batch statistics over all ranks); here BatchNorm statistics are per rank (one scene
-each) and rank 0's running statistics are the ones checkpointed.  Single-GPU training (every shipped config) is unaffected.
+instead of DistributedDataParallel hooks.  As in the reference's multi-GPU recipe (run/train.py:212-213 converts the student
+to MinkowskiSyncBatchNorm), BatchNorm statistics and the backward reductions are taken over the rows of ALL ranks: four small
+fp64 all-reduces per BatchNorm layer and step (sharding.sync_batch_stats / sync_bwd_sums), so every rank holds the same
+running statistics.  Single-GPU training (every shipped config) takes the local path.
 """
 import argparse
 import os

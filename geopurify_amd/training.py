@@ -19,7 +19,7 @@ import math
 
 import torch
 
-from . import ops
+from . import ops, sharding
 from .pipeline import CONV_PAD, GEO_DIM, _pad_to
 
 N_MACRO = 48                                   # affinity_module.py:1122
@@ -86,7 +86,7 @@ class StudentTrainer:
     state, and the forward/backward of one scene."""
 
     def __init__(self, state_dict, device="cuda", base_lr=1e-4, weight_decay=1e-5, temperature=0.07, bn_momentum=0.1,
-                 bn_eps=1e-5, warmup_iters=0, main_iters=1):
+                 bn_eps=1e-5, warmup_iters=0, main_iters=1, sync_bn=False, group=None):
         dev = torch.device(device)
         self.device = dev
         sd = {k: v.detach().clone() for k, v in state_dict.items()}
@@ -112,6 +112,9 @@ class StudentTrainer:
         self.opt_state = {}                          # name -> (exp_avg, exp_avg_sq), allocated on the first optimizer step
         self.steps_done = 0
         self.fast = self.hidden % 256 == 0           # f16x3 matrix-core path; else the exact fp32 MFMA kernel
+        # SyncBatchNorm (run/train.py:212-213): statistics and backward reductions over the rows of ALL ranks -- four small
+        # all-reduces per BatchNorm layer and step (sharding.sync_*); without a process group identical to the local path
+        self.sync_bn, self.group = sync_bn, group
 
     # ---- state_dict in the reference layout (input kernel un-padded) -----------------------------------
     def state_dict(self):
@@ -182,11 +185,29 @@ class StudentTrainer:
         mom = self.bn_momentum
 
         def bn_fwd(y, prefix, residual=None, want_split=True):
-            mean, var = ops.col_stats(y)
             rm, rv = (B[prefix + ".bn.running_mean"], B[prefix + ".bn.running_var"]) if update_running else (None, None)
+            if self.sync_bn:
+                c = y.shape[1]
+                mean, var, n_tot = sharding.sync_batch_stats(lambda m: ops.col_sums_f64(y, c, m), y.shape[0], c, dev, self.group)
+                out, sp = ops.bn_train_apply(y, mean, var, P[prefix + ".bn.weight"], P[prefix + ".bn.bias"], self.bn_eps, residual=residual,
+                                             relu=True, want_split=want_split and self.fast, momentum=mom)
+                if rm is not None:
+                    sharding.sync_running_stats(rm, rv, mean, var, n_tot, mom)
+                return out, sp, (mean, var, n_tot)
+            mean, var = ops.col_stats(y)
             out, sp = ops.bn_train_apply(y, mean, var, P[prefix + ".bn.weight"], P[prefix + ".bn.bias"], self.bn_eps, residual=residual,
                                          relu=True, want_split=want_split and self.fast, momentum=mom, running_mean=rm, running_var=rv)
             return out, sp, (mean, var)
+
+        def bn_bwd(dout, act, y, st, gamma, want_dz=False):
+            """(dy, dgamma, dbeta[, dz]); with SyncBatchNorm the dy formula uses the reductions over all ranks"""
+            if self.sync_bn:
+                c = st[0].shape[0]
+                g_sums, l_sums = sharding.sync_bwd_sums(ops.bn_bwd_sums_f64(dout, act, y, st[0], st[1], self.bn_eps), self.group)
+                r = ops.bn_bwd_apply(dout, act, y, st[0], st[1], self.bn_eps, gamma, g_sums, st[2], want_dz=want_dz)
+                dy, dz = r if want_dz else (r, None)
+                return (dy, l_sums[c:].clone(), l_sums[:c].clone(), dz) if want_dz else (dy, l_sums[c:].clone(), l_sums[:c].clone())
+            return ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz)
 
         # ---------------- forward (activations kept for the backward pass)
         saved = []
@@ -210,19 +231,18 @@ class StudentTrainer:
         dh = dE @ P["output_layer.kernel"].t()
         for i in reversed(range(self.num_blocks)):
             h_in, y1, a1, st1, y2, st2, h_out, h_in_s, a1_s = blocks[i]
-            dy2, dg2, db2, dz = ops.bn_train_backward(dh, h_out, y2, st2[0], st2[1], self.bn_eps, P[f"res_blocks.{i}.norm2.bn.weight"],
-                                                      want_dz=True)
+            dy2, dg2, db2, dz = bn_bwd(dh, h_out, y2, st2, P[f"res_blocks.{i}.norm2.bn.weight"], want_dz=True)
             g[f"res_blocks.{i}.norm2.bn.weight"], g[f"res_blocks.{i}.norm2.bn.bias"] = dg2, db2
             gs2 = self._grad_split(dy2) if self.fast else None
             g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, a1_s, dy2, ctx, self.hidden, gs2)
             da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx, gs2)
-            dy1, dg1, db1 = ops.bn_train_backward(da1, a1, y1, st1[0], st1[1], self.bn_eps, P[f"res_blocks.{i}.norm1.bn.weight"])
+            dy1, dg1, db1 = bn_bwd(da1, a1, y1, st1, P[f"res_blocks.{i}.norm1.bn.weight"])
             g[f"res_blocks.{i}.norm1.bn.weight"], g[f"res_blocks.{i}.norm1.bn.bias"] = dg1, db1
             gs1 = self._grad_split(dy1) if self.fast else None
             g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1)
             dh = dz + self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1)
         h0 = blocks[0][0] if self.num_blocks else h
-        dy0, dg0, db0 = ops.bn_train_backward(dh, h0, y0, st0[0], st0[1], self.bn_eps, P["input_layer.1.bn.weight"])
+        dy0, dg0, db0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"])
         g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
         g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad)
         return loss, g, E
@@ -301,8 +321,10 @@ def training_forward(student_module, F_lift, gauss, inds_reconstruct, coords_3d,
     if anchor_indices is None:
         anchor_indices = torch.randperm(N, device=dev)[:A]               # affinity_module.py:1112
     named = dict(student_module.named_parameters())
+    # SyncBatchNorm whenever a process group is up (run/train.py:212-213 converts the student before wrapping it in DDP)
     tr = StudentTrainer(student_module.state_dict(), dev, temperature=temperature,
-                        bn_momentum=student_module.input_layer[1].bn.momentum, bn_eps=student_module.input_layer[1].bn.eps)
+                        bn_momentum=student_module.input_layer[1].bn.momentum, bn_eps=student_module.input_layer[1].bn.eps,
+                        sync_bn=sharding._world() > 1)
     out = tr.scene_step(F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, anchor_indices, num_negatives, K, optimize=False)
     names = [n for n in named if n in out["grads"]]
     grads = []

@@ -372,6 +372,19 @@ int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, i
                          int64_t ld_y, const float *mean, const float *var, float eps, const float *gamma,
                          int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz,
                          float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+/* SyncBatchNorm pieces (run/train.py:212-213 converts the student to MinkowskiSyncBatchNorm; geopurify_amd/sharding.py     */
+/* all-reduces these small vectors over the ranks).  gp_col_sums_f64: mean == NULL -> out[col] = sum_r y[r][col], else         */
+/* out[col] = sum_r (y[r][col] - mean[col])^2 (fp64, fixed order).  gp_bn_bwd_sums_f64: sums[0:c] = sum dz,                    */
+/* sums[c:2c] = sum dz * xhat.  gp_bn_bwd_apply: the dy formula of gp_bn_train_backward with caller-supplied fp32 sums        */
+/* [2c] and the row count n_total they were taken over.  workspace: gp_col_stats_workspace_bytes(nv, c).                     */
+int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, double *out, void *workspace,
+                    size_t workspace_bytes, void *stream);
+int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
+                       const float *mean, const float *var, float eps, int64_t nv, int32_t c, double *sums, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int gp_bn_bwd_apply(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
+                    const float *mean, const float *var, float eps, const float *gamma, const float *sums, int64_t n_total,
+                    int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, void *stream);
 /* InfoNCE (affinity_module.py:1219-1233) forward + backward: samples s -> voxel rows sample_to_voxel[s]; */
 /* point_to_batch i64 [A*(2+Nn)] = sample ids of (anchors | positives | negatives row-major).           */
 /* loss f32 device scalar; de f32 [nv, d] = d loss / d e (overwritten).                                  */

@@ -530,6 +530,25 @@ def test_error_paths(ops):
         ops.pool_ell(x, nbr, w, 512, x)                              # aliasing is rejected
     with pytest.raises(GeoPurifyHipError):
         ops.sparse_conv(x, None, torch.zeros((100, 128), device="cuda"))   # cin not a multiple of 32
+    # half-specified chunking (a chunk count without the host chunk tables) is rejected instead of falling back to the
+    # upper-bound tile count (the branch a C-ABI caller could still reach)
+    rng = np.random.default_rng(3)
+    c = surface_voxels(rng, 600)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    pairs = ops.conv_pairs_build(ops.kernel_map_build(grid, cs), 256)
+    hi, lo = ops.conv_weights_split(torch.randn(27, 32, 256, device="cuda") * 0.05, 1.0)
+    xin = torch.randn(len(c), 32, device="cuda")
+    good = ops.sparse_conv_f16x3(xin, pairs, hi, lo)
+    saved = pairs.chunk_tile_off
+    pairs.chunk_tile_off = None
+    with pytest.raises(GeoPurifyHipError, match="chunk tables"):
+        ops.sparse_conv_f16x3(xin, pairs, hi, lo)
+    pairs.chunk_tile_off = saved
+    pairs.chunk_rows = 128                                             # chunks that do not cover the rows
+    with pytest.raises(GeoPurifyHipError):
+        ops.sparse_conv_f16x3(xin, pairs, hi, lo)
+    pairs.chunk_rows = 256
+    assert torch.equal(ops.sparse_conv_f16x3(xin, pairs, hi, lo), good)
 
 
 # ------------------------------------------------------------------------------------------ row 9 fast path

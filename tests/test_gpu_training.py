@@ -329,3 +329,21 @@ def test_train_driver_loop_and_checkpoints(ops, tmp_path):
     opt2 = td.build_optimizer(model.affinity_student, 1e-3, 1e-5)
     start, sc = td.load_resume(model.affinity_student, opt2, str(tmp_path / "model" / "affinity_predictor_epoch_1.pth"), "cuda")
     assert start == 2 and sc["loss_train"] == scalars["loss_train"]
+
+
+def test_two_rank_sync_batchnorm_training_step(ops):
+    """run/train.py:206-213 (DDP + SyncBatchNorm): two ranks on this box's one GPU (gloo) train on different scenes; the
+    mean loss, the all-reduced gradients and the running statistics equal a single process on the concatenated scene."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "syncbn_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])

@@ -112,6 +112,72 @@ def test_two_rank_gradient_allreduce_is_the_mean():
             assert np.allclose(res[r][k], want[k], atol=1e-6)
 
 
+def _syncbn_worker(rank, world, port, q):
+    """SyncBatchNorm host logic with torch stand-ins for the kernels' fp64 column sums."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7 + rank)
+    n, C = (300, 250)[rank], 24                                           # different row counts per rank
+    y = torch.randn(n, C, generator=g) * (1.0 + rank) + 0.3 * rank
+    dout = torch.randn(n, C, generator=g)
+    eps = 1e-5
+
+    def col_sums(mean):
+        return y.double().sum(0) if mean is None else ((y - mean).double() ** 2).sum(0)
+    mean, var, n_tot = sharding.sync_batch_stats(col_sums, n, C, "cpu")
+    rm, rv = torch.zeros(C), torch.ones(C)
+    sharding.sync_running_stats(rm, rv, mean, var, n_tot, 0.1)
+    xhat = (y - mean) / torch.sqrt(var + eps)
+    local = torch.cat([dout.double().sum(0), (dout.double() * xhat.double()).sum(0)])
+    g_sums, l_sums = sharding.sync_bwd_sums(local)
+    gamma = torch.linspace(0.5, 1.5, C)
+    dy = gamma / torch.sqrt(var + eps) * (dout - g_sums[:C] / n_tot - xhat * g_sums[C:] / n_tot)
+    grads = {"bn.weight": l_sums[C:].clone(), "bn.bias": l_sums[:C].clone()}
+    sharding.allreduce_mean_gradients(grads)
+    q.put((rank, {k: v.numpy().copy() for k, v in dict(mean=mean, var=var, rm=rm, rv=rv, dy=dy, dg=grads["bn.weight"], db=grads["bn.bias"]).items()}, n_tot))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_single_process_over_all_rows():
+    """run/train.py:212-213 (SyncBatchNorm): two ranks with different scenes reproduce single-process BatchNorm over the
+    concatenated rows -- statistics, running statistics (1e-6), dy and the DDP-averaged affine gradients (1e-5)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, d, n_tot = q.get(timeout=120)
+        got[r] = d
+        assert n_tot == 550
+    for p in procs:
+        p.join(timeout=60)
+    ys, douts = [], []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(7 + rank)
+        n, C = (300, 250)[rank], 24
+        ys.append(torch.randn(n, C, generator=g) * (1.0 + rank) + 0.3 * rank)
+        douts.append(torch.randn(n, C, generator=g))
+    Y = torch.cat(ys).double().requires_grad_(True)
+    gamma = torch.linspace(0.5, 1.5, 24).double().requires_grad_(True)
+    beta = torch.zeros(24, dtype=torch.float64, requires_grad=True)
+    rm, rv = torch.zeros(24, dtype=torch.float64), torch.ones(24, dtype=torch.float64)
+    out = torch.nn.functional.batch_norm(Y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    # DDP averages the per-rank losses' gradients: loss = (1/2) sum_r <dout_r, out_r>
+    (out * torch.cat(douts).double()).sum().mul(0.5).backward()
+    for r in range(2):
+        assert np.allclose(got[r]["mean"], Y.detach().mean(0).numpy(), atol=1e-6)
+        assert np.allclose(got[r]["var"], Y.detach().var(0, unbiased=False).numpy(), atol=1e-6)
+        assert np.allclose(got[r]["rm"], rm.numpy(), atol=1e-6) and np.allclose(got[r]["rv"], rv.numpy(), atol=1e-6)
+        assert np.allclose(got[r]["dg"], gamma.grad.numpy(), atol=1e-5) and np.allclose(got[r]["db"], beta.grad.numpy(), atol=1e-5)
+    dy_ref = Y.grad.numpy() * 2.0                                          # d/dY of sum_r <dout_r, out_r>
+    assert np.allclose(np.concatenate([got[0]["dy"], got[1]["dy"]]), dy_ref, atol=1e-5)
+
+
 def test_summary_and_log_lines_match_reference_validate(golden_dir):
     """The running Base/Novel/All numbers and the log strings of the product (sharding.summarize / log_lines on exact
     int64 counts) equal what the reference's validate() logged (tests/golden/ref_validate.npz), line for line."""
