@@ -62,6 +62,70 @@ def scene_based_collate_fn(batch):
             batch_and_mask, torch.cat(inds_rec), torch.cat(unique_map), torch.cat(mapping), captions, point_features[0])
 
 
+def view_sample(locs_in, labels_in, point_features, world_view_transform, intrinsics, depth, image, label_img, *, dataset, img_dim,
+                vis_thres, cut_bound, voxel_size, category_split, split, val_keep, label_2d_ids=None, input_color=False,
+                min_visible=400):
+    """The per-view sample tuple of the reference datasets after the scene cache and the image readers
+    (data_loader_ablation.py:242-394; Matterport: data_loader_matterport.py:190-300) on arrays: the mapper and both
+    voxelizations run on the HIP kernels, np.random is consumed in the reference's order (per-view voxelization, then the
+    whole scene).  `image`: the view's RGB image already at img_dim ([H,W,3], uint8 or float); `label_img`: the 2D label
+    image at img_dim (ScanNet) or None (zeros).  min_visible: the reference's 400; the synthetic T config lowers it.
+    Returns None for a dropped view: no visible point, fewer than min_visible, or more than 65000 (split 'train') /
+    val_keep (other splits) visible points (:254-255, :279-288)."""
+    from .fusion_util import PointCloudToImageMapper, PointCloudToImageMappermatterport
+    from .voxelizer import default_voxelizer
+    mapping = np.ones([locs_in.shape[0], 4], dtype=int)
+    if dataset == "scannet":
+        mapper = PointCloudToImageMapper(img_dim, vis_thres, cut_bound, intrinsics)
+        mapping[:, 1:4], _ = mapper.compute_mapping(world_view_transform, locs_in, depth)
+    else:
+        mapper = PointCloudToImageMappermatterport(img_dim, vis_thres, cut_bound)
+        cam_to_world = np.asarray(world_view_transform).T                  # data_loader_matterport.py:213
+        mapping[:, 1:4] = mapper.compute_mapping(cam_to_world, locs_in, depth, intrinsics)
+    mask = mapping[:, 3]
+    n_vis = int(mask.sum())
+    if n_vis == 0:
+        return None
+    vis = mask == 1
+    unique_map = mapping.copy()
+    mapping = mapping[np.all(mapping != 0, axis=1)]
+    label_3d, feature_3d, locals_3d = labels_in[vis].copy(), point_features[vis].copy(), locs_in[vis].copy()
+    # binary_label IS the array the reference tests while writing into it (:265-274): a base class becomes 1 and is then
+    # compared with the novel list as 1
+    binary = labels_in[vis].copy()
+    binary[np.isin(binary, category_split["base_category"])] = 1
+    binary[np.isin(binary, category_split["novel_category"])] = 0
+    upper = 65000 if split == "train" else val_keep
+    if n_vis < min_visible or n_vis > upper:
+        return None
+    W, H = img_dim
+    if label_img is not None and label_2d_ids is not None:               # ScanNet 2D labels (:297-322)
+        ids = list(label_2d_ids) if split in ("val", "test") else [label_2d_ids[c] for c in category_split["base_category"]]
+        lab2d = np.array(label_img, copy=True).astype(np.int32)
+        lab2d[~np.isin(lab2d, ids)] = 255
+        lut = np.arange(max(256, int(lab2d.max()) + 1))
+        lut[np.asarray(ids, dtype=np.int64)] = np.arange(len(ids))
+        lab2d = lut[lab2d]
+        if split not in ("val", "test"):
+            lab2d[lab2d == 255] = len(category_split["base_category"])
+        label_2d = torch.from_numpy(lab2d).long()
+    else:
+        label_2d = torch.zeros((H, W), dtype=torch.long)
+    vox = default_voxelizer(voxel_size)
+    locs, feats, _, inds_reconstruct = vox.voxelize(locals_3d, feature_3d, label_3d)              # per-view voxelization (:324)
+    coords = torch.cat((torch.ones(locs.shape[0], 1, dtype=torch.int), torch.from_numpy(locs).int()), dim=1)
+    feats = torch.from_numpy(feats[:, :3]).float() / 255.0 if input_color else torch.ones(coords.shape[0], 3)
+    scene_locs, _, _, scene_inv = vox.voxelize(locs_in, point_features, labels_in)                # whole scene (:364)
+    locals_t = torch.from_numpy(locals_3d).float()
+    return (torch.from_numpy(locs_in).float(), torch.from_numpy(scene_locs).float(), torch.from_numpy(scene_inv).long(),
+            torch.from_numpy(labels_in).long(), torch.cat((torch.ones(locals_t.shape[0], 1), locals_t), dim=1), coords, feats,
+            torch.from_numpy(feature_3d).float(), torch.from_numpy(label_3d).long(), torch.from_numpy(binary).float(),
+            label_2d, torch.from_numpy(np.asarray(image)).float(),
+            torch.from_numpy(mapping[:, 1][mapping[:, 1] != 0]).long(), torch.from_numpy(mapping[:, 2][mapping[:, 2] != 0]).long(),
+            torch.from_numpy(mask).bool(), torch.from_numpy(inds_reconstruct).long(), torch.from_numpy(unique_map).long(),
+            torch.from_numpy(mapping), None, torch.from_numpy(point_features).float())
+
+
 class ScannetLoaderFull(Dataset):
     """(scene, view) samples of synthetic ScanNet-/Matterport-shaped scenes behind the reference's constructor.
 
@@ -111,45 +175,15 @@ class ScannetLoaderFull(Dataset):
         return self.scene_cache[name]
 
     def __getitem__(self, index_long):
-        """The per-view sample tuple of data_loader_ablation.py:373-394 (None when the view is dropped, :254-255,280-288)."""
-        from .fusion_util import PointCloudToImageMapper, PointCloudToImageMappermatterport
-        from .voxelizer import default_voxelizer
+        """The per-view sample tuple of data_loader_ablation.py:373-394 (None when the view is dropped, :254-255,279-288)."""
         s = self.samples[index_long % len(self.samples)]
         scene, cfg = self._scene(s["scene_name"]), self.cfg
         view = scene.views[s["view_idx"]]
-        locs_in = scene.coords
-        labels_in = scene.labels.copy()
         point_features = np.concatenate([scene.colors, scene.normals], 1)        # rgb in [0,1] ++ normal (:163,214)
-        mapping = np.ones([locs_in.shape[0], 4], dtype=int)
-        if cfg.dataset == "scannet":
-            mapper = PointCloudToImageMapper(cfg.image_dim, cfg.vis_thres, cfg.cut_bound, view.K)
-            mapping[:, 1:4], _ = mapper.compute_mapping(view.pose, locs_in, view.depth)
-        else:
-            mapper = PointCloudToImageMappermatterport(cfg.image_dim, cfg.vis_thres, cfg.cut_bound)
-            mapping[:, 1:4] = mapper.compute_mapping(view.pose, locs_in, view.depth, view.K)
-        mask = mapping[:, 3]
-        n_vis = int(mask.sum())
-        if n_vis == 0 or n_vis < cfg.min_visible or n_vis > self.val_keep:
-            return None
-        vis = mask == 1
-        unique_map = mapping.copy()
-        mapping = mapping[np.all(mapping != 0, axis=1)]
-        label_3d, feature_3d, locals_3d = labels_in[vis].copy(), point_features[vis].copy(), locs_in[vis].copy()
-        binary = label_3d.copy()
-        binary[np.isin(label_3d, self.category_split["base_category"])] = 1
-        binary[np.isin(label_3d, self.category_split["novel_category"])] = 0
-        vox = default_voxelizer(self.voxel_size)
-        locs, feats, _, inds_reconstruct = vox.voxelize(locals_3d, feature_3d, label_3d)          # per-view voxelization (:324)
-        coords = torch.cat((torch.ones(locs.shape[0], 1, dtype=torch.int), torch.from_numpy(locs).int()), dim=1)
-        feats = torch.from_numpy(feats[:, :3]).float() / 255.0 if self.input_color else torch.ones(coords.shape[0], 3)
-        scene_locs, _, _, scene_inv = vox.voxelize(locs_in, point_features, labels_in)            # whole scene (:364)
         W, H = cfg.image_dim
-        img = torch.full((H, W, 3), float(s["view_idx"]))              # no RGB offline: the view index, for the VLM stand-in
-        locals_t = torch.from_numpy(locals_3d).float()
-        return (torch.from_numpy(locs_in).float(), torch.from_numpy(scene_locs).float(), torch.from_numpy(scene_inv).long(),
-                torch.from_numpy(labels_in).long(), torch.cat((torch.ones(locals_t.shape[0], 1), locals_t), dim=1), coords, feats,
-                torch.from_numpy(feature_3d).float(), torch.from_numpy(label_3d).long(), torch.from_numpy(binary).float(),
-                torch.zeros((H, W), dtype=torch.long), img,
-                torch.from_numpy(mapping[:, 1][mapping[:, 1] != 0]).long(), torch.from_numpy(mapping[:, 2][mapping[:, 2] != 0]).long(),
-                torch.from_numpy(mask).bool(), torch.from_numpy(inds_reconstruct).long(), torch.from_numpy(unique_map).long(),
-                torch.from_numpy(mapping), None, torch.from_numpy(point_features).float())
+        img = np.full((H, W, 3), float(s["view_idx"]), dtype=np.float32)   # no RGB offline: the view index, for the VLM stand-in
+        wvt = view.pose if cfg.dataset == "scannet" else np.ascontiguousarray(view.pose.T)   # Matterport poses are camera-to-world
+        return view_sample(scene.coords, scene.labels.copy(), point_features, wvt, view.K, view.depth, img, None,
+                           dataset=cfg.dataset, img_dim=cfg.image_dim, vis_thres=cfg.vis_thres, cut_bound=cfg.cut_bound,
+                           voxel_size=self.voxel_size, category_split=self.category_split, split=self.split, val_keep=self.val_keep,
+                           label_2d_ids=None, input_color=self.input_color, min_visible=cfg.min_visible)

@@ -78,3 +78,49 @@ def view_sample(locs_in, labels_in, point_features, world_view_transform, intrin
             locals_out, coords, feats_out, feature_3d.astype(np.float32), label_3d.astype(np.int64), binary.astype(np.float32),
             lab2d.astype(np.int64), img, x_label.astype(np.int64), y_label.astype(np.int64), mask.astype(bool),
             inds_reconstruct.astype(np.int64), unique_map.astype(np.int64), mapping, None, point_features.astype(np.float32))
+
+
+def fused_feature_item(locs_in, cols, labs, processed, *, split, voxel_size, n_occur=1, input_color=True, eval_all=True):
+    """dataset/feature_loader.py:66-218 after the file reads (memcache off, aug off): `processed` is the dict of the chosen
+    fused-feature file (picked by np.random.randint(n_occur) when n_occur > 1, consumed here in the reference's order).
+    Returns (coords i32 [Nv,4], feats f32, labels i64, feat_3d, mask bool[, inds_reconstruct i64]) as numpy arrays."""
+    labels_in = np.array(labs, copy=True)
+    labels_in[labels_in == -100] = 255
+    labels_in = labels_in.astype(np.uint8)
+    feats_in = (np.asarray(cols) + 1.0) * 127.5
+    if n_occur > 1:
+        np.random.randint(n_occur)                           # (the caller has already resolved `processed` with the same draw)
+    two_key = len(processed) == 2
+    if two_key:
+        feat_3d, mask_chunk = np.asarray(processed["feat"]), np.asarray(processed["mask_full"]).astype(bool)
+        mask = mask_chunk.copy()
+        if split != "train":
+            full = np.zeros((locs_in.shape[0], feat_3d.shape[1]), dtype=feat_3d.dtype)
+            full[mask] = feat_3d
+            feat_3d, mask_chunk = full, np.ones_like(mask_chunk)
+    else:
+        feat_3d, mask_chunk = np.asarray(processed["feat"]), np.asarray(processed["mask_full"]).astype(bool).copy()
+        mask = np.zeros(feat_3d.shape[0], dtype=bool)
+        mask[np.asarray(processed["mask"])] = True
+    if feat_3d.ndim > 2:
+        feat_3d = feat_3d[..., 0]
+    if split == "train":
+        if not two_key:
+            feat_3d = feat_3d[mask]
+            sub = mask_chunk.copy()
+            mask_chunk[sub] = mask                           # only the visible chunk points keep a feature row
+        locs, feats, labels, inv, vox_ind = voxelize.voxelize(locs_in.astype(np.float64), feats_in, labels_in, voxel_size)
+        mask = mask_chunk[vox_ind]
+        rank = np.cumsum(mask_chunk.astype(np.int64)) - 1    # row in feat_3d of every chunk point
+        feat_3d = feat_3d[rank[vox_ind[mask_chunk[vox_ind]]]]
+    else:
+        locs, feats, labels, inv, vox_ind = voxelize.voxelize(locs_in[mask_chunk].astype(np.float64), feats_in[mask_chunk],
+                                                              labels_in[mask_chunk], voxel_size)
+        feat_3d = feat_3d[vox_ind]
+        mask = mask[vox_ind]
+    if eval_all:
+        labels = labels_in
+    coords = np.concatenate([np.ones((locs.shape[0], 1), np.int32), locs.astype(np.int32)], axis=1)
+    feats = (feats.astype(np.float32) / 127.5 - 1.0) if input_color else np.ones((coords.shape[0], 3), np.float32)
+    out = (coords, feats.astype(np.float32), labels.astype(np.int64), feat_3d, mask)
+    return out + (inv.astype(np.int64),) if eval_all else out

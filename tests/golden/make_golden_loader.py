@@ -96,11 +96,19 @@ _torch_load = torch.load
 torch.load = lambda *a, **k: _torch_load(*a, **{**k, "weights_only": False})
 
 
-def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp):
+def case_config(dataset, n_points, num_views):
+    """the synthetic scene shape of a fixture case (also used by the tests to regenerate the train-rule scene)"""
     import dataclasses
     base = syn.CONFIGS["T"]
-    cfg = dataclasses.replace(base, num_points=n_points, num_views=num_views, dataset=dataset,
-                              depth_scale=1000.0 if dataset == "scannet" else 4000.0)
+    if dataset == "scannet":
+        return dataclasses.replace(base, num_points=n_points, num_views=num_views, dataset=dataset, depth_scale=1000.0)
+    # Matterport intrinsics are given at image_dim and do not scale with it: a 640 x 512 image keeps a useful field of view
+    return dataclasses.replace(base, num_points=n_points, num_views=num_views, dataset=dataset, depth_scale=4000.0,
+                               image_dim=(640, 512), mask_shape=(512, 640), cut_bound=2)
+
+
+def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp, store_images=True):
+    cfg = case_config(dataset, n_points, num_views)
     scene = syn.make_scene(cfg, seed)
     rng = np.random.default_rng(seed)
     W, H = cfg.image_dim
@@ -126,7 +134,7 @@ def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp):
     for i, v in enumerate(scene.views):
         img_path = os.path.join(tmp, "2d", name, "color", f"{i}.jpg") if dataset == "scannet" else \
             os.path.join(tmp, "2d", name, "color", f"uuid{i:04d}_i1_{i % 6}.jpg")
-        image = torch.from_numpy(rng.random((3, H, W)).astype(np.float32))
+        image = torch.from_numpy(np.random.default_rng(7000 + i).random((3, H, W)).astype(np.float32))
         depth_units = np.round(v.depth * cfg.depth_scale).astype(np.uint16)
         if dataset == "scannet":
             IMAGES[img_path.replace("color", "depth").replace("jpg", "png")] = depth_units
@@ -146,8 +154,10 @@ def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp):
         infos.append(types.SimpleNamespace(intrinsics=intr))
         inputs[f"v{i}_world_view_transform"] = wvt.numpy().copy()
         inputs[f"v{i}_intrinsics"] = np.asarray(intr, dtype=np.float64)
-        inputs[f"v{i}_depth_used"] = depth_units / cfg.depth_scale
-        inputs[f"v{i}_image_u8"] = (image.permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+        inputs[f"v{i}_depth_units"] = depth_units                  # the loader divides by 1000 (ScanNet) / fusion.depth_scale
+        inputs[f"v{i}_image_seed"] = np.int64(7000 + i)          # image = default_rng(seed).random((3, H, W)) as float32
+        if store_images:
+            inputs[f"v{i}_image_u8"] = (image.permute(1, 2, 0).numpy() * 255).astype(np.uint8)
     views.camera_info = infos
     _Scene.registry[name] = views
     split_cfg = AttrDict(base_category=[0, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 15, 17, 18, 19], novel_category=[1, 4, 6, 10, 16],
@@ -164,7 +174,7 @@ def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp):
                            scene_config=scene_cfg)
     assert len(ds.samples) == num_views
     out = dict(inputs)
-    out.update(dataset=dataset, split=split, num_views=np.int64(num_views), val_keep=np.int64(val_keep), voxel_size=cfg.voxel_size,
+    out.update(dataset=dataset, split=split, depth_scale=np.float64(cfg.depth_scale), num_views=np.int64(num_views), val_keep=np.int64(val_keep), voxel_size=cfg.voxel_size,
                img_dim=np.array(cfg.image_dim), vis_thres=cfg.vis_thres, cut_bound=np.int64(cfg.cut_bound), label_2d_ids=np.array(label_ids),
                base_category=np.array(split_cfg.base_category), novel_category=np.array(split_cfg.novel_category),
                ignore_category=np.array(split_cfg.ignore_category))
@@ -176,7 +186,7 @@ def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp):
         kept.append(r is not None)
         if r is not None:
             for j, x in enumerate(r):
-                if x is not None:
+                if x is not None and (store_images or j not in (10, 11)):
                     out[f"v{i}_out_{j}"] = x.numpy() if torch.is_tensor(x) else np.asarray(x)
     out["kept"] = np.array(kept)
     return out, kept
@@ -185,7 +195,7 @@ def make_case(dataset, split, seed, n_points, num_views, val_keep, tmp):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         # ScanNet, val: one view below 400 visible points (camera looking at a corner), one above val_keep
-        out, kept = make_case("scannet", "val", 31, 5000, 5, 1400, tmp)
+        out, kept = make_case("scannet", "val", 31, 5000, 5, 470, tmp)
         print("scannet val kept:", kept, "visible:", [int(out[f"v{i}_out_14"].sum()) if k else None for i, k in enumerate(kept)])
         assert any(kept) and not all(kept)
         np.savez_compressed(os.path.join(HERE, "ref_loader_scannet.npz"), **out)
@@ -193,18 +203,22 @@ def main():
         if k.startswith("dataset.data_loader"):
             del sys.modules[k]
     with tempfile.TemporaryDirectory() as tmp:
-        out, kept = make_case("matterport", "val", 47, 5000, 4, 10_000_000, tmp)
-        print("matterport val kept:", kept)
+        # Matterport, val: view 1 below 400 visible points, view 3 above val_keep (images are regenerated from their seeds)
+        out, kept = make_case("matterport", "val", 47, 8000, 5, 1500, tmp, store_images=False)
+        print("matterport val kept:", kept, "visible:", [int(out[f"v{i}_out_14"].sum()) if k else None for i, k in enumerate(kept)])
+        assert any(kept) and not all(kept)
         np.savez_compressed(os.path.join(HERE, "ref_loader_matterport.npz"), **out)
     with tempfile.TemporaryDirectory() as tmp:
-        # train rule (400 .. 65000 visible points): a 90k-point scene; only the keep / drop decisions and counts are stored
+        # train rule (400 .. 65000 visible points, :279-281): a 700k-point scene whose views see up to ~90k points; only the
+        # keep / drop decisions are stored (the tests regenerate the scene from its seed)
         _Scene.registry.clear()
         from dataset.data_loader_ablation import ScannetLoaderFull  # noqa: F401
-        out, kept = make_case("scannet", "train", 53, 90_000, 4, 10_000_000, tmp)
+        out, kept = make_case("scannet", "train", 53, 700_000, 3, 10_000_000, tmp, store_images=False)
+        assert any(kept) and not all(kept)
         small = {k: v for k, v in out.items() if not k.startswith("v") or k.endswith(("_world_view_transform", "_intrinsics", "_np_seed"))}
         small["kept"] = np.array(kept)
         print("scannet train kept:", kept)
-        small["seed"], small["n_points"] = np.int64(53), np.int64(90_000)
+        small["seed"], small["n_points"] = np.int64(53), np.int64(700_000)
         np.savez_compressed(os.path.join(HERE, "ref_loader_train_rule.npz"), **{k: v for k, v in small.items() if k not in ("locs_in", "feats_in", "normals", "labels_in")})
     print("ok")
 

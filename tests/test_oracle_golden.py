@@ -245,3 +245,97 @@ def test_validate_tail_matches_reference(golden_dir):
     assert lines == [str(s) for s in g["log_lines"]]
     s = meters.summary()
     assert np.float32(s["Base"]["mIoU"]) == np.float32(g["result"][0]) and np.float32(s["Novel"]["mIoU"]) == np.float32(g["result"][1])
+
+
+# ------------------------------------------------------------------------------------------ dataset __getitem__ (row 4)
+def _loader_case(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    split = {"base_category": g["base_category"].tolist(), "novel_category": g["novel_category"].tolist(),
+             "ignore_category": g["ignore_category"].tolist()}
+    kw = dict(dataset=str(g["dataset"]), img_dim=tuple(int(v) for v in g["img_dim"]), vis_thres=float(g["vis_thres"]),
+              cut_bound=int(g["cut_bound"]), voxel_size=float(g["voxel_size"]), category_split=split, split=str(g["split"]),
+              val_keep=int(g["val_keep"]), label_2d_ids=g["label_2d_ids"].tolist())
+    return g, kw
+
+
+def _loader_view_inputs(g, i, dataset, H, W):
+    depth = g[f"v{i}_depth_units"] / float(g["depth_scale"])
+    if f"v{i}_image_u8" in g:
+        img = g[f"v{i}_image_u8"]
+    else:
+        im = np.random.default_rng(int(g[f"v{i}_image_seed"])).random((3, H, W)).astype(np.float32)
+        img = (im.transpose(1, 2, 0) * 255).astype(np.uint8)
+    lab = g[f"v{i}_label_img"] if dataset == "scannet" else None
+    return depth, img, lab
+
+
+@pytest.mark.parametrize("name", ["ref_loader_scannet.npz", "ref_loader_matterport.npz"])
+def test_loader_getitem_vs_reference_fixture(golden_dir, name):
+    """oracle/loader.py against the reference's own ScannetLoaderFull.__getitem__ (data_loader_ablation.py:128-394,
+    data_loader_matterport.py:144-300): every slot of the per-view tuple bit for bit, the view-drop rule included (one
+    view below 400 visible points, one above val_keep)."""
+    from oracle import loader as o_loader
+    g, kw = _loader_case(golden_dir, name)
+    pf, labels = o_loader.scene_prepare(g["locs_in"], g["feats_in"], g["normals"], g["labels_in"], kw["category_split"]["ignore_category"][-1])
+    W, H = kw["img_dim"]
+    kept = g["kept"].tolist()
+    assert any(kept) and not all(kept)
+    for i in range(int(g["num_views"])):
+        depth, img, lab = _loader_view_inputs(g, i, kw["dataset"], H, W)
+        np.random.seed(int(g[f"v{i}_np_seed"]))
+        r = o_loader.view_sample(g["locs_in"], labels, pf, g[f"v{i}_world_view_transform"], g[f"v{i}_intrinsics"], depth, img, lab, **kw)
+        assert (r is not None) == kept[i], (i, kept[i])
+        if r is None:
+            continue
+        for j, x in enumerate(r):
+            key = f"v{i}_out_{j}"
+            if x is None or key not in g:
+                assert j in (10, 11, 18)
+                continue
+            want = g[key]
+            assert x.shape == want.shape and np.array_equal(np.asarray(x, dtype=want.dtype), want), (i, j)
+
+
+def test_loader_train_rule_vs_reference_fixture(golden_dir):
+    """split == 'train' drops views with fewer than 400 or MORE THAN 65000 visible points (data_loader_ablation.py:279-281,
+    ADVICE r2): the reference's keep / drop decisions on a 700k-point scene, regenerated here from its seed."""
+    import importlib.util
+    from oracle import loader as o_loader
+    spec = importlib.util.spec_from_file_location("mgl", os.path.join(golden_dir, "make_golden_loader.py"))
+    g = np.load(os.path.join(golden_dir, "ref_loader_train_rule.npz"))
+    from geopurify_amd import synthetic as syn
+    import dataclasses
+    cfg = dataclasses.replace(syn.CONFIGS["T"], num_points=int(g["n_points"]), num_views=int(g["num_views"]), dataset="scannet",
+                              depth_scale=1000.0)
+    scene = syn.make_scene(cfg, int(g["seed"]))
+    from oracle import project
+    kept = []
+    for i, v in enumerate(scene.views):
+        assert np.array_equal(np.asarray(v.pose), g[f"v{i}_world_view_transform"])
+        depth = np.round(v.depth * 1000.0).astype(np.uint16) / 1000.0
+        K = project.scannet_intrinsics(cfg.image_dim, v.K)
+        m, _ = project.compute_mapping_scannet(v.pose, scene.coords, depth, K, cfg.image_dim, cfg.cut_bound, cfg.vis_thres)
+        n = int(m[:, 2].sum())
+        kept.append(400 <= n <= 65000)
+    assert kept == g["kept"].tolist() and not all(kept)
+
+
+@pytest.mark.parametrize("case", ["val_2key", "val_3key", "train_2key", "train_3key"])
+def test_fused_feature_loader_vs_reference_fixture(golden_dir, case):
+    """oracle/loader.fused_feature_item against the reference's own FusedFeatureLoader.__getitem__
+    (dataset/feature_loader.py:66-218): 2-key and 3-key feature files, train and val, eval_all, bit for bit."""
+    from oracle import loader as o_loader
+    g = np.load(os.path.join(golden_dir, "ref_feature_loader.npz"))
+    split, form = case.split("_")
+    np.random.seed(int(g["np_seed"]))
+    if form == "2key":
+        k = np.random.randint(2)                               # feature_loader.py:100: two occurrence files
+        processed = {"feat": g[f"feat2_{k}"], "mask_full": g["mask_full"]}
+        np.random.seed(int(g["np_seed"]))
+        r = o_loader.fused_feature_item(g["locs"], g["cols"], g["labs"], processed, split=split, voxel_size=float(g["voxel_size"]), n_occur=2)
+    else:
+        processed = {"feat": g["feat3"], "mask": g["mask_visible"], "mask_full": g["mask_full"]}
+        r = o_loader.fused_feature_item(g["locs"], g["cols"], g["labs"], processed, split=split, voxel_size=float(g["voxel_size"]), n_occur=1)
+    for j, x in enumerate(r):
+        want = g[f"{case}_out_{j}"]
+        assert x.shape == want.shape and np.array_equal(np.asarray(x, dtype=want.dtype), want), (case, j)
