@@ -44,7 +44,10 @@ def parse():
                     help="cpu_baseline: one whole scene of the workload through the oracle (measured, ~1 min at S) or the "
                          "bounded sub-sampled scene extrapolated per stage")
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
-    ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma", "mfma_persist", "tiles", "ell"])
+    ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma_cs", "mfma_engine", "mfma", "mfma_persist", "tiles", "ell"])
+    ap.add_argument("--api", default="both", choices=["device", "both"],
+                    help="both: after the headline run also time the DROP-IN call SonataXAffinityTrainer.evaluate_scene(20-tuple of "
+                         "CPU tensors) (run/validation.py:408), reported as the extra object `api_tuple` -- never as `value`")
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
     ap.add_argument("--streams", type=int, default=2, help="--schedule alternate: HIP streams that consecutive scenes alternate over "
                     "(1 = everything on one stream); --schedule split always uses two")
@@ -121,6 +124,79 @@ def training_step_rate(batch, dev, sd, steps=6):
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(1.0 / dt, 3), "unit": "optimizer steps/s (1 scene per step)", "ms_per_step": round(dt * 1e3, 2),
             "sampled_voxels": int(o["num_voxels"]), "loss": round(float(o["loss"]), 4), "data": "synthetic teacher + lifted features"}
+
+
+def api_tuple_rate(batches, vlms, sd, cfg, pool_iters, dev, steps=4):
+    """Throughput of the drop-in entry point itself (run/validation.py:408-411): the reference's DataLoader hands
+    `evaluate_scene` the positional 20-tuple of CPU tensors (scene_based_collate_fn).  The same scenes as the headline run,
+    as pinned-host tuples (points, colours + normals, labels, per-view lists, the [V*N,2] visibility table, the V RGB images:
+    the host -> device copy is part of the call), through geopurify_amd.affinity_module.SonataXAffinityTrainer:
+      serial      evaluate_scene(cpu tuple): copy, parse, lift, refine one after the other on one stream;
+      prefetched  the next scene's tuple is copied on a second stream while this scene runs (what a DataLoader with
+                  pin_memory + a device prefetcher gives), evaluate_scene receives the device tuple.
+    Loader math (projection, voxelization) is NOT inside: the tuple already carries its results, as in the reference."""
+    import types
+    from geopurify_amd.affinity_module import SonataXAffinityTrainer
+    ns = types.SimpleNamespace(all_label=[f"c{i}" for i in range(cfg.num_classes)], mask_shape=list(cfg.mask_shape), voxel_size=cfg.voxel_size)
+    model = SonataXAffinityTrainer(ns, None, None, device="cuda", use_lseg=False, vlm=vlms[0], feature_dim=cfg.feat_dim).to(dev)
+    model.affinity_student.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    model.num_pool_iters = pool_iters
+    model.eval()
+    tuples, nbytes = [], 0
+    H, W = cfg.mask_shape
+    for b in batches:
+        raw = list(b.as_tuple())
+        if not (torch.is_tensor(raw[11]) and raw[11].numel()):           # slot 11: the V RGB images the 2D VLM is run on (:496)
+            raw[11] = torch.stack([torch.full((H, W, 3), float(i)) for i in range(len(b.views))])
+        t = tuple(x.cpu().pin_memory() if torch.is_tensor(x) else x for x in raw)
+        nbytes = sum(x.numel() * x.element_size() for x in t if torch.is_tensor(x))
+        tuples.append(t)
+    n = len(tuples)
+
+    def run(i, tup):
+        model.vlm = vlms[i % n]
+        return model.evaluate_scene(tup)
+    for i in range(2):
+        run(i, tuples[i % n])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run(i, tuples[i % n])
+    torch.cuda.synchronize()
+    serial = (time.perf_counter() - t0) / steps
+    copy_stream = torch.cuda.Stream()
+
+    def upload(tup):
+        with torch.cuda.stream(copy_stream):
+            d = tuple(x.to(dev, non_blocking=True) if torch.is_tensor(x) else x for x in tup)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        return d, ev
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(copy_stream)
+    d, ev = upload(tuples[0])
+    e1.record(copy_stream)
+    torch.cuda.synchronize()
+    h2d_ms = e0.elapsed_time(e1)
+    nxt = upload(tuples[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        d, ev = nxt
+        torch.cuda.current_stream().wait_event(ev)
+        if i + 1 < steps:
+            nxt = upload(tuples[(i + 1) % n])
+        for x in d:
+            if torch.is_tensor(x):
+                x.record_stream(torch.cuda.current_stream())
+        run(i, d)
+    torch.cuda.synchronize()
+    pref = (time.perf_counter() - t0) / steps
+    return {"entry_point": "geopurify_amd.affinity_module.SonataXAffinityTrainer.evaluate_scene(20-tuple), run/validation.py:408",
+            "serial": {"value": round(1.0 / serial, 3), "unit": "scenes/s", "ms_per_scene": round(serial * 1e3, 3)},
+            "prefetched": {"value": round(1.0 / pref, 3), "unit": "scenes/s", "ms_per_scene": round(pref * 1e3, 3)},
+            "h2d_ms": round(h2d_ms, 3), "tuple_mbytes": round(nbytes / 1e6, 1), "steps": steps,
+            "note": "pinned host tuples; loader math is not inside (the tuple carries its results); never the headline `value`"}
 
 
 def pmc_traffic(kernel, nv):
@@ -604,6 +680,15 @@ def main():
                 out["training_step"] = training_step_rate(last, dev, sd)
             except Exception as e:
                 out["training_step"] = {"value": None, "error": repr(e)}
+        if args.api == "both" and world == 1 and not val_mode and not cfg.dense_features and args.scenes:
+            try:                                  # an extra; never lose the headline line over it
+                log("drop-in entry point: evaluate_scene(20-tuple of CPU tensors)")
+                with torch.cuda.stream(streams[0]):
+                    bts = [pl.build_scene_batch(scenes[j], rigids[j], dev, batch_views=False) for j in range(min(args.scenes, 2))]
+                torch.cuda.synchronize()
+                out["api_tuple"] = api_tuple_rate(bts, vlms, sd, cfg, args.pool_iters, dev)
+            except Exception as e:
+                out["api_tuple"] = {"value": None, "error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (the oracle on the host cores)")
             try:

@@ -164,10 +164,16 @@ class SonataXAffinityTrainer(nn.Module):
         self.info_nce_temperature = 0.07          # :279
 
     def _hot_path(self):
+        """The device pipeline of this trainer, kept across scenes (its resize tap tables, 15 ms of host work per mask shape,
+        and the student's device weights are built once) and rebuilt when the weights or the options change."""
         dev = torch.device(self.device if self.device != "cuda" else f"cuda:{torch.cuda.current_device()}")
         st = self.affinity_student.device_weights(dev)
-        return HotPath(st, tuple(self.cfg["mask_shape"] if isinstance(self.cfg, dict) else self.cfg.mask_shape),
-                       K=self.K, sharpen=float(self.affinity_sharpen_factor), num_iters=self.num_pool_iters, device=dev)
+        shape = tuple(self.cfg["mask_shape"] if isinstance(self.cfg, dict) else self.cfg.mask_shape)
+        key = (id(st), shape, self.K, float(self.affinity_sharpen_factor), self.num_pool_iters, str(dev))
+        if getattr(self, "_hp_key", None) != key:
+            self._hp = HotPath(st, shape, K=self.K, sharpen=float(self.affinity_sharpen_factor), num_iters=self.num_pool_iters, device=dev)
+            self._hp_key = key
+        return self._hp
 
     @staticmethod
     def _batch_from_tuple(batch_data, device):
@@ -176,19 +182,36 @@ class SonataXAffinityTrainer(nn.Module):
          _l2, imgs, x_labels, y_labels, mask_2ds, _ir, _um, _mp, _cap, scene_gauss_features) = batch_data
         dev = torch.device(device)
         N = scene_coords.shape[0]
-        mask_2ds = mask_2ds.to(dev)
+        nb = True                                                # (pinned host tensors copy asynchronously)
+        mask_2ds = mask_2ds.to(dev, non_blocking=nb)
         V = int(mask_2ds.shape[0] // N)
         imgs = imgs if torch.is_tensor(imgs) and imgs.dim() == 4 and imgs.shape[0] == V else None   # slot 11: what the VLM sees
-        vis = mask_2ds[:, 1].view(V, N).bool()
-        view_of = ori_coords_3ds[:, 0].to(dev).long()
-        x_labels, y_labels = x_labels.to(dev), y_labels.to(dev)
-        views = []
+        x_labels, y_labels = x_labels.to(dev, non_blocking=nb), y_labels.to(dev, non_blocking=nb)
+        # The collate concatenates the views in order, so the rows of view i are one contiguous range of x_labels / y_labels /
+        # ori_coords_3ds and the visible flags of mask_2ds in view-major order name their points in the same order: ONE
+        # nonzero + ONE bincount + ONE host read-back instead of three launches and a sync per view.
+        flat = torch.nonzero(mask_2ds[:, 1]).squeeze(1)            # view * N + point, ascending
+        view_of = ori_coords_3ds[:, 0].to(dev, non_blocking=nb).long()
+        counts = torch.bincount(view_of, minlength=V)
+        host = torch.cat([counts, torch.bincount(torch.div(flat, N, rounding_mode="floor"), minlength=V)]).cpu().tolist()
+        if host[:V] != host[V:2 * V] or not bool((view_of[1:] >= view_of[:-1]).all()):
+            raise ValueError("batch tuple: the rows of ori_coords_3ds / x_labels do not follow the visible flags of mask_2ds view by view")
+        pts = flat - torch.div(flat, N, rounding_mode="floor") * N
+        views, o = [], 0
         for i in range(V):
-            sel = view_of == i
-            views.append(ViewLists(torch.where(vis[i])[0], x_labels[sel].contiguous(), y_labels[sel].contiguous(), i))
-        return SceneBatch(scene_coords.to(dev).float().contiguous(), scene_coords_3d.to(dev).float().contiguous(),
-                          scene_inds_reconstruct.to(dev).long().contiguous(), scene_label.to(dev).long(),
-                          scene_gauss_features[:, :6].to(dev).float().contiguous(), views, imgs=imgs)
+            n_i = host[i]
+            views.append(ViewLists(pts[o:o + n_i], x_labels[o:o + n_i], y_labels[o:o + n_i], i))
+            o += n_i
+        # the same lists as ONE set of view-major arrays: what gp_views_visible_lists produces on device-built batches, so that
+        # the lift takes its all-views kernels (gp_lift_masks_views) on the reference's tuple as well
+        ent = None
+        if V and o > 0:
+            ent = {"pt": pts.contiguous(), "x": x_labels.long().contiguous(), "y": y_labels.long().contiguous(),
+                   "view": view_of.to(torch.int32).contiguous(), "view_off": torch.cat([counts.new_zeros(1), counts.cumsum(0)]),
+                   "keep": torch.ones(V, dtype=torch.uint8, device=dev), "total": o, "max_nv": max(host[:V]), "num_views": V}
+        return SceneBatch(scene_coords.to(dev, non_blocking=nb).float().contiguous(), scene_coords_3d.to(dev, non_blocking=nb).float().contiguous(),
+                          scene_inds_reconstruct.to(dev, non_blocking=nb).long().contiguous(), scene_label.to(dev, non_blocking=nb).long(),
+                          scene_gauss_features[:, :6].to(dev, non_blocking=nb).float().contiguous(), views, imgs=imgs, ent=ent)
 
     @torch.no_grad()
     def evaluate_scene(self, batch_data, vis_prefix="scene0695_00"):

@@ -267,6 +267,7 @@ class SyntheticVLM:
     def __init__(self, outputs, device="cuda", index_from_image=False):
         dev = torch.device(device)
         self.index_from_image = index_from_image       # the generator's view index is read from pixel (0,0) of the image
+        self.ignores_image = not index_from_image      # outputs precomputed for every view: the lift may take them stacked
         self.pred_masks = torch.as_tensor(outputs["pred_masks"]).to(dev)
         self.pred_logits = torch.as_tensor(outputs["pred_logits"]).to(dev)
         self.mask_embed = torch.as_tensor(outputs["mask_embed"]).to(dev)
@@ -344,8 +345,8 @@ class HotPath:
         # src_view (the synthetic stand-in on device-built batches); a batch that carries images (the reference's tuple,
         # slot 11) runs the VLM on imgs[view_idx] view by view, as affinity_module.py:496,518-519 does
         has_img = batch.imgs is not None and batch.imgs.numel() > 0
-        batched = (not has_img and torch.is_tensor(getattr(vlm, "mask_embed", None)) and vlm.mask_embed.dim() == 3
-                   and vlm.mask_embed.is_contiguous())
+        batched = ((not has_img or getattr(vlm, "ignores_image", False)) and torch.is_tensor(getattr(vlm, "mask_embed", None))
+                   and vlm.mask_embed.dim() == 3 and vlm.mask_embed.is_contiguous())
         outs = None
         if batched:
             text_embed, logit_scale = vlm.text_embed, float(vlm.logit_scale)

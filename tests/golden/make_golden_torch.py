@@ -329,6 +329,58 @@ def gold_lift_lseg():
 
 
 # ---------------------------------------------------------------------------------------------------
+def gold_lift_many_views():
+    """lift_xdecoder_features (:455-714) on a scene with MORE THAN 64 surviving views: the second word of the product's
+    per-point view mask, many points seen by far more than three views.  The 2D-model stand-in serves 12 distinct outputs,
+    view i gets output i % 12 (stored once)."""
+    cfg = dataclasses.replace(syn.CONFIGS["T"], num_points=700, num_views=96, feat_dim=512, pitch=0.11, min_visible=12, num_queries=10)
+    scene = syn.make_scene(cfg, 17)
+    rigid = scene_rigid_transform(cfg.voxel_size * 3.0, 17)
+    ld = o_pipe.loader_math(scene, rigid)
+    V = len(ld["views"])
+    assert V > 64, V
+    N = scene.coords.shape[0]
+    NS = 12
+    vlm = syn.make_vlm_outputs(cfg, NS, 17)
+    H, W = cfg.mask_shape
+    imgs = torch.stack([torch.full((H, W, 3), float(i)) for i in range(V)])
+
+    class _XModel:
+        def forward_seg_all(self, batch_inputs):
+            i = int(batch_inputs[0]["image"][0, 0, 0, 0].item())
+            s = i % NS
+            return None, {"pred_masks": torch.from_numpy(vlm["pred_masks"][s])[None],
+                          "pred_logits": torch.from_numpy(vlm["pred_logits"][s])[None],
+                          "mask_embed": torch.from_numpy(vlm["mask_embed"][s])[None],
+                          "text_embed": torch.from_numpy(vlm["text_embed"]),
+                          "logit_scale": torch.tensor(float(vlm["logit_scale"]))}
+
+    class _Self:
+        lift_xdecoder_features = Trainer.lift_xdecoder_features
+        use_lseg = False
+        use_ape = False
+        device = "cpu"
+        xdecoder_teacher = types.SimpleNamespace(model=_XModel())
+
+    me = _Self()
+    me.cfg = types.SimpleNamespace(mask_shape=list(cfg.mask_shape), all_label=[f"c{i}" for i in range(cfg.num_classes)])
+    batch = build_tuple(scene, ld, imgs)
+    F_lift, text_features, logit_scale = me.lift_xdecoder_features(batch)
+    counter = torch.zeros(N, dtype=torch.long)
+    for v in ld["views"]:
+        counter[v["pt"]] += 1
+    np.savez_compressed(
+        os.path.join(HERE, "ref_lift_masks_manyviews.npz"),
+        scene_coords=batch[0].numpy(), num_views=np.int64(V), mask_shape=np.array(cfg.mask_shape), **view_arrays(ld),
+        view_source=np.arange(V) % NS, pred_masks=vlm["pred_masks"], pred_logits=vlm["pred_logits"], mask_embed=vlm["mask_embed"],
+        text_embed=vlm["text_embed"], logit_scale=np.float32(vlm["logit_scale"]),
+        out_features=F_lift.numpy(), out_text_features=text_features.numpy(), out_logit_scale=np.float32(logit_scale),
+        n_unseen=np.int64((counter == 0).sum()), n_more_than_3_views=np.int64((counter > 3).sum()), max_views_per_point=np.int64(counter.max()))
+    print(f"lift_xdecoder_features (many views): N={N} V={V} unseen={int((counter == 0).sum())} >3views={int((counter > 3).sum())} "
+          f"max views per point {int(counter.max())}")
+
+
+# ---------------------------------------------------------------------------------------------------
 def gold_sampler():
     from oracle import train as o_train
     rng = np.random.default_rng(9)
@@ -355,7 +407,11 @@ def gold_sampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "many_views":       # only the > 64-view lift fixture
+        gold_lift_many_views()
+        sys.exit(0)
     gold_lift_and_tail()
+    gold_lift_many_views()
     gold_lift_lseg()
     gold_sampler()
     for f in sorted(os.listdir(HERE)):
