@@ -416,7 +416,9 @@ def main():
             vlms.append(shared_vlm)                       # config V: one set of synthetic 2D outputs serves every scene (the
             vlm_np = vlm_np0                              # geometry, hence every kernel's work, differs per scene)
         else:
-            vlm_np = syn.make_vlm_outputs(cfg, cfg.num_views, seed)
+            # config V: the shared 2D outputs are seeded independently of the rank and of the assignment, so that the reduced
+            # IoU counts of a scene set do not depend on the sharding policy (checked by the two-rank test)
+            vlm_np = syn.make_vlm_outputs(cfg, cfg.num_views, 5557 if val_mode else seed)
             vlms.append(pl.SyntheticVLM(vlm_np, dev))
             shared_vlm = vlms[-1]
         if s == 0:

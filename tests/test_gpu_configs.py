@@ -169,3 +169,40 @@ def test_bench_two_ranks_share_one_gpu_counts_are_the_sum(tmp_path):
         want += sum(per_scene[i % nscn] for i in range(steps))
     assert rec["n_gpus"] == 2 and rec["iou_target_points"] == want, (rec["iou_target_points"], want)
     assert rec["value"] > 0 and rec["stages_ms_per_scene"]
+
+
+def test_bench_config_v_two_ranks_shard_record(tmp_path):
+    """BASELINE configs[2] with more than one rank: `bench.py --config V --gpus 2` under gloo on
+    this box's one GPU.  The `shard` record must describe an LPT assignment of every scene exactly once, per-rank busy times,
+    and the reduced target counts must be the labelled points of all scenes of both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    recs = {}
+    for policy in ("lpt", "contiguous"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--warmup", "1", "--config", "V",
+               "--val-scenes", "2", "--shard-policy", policy, "--no-cpu-baseline", "--no-train", "--api", "device"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-3000:]
+        recs[policy] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for policy, rec in recs.items():
+        sh = rec["shard"]
+        assert rec["n_gpus"] == 2 and sh["policy"] == policy and sh["scenes_total"] == 4
+        assert len(sh["busy_s_per_rank"]) == 2 and all(b > 0 for b in sh["busy_s_per_rank"])
+        assert sh["imbalance_max_over_mean"] >= 1.0
+        assert sum(sh["scenes_per_rank"]) == 4 and len(sh["points_per_rank"]) == 2
+        assert rec["value"] > 0 and rec["iou_target_points"] > 0 and rec["scaling"] == "weak"
+    assert max(recs["lpt"]["shard"]["points_per_rank"]) <= max(recs["contiguous"]["shard"]["points_per_rank"])
+    # the same scenes under both policies: the reduced counts do not depend on the assignment
+    assert recs["lpt"]["iou_target_points"] == recs["contiguous"]["iou_target_points"]
+    assert recs["lpt"]["iou_intersection_points"] == recs["contiguous"]["iou_intersection_points"]
