@@ -238,9 +238,9 @@ def test_bench_helpers_traffic_and_schedule():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    rec = json.load(open(os.path.join(root, "profiles", "pool_pmc.json")))["pool_mfma_kernel"]
-    t = bench.pmc_traffic("pool_mfma_kernel", rec["nv"])
+    rec = json.load(open(os.path.join(root, "profiles", "pool_pmc.json")))["cs_pool_kernel"]
+    t = bench.pmc_traffic("cs_pool_kernel", rec["nv"])
     assert t["traffic"] == int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024) and "pool_pmc.json" in t["traffic_source"]
-    assert bench.pmc_traffic("pool_mfma_kernel", rec["nv"] // 2)["traffic"] == int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024 * (rec["nv"] // 2) / rec["nv"])
+    assert bench.pmc_traffic("cs_pool_kernel", rec["nv"] // 2)["traffic"] == int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024 * (rec["nv"] // 2) / rec["nv"])
     assert bench.pmc_traffic("no_such_kernel", 1000) == {"traffic": None}
     assert 1 <= bench.host_threads() <= 16
