@@ -431,7 +431,6 @@ class PoolCs:
         self.bu_off, self.bu_n, self.bu_row, self.bu_mask = bu_off, bu_n, bu_row, bu_mask
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
         self.block_rows = 128
-        self.queue = torch.zeros(9, dtype=torch.int32, device=bu_off.device)   # tile counters of the engine (left zero by every launch)
 
 
 def pool_cs_build(nbr, w):
@@ -460,16 +459,17 @@ def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, 
     out_scale: device scalar multiplied into out_f32 (1/s of a pow2_scale()-scaled x_split).
     engine: the producer / consumer form of the kernel (same results)."""
     lib = _lib.load()
+    if engine:
+        lib.gp_debug_set(11, 8)
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
     yh, yl = out_split if out_split is not None else (None, None)
-    args = (_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
-            _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
-            _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale))
+    check(lib.gp_pool_cs_apply(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
+                               _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
+                               _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()),
+          "gp_pool_cs_apply")
     if engine:
-        check(lib.gp_pool_cs_apply_engine(*args, _ptr(op.queue), _stream()), "gp_pool_cs_apply_engine")
-    else:
-        check(lib.gp_pool_cs_apply(*args, _stream()), "gp_pool_cs_apply")
+        lib.gp_debug_set(11, 0)
     return out_f32 if out_f32 is not None else out_split
 
 

@@ -243,14 +243,6 @@ int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, c
 int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                      const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
                      void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream);
-/* The same application through the producer / consumer engine (one persistent workgroup per CU: loader waves, consumer    */
-/* waves, tiles of 128 rows x 128 columns claimed in order per XCD).  queue: 9 x uint32 of device memory, ZERO at the      */
-/* first launch and left zero by every launch; launches that share a queue must be stream-ordered.  Bit-identical to      */
-/* gp_pool_cs_apply.                                                                                                      */
-int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
-                            const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
-                            void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale,
-                            uint32_t *queue, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */

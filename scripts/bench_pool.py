@@ -98,10 +98,6 @@ _bm = cs.bu_mask.cpu().numpy().astype(np.int64) & 0xFF
 print(f"cs BR=128: union rows/row (padded) {cs.total / Nv:.2f}  non-empty fragments {np.unpackbits(_bm.astype(np.uint8)[:, None], axis=1).mean():.3f}"
       f"  build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
 variants += [("cs128 column-sliced (split out)", ("cs", 0)), ("cs128 column-sliced (fp32 out)", ("cs32", 0)),
-             ("cs128 quarters ring 4 (split out)", ("csq", 9)), ("cs128 quarters ring 3 (split out)", ("csq", 10)),
-             ("cs128 quarters ring 5 (split out)", ("csq", 11)), ("cs128 quarters ring 2, 2 wg/CU (split out)", ("csq", 12)),
-             ("cs128 persistent static (split out)", ("csq", 13)), ("cs128 persistent claims (split out)", ("csq", 14)),
-             ("cs128 persistent claims (fp32 out)", ("csq32", 14)),
              ("engine cs128 x 128c (split out)", ("eng", 0)), ("engine cs128 x 128c (fp32 out)", ("eng32", 0)),
              ("mfma64 (split out)", ("mfma", 64, 0, 0)), ("mfma64 (fp32 out)", ("mfma32", 64, 0, 0)),
              ("mfma64 column-sliced waves (split out)", ("mfmacs", 64, 0, 0)),
@@ -115,8 +111,6 @@ print("min steps per row block:", {br: mf[br].min_steps for br in (64, 128)}, fl
 ABL = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # pool_mfma ablation bits (timing only, results invalid)
 lib.gp_debug_set(4, ABL)
 lib.gp_debug_set(9, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
-lib.gp_debug_set(10, int(os.environ.get("GP_KNOB10", 0)))
-lib.gp_debug_ptr(1, cs.queue.data_ptr())
 if len(sys.argv) > 1:                                   # e.g. "mfma": only variants whose name contains the word
     variants = [v for v in variants if sys.argv[1] in v[0]]
 res = {}
@@ -126,18 +120,14 @@ for rnd in range(3):
             t = timeit(lambda: ops.pool_ell(X, nbr, w, D, Y))
         elif v[0] == "cs":
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
-        elif v[0] == "csq":
-            lib.gp_debug_set(11, v[1])
+        elif v[0] == "eng":
+            lib.gp_debug_set(11, 8)
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
             lib.gp_debug_set(11, 0)
-        elif v[0] == "csq32":
-            lib.gp_debug_set(11, v[1])
+        elif v[0] == "eng32":
+            lib.gp_debug_set(11, 8)
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
             lib.gp_debug_set(11, 0)
-        elif v[0] == "eng":
-            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys, engine=True))
-        elif v[0] == "eng32":
-            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y, engine=True))
         elif v[0] == "cs32":
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
         elif v[0] == "mfma":
@@ -170,25 +160,10 @@ yc = torch.empty((Nv, D), device="cuda"); ye = torch.empty((Nv, D), device="cuda
 ops.pool_cs_apply(xs, cs, D, out_f32=yc)
 ops.pool_ell(X, nbr, w, D, ye)
 print("cs128 vs ELL max |diff|:", float((yc - ye).abs().max()), flush=True)
+lib.gp_debug_set(11, 8)
 yg = torch.empty((Nv, D), device="cuda")
-ops.pool_cs_apply(xs, cs, D, out_f32=yg, engine=True)
-lib.gp_debug_ptr(1, cs.queue.data_ptr())
-for kq in (9, 12, 13, 14):
-    yq = torch.empty((Nv, D), device="cuda")
-    lib.gp_debug_set(11, kq)
-    ops.pool_cs_apply(xs, cs, D, out_f32=yq)
-    lib.gp_debug_set(11, 0)
-    torch.cuda.synchronize()
-    print(f"variant (knob {kq}) == cs128 bitwise:", bool(torch.equal(yq, yc)), flush=True)
-    if kq in (13, 14):
-        ysq = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
-        ysr = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
-        ops.pool_cs_apply(xs, cs, D, out_split=ysr)
-        lib.gp_debug_set(11, kq)
-        ops.pool_cs_apply(xs, cs, D, out_split=ysq)
-        lib.gp_debug_set(11, 0)
-        torch.cuda.synchronize()
-        print("  split outputs bitwise:", bool(torch.equal(ysq[0], ysr[0]) and torch.equal(ysq[1], ysr[1])), flush=True)
+ops.pool_cs_apply(xs, cs, D, out_f32=yg)
+lib.gp_debug_set(11, 0)
 torch.cuda.synchronize()
 print("engine vs ELL max |diff|:", float((yg - ye).abs().max()), " engine == cs128 bitwise:", bool(torch.equal(yg, yc)), flush=True)
 # the column-sliced wave mapping computes the same sums in the same order per element: identical outputs

@@ -3,15 +3,13 @@
 v[202:203] across loop steps -- registers named in inline asm, which a clobber list does not reserve.  The guard reads the
 kernel's ISA (hipcc -S) and fails when the COMPILER's own allocation comes near them: any vector register >= 192 other
 than v200, v202, v203 in an instruction of that kernel.
-The same guard serves cs_pool_persist_kernel (pool_mfma_cs.hip: v250).
-usage: check_pinned_vgprs.py <file.s> <kernel-name-substring> [pinned registers, comma separated = 200,202,203] [guard from = 192]"""
+usage: check_pinned_vgprs.py <file.s> <kernel-name-substring>"""
 import re
 import sys
 
 text = open(sys.argv[1]).read()
 want = sys.argv[2]
-pinned = {int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "200,202,203").split(",")}
-guard = int(sys.argv[4]) if len(sys.argv) > 4 else 192
+pinned = {200, 202, 203}
 bad, seen, inside, n_kernels = set(), set(), False, 0
 for line in text.splitlines():
     if re.match(r"^_Z\w*:", line):
@@ -29,9 +27,8 @@ for line in text.splitlines():
         seen.add(int(a))
 if not n_kernels:
     sys.exit(f"check_pinned_vgprs: no kernel matching '{want}' in {sys.argv[1]}")
-bad = {r for r in seen if r >= guard and r not in pinned}
+bad = {r for r in seen if r >= 192 and r not in pinned}
 top = max((r for r in seen if r not in pinned), default=-1)
-names = ", ".join(f"v{r}" for r in sorted(pinned))
-print(f"{want}: compiler-allocated VGPRs up to v{top} in {n_kernels} instantiation(s); pinned {names}")
+print(f"{want}: compiler-allocated VGPRs up to v{top} in {n_kernels} instantiation(s); pinned v200, v202, v203")
 if bad:
-    sys.exit(f"{want}: VGPRs {sorted(bad)} are allocated next to the pinned registers {names} -- the asynchronous tile claim is no longer safe")
+    sys.exit(f"{want}: VGPRs {sorted(bad)} are allocated next to the pinned registers v200..v203 -- the asynchronous tile claim is no longer safe")
