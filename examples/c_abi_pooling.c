@@ -71,7 +71,7 @@ int main(void) {
 
     size_t ws_bytes = gp_pool_mfma_workspace_bytes(nv, br);
     CHECK_HIP(hipMalloc(&d_ws, ws_bytes));
-    CHECK_GP(gp_pool_mfma_count(d_nbr, nv, k, br, d_bu_off, d_bu_n, d_ws, ws_bytes, NULL));
+    CHECK_GP(gp_pool_mfma_count(d_nbr, nv, k, br, 0, d_bu_off, d_bu_n, d_ws, ws_bytes, NULL));
     int64_t total = 0;
     CHECK_HIP(hipMemcpy(&total, d_bu_off + nb, sizeof(int64_t), hipMemcpyDeviceToHost));
     CHECK_HIP(hipMalloc((void **)&d_bu_row, sizeof(int32_t) * total));

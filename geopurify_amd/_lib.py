@@ -55,7 +55,7 @@ SIGNATURES = {
     "gp_pool_tiles_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "gp_pool_tiles_apply": (c_int32, [_P, c_int64, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64, _P]),
     "gp_pool_mfma_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "gp_pool_mfma_count": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "gp_pool_mfma_count": (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "gp_pool_mfma_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P]),
     "gp_pool_mfma_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_pool_mfma_apply_persistent": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64,

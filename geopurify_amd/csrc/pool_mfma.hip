@@ -72,7 +72,7 @@ __device__ __forceinline__ void bitonic_sort_lds(int *a, int n_pow2, int tid, in
 // count pass: bu_n / padded count; fill pass: bu_row (padding repeats the first id; its weights stay zero).
 constexpr int PM_HS = 16384;          // hash slots (>= the largest possible union, so insertion always ends)
 __global__ void __launch_bounds__(1024)
-pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int64_t *__restrict__ padded_cnt,
+pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int min_steps, int64_t *__restrict__ padded_cnt,
                 int32_t *__restrict__ bu_n, const int64_t *__restrict__ bu_off, int32_t *__restrict__ bu_row) {
     extern __shared__ int s_mem[];                       // keys[PM_HS] | dense[np2(br*k)]
     int *keys = s_mem, *dense = s_mem + PM_HS;
@@ -123,13 +123,14 @@ pm_union_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int br, int6
         if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += s_wcnt[w]; s_base += tot; }
         __syncthreads();
     }
-    // padded to whole steps and to at least PM_MIN_STEPS steps (pad rows repeat the first id with zero weights): the persistent
-    // kernel learns its next tile at step 5 and needs it from step n - 4 on
-    const int U = s_base, Up = max((U + PM_KS - 1) / PM_KS, PM_MIN_STEPS) * PM_KS;
+    // padded to whole steps and to at least min_steps steps (pad rows repeat the first id with zero weights; the persistent
+    // kernel learns its next tile at step 5 and needs it from step n - 4 on: PM_MIN_STEPS); pass 2 takes the padded size of pass 1
+    const int U = s_base;
     if (!bu_row) {
-        if (tid == 0) { padded_cnt[b] = Up; bu_n[b] = U; }
+        if (tid == 0) { padded_cnt[b] = max((U + PM_KS - 1) / PM_KS, min_steps) * PM_KS; bu_n[b] = U; }
         return;
     }
+    const int Up = (int)(bu_off[b + 1] - bu_off[b]);
     int np2 = 1;
     while (np2 < U) np2 <<= 1;
     for (int i = U + tid; i < np2; i += 1024) dense[i] = INT32_MAX;
@@ -1021,9 +1022,10 @@ extern "C" size_t gp_pool_mfma_workspace_bytes(int64_t nv, int32_t block_rows) {
 }
 
 // pass 1: bu_off i64 [nblocks+1] (padded union rows before each block; multiple of 32), bu_n i32 [nblocks]
-extern "C" int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t block_rows, int64_t *bu_off, int32_t *bu_n,
-                                  void *workspace, size_t workspace_bytes, void *stream_) {
+extern "C" int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t block_rows, int32_t min_steps, int64_t *bu_off,
+                                  int32_t *bu_n, void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(nbr && bu_off && bu_n && workspace && nv > 0 && k > 0, "gp_pool_mfma_count: null/empty argument");
+    GP_CHECK_ARG(min_steps >= 0 && min_steps <= 64, "gp_pool_mfma_count: min_steps=%d (0..64; %d for the persistent kernel)", min_steps, PM_MIN_STEPS);
     GP_CHECK_ARG(block_rows == 64 || block_rows == 128, "gp_pool_mfma_count: block_rows=%d (64 or 128)", block_rows);
     GP_CHECK_ARG((int64_t)block_rows * k <= PM_MAXID, "gp_pool_mfma_count: k=%d too large (block_rows*k <= %d)", k, PM_MAXID);
     int64_t nb = (nv + block_rows - 1) / block_rows;
@@ -1037,7 +1039,7 @@ extern "C" int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int
     size_t sm = (size_t)(PM_HS + pm_np2((int64_t)block_rows * k)) * sizeof(int);
     GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pm_union_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (PM_HS + PM_MAXID) * (int)sizeof(int)));
-    pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, cnt, bu_n, nullptr, nullptr);
+    pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, min_steps, cnt, bu_n, nullptr, nullptr);
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, cnt, bu_off, (int64_t)0, (size_t)(nb + 1), rocprim::plus<int64_t>(), s));
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -1059,7 +1061,7 @@ extern "C" int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv,
     size_t sm = (size_t)(PM_HS + pm_np2((int64_t)block_rows * k)) * sizeof(int);
     GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pm_union_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (PM_HS + PM_MAXID) * (int)sizeof(int)));
-    pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, nullptr, nullptr, bu_off, bu_row);
+    pm_union_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, block_rows, 0, nullptr, nullptr, bu_off, bu_row);
     pm_weights_kernel<<<(unsigned)nb, 256, 0, s>>>(nbr, w, nv, k, block_rows, bu_off, bu_n, bu_row, static_cast<_Float16 *>(wa_hi),
                                                    static_cast<_Float16 *>(wa_lo));
     GP_CHECK_LAUNCH();

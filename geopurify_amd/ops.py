@@ -390,8 +390,9 @@ class PoolMfma:
         return (self.nv + self.block_rows - 1) // self.block_rows * self.block_rows
 
 
-def pool_mfma_build(nbr, w, block_rows=64):
-    """One host sync (total padded union rows, to size the arrays)."""
+def pool_mfma_build(nbr, w, block_rows=64, min_steps=0):
+    """One host sync (total padded union rows, to size the arrays).  min_steps: pad every row block to at least this many
+    32-row steps (9 for pool_mfma_apply_persistent, else 0)."""
     lib = _lib.load()
     nv, k = nbr.shape
     dev = nbr.device
@@ -399,8 +400,8 @@ def pool_mfma_build(nbr, w, block_rows=64):
     ws = _ws(lib.gp_pool_mfma_workspace_bytes(nv, block_rows), dev)
     bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
     bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
-    check(lib.gp_pool_mfma_count(_ptr(nbr), nv, int(k), int(block_rows), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(),
-                                 _stream()), "gp_pool_mfma_count")
+    check(lib.gp_pool_mfma_count(_ptr(nbr), nv, int(k), int(block_rows), int(min_steps), _ptr(bu_off), _ptr(bu_n), _ptr(ws),
+                                 ws.numel(), _stream()), "gp_pool_mfma_count")
     total, min_rows = torch.stack([bu_off[nb], torch.diff(bu_off).min()]).cpu().tolist()     # the one host sync
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * (block_rows // 16) * 64 * 8, dtype=torch.float16, device=dev)

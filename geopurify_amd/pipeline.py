@@ -541,7 +541,7 @@ class HotPath:
             # "mfma_persist": the persistent kernel (one workgroup per CU, 256 columns per workgroup, weight fragments shared
             # by both column groups, rings kept full across row blocks) -- same speed within run-to-run noise on MI355X
             # (DESIGN.md section 6); needs >= 4 steps per row block and 64-row blocks, else falls back to "mfma"
-            op = ops.pool_mfma_build(nbr, w, self.pool_block_rows)
+            op = ops.pool_mfma_build(nbr, w, self.pool_block_rows, min_steps=9 if mode == "mfma_persist" else 0)
             persistent = mode == "mfma_persist" and op.min_steps >= 9 and self.pool_block_rows == 64
             rows = op.rows_padded if persistent else Nv
             out = torch.empty((rows, D), dtype=torch.float32, device=dev)

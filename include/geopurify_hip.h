@@ -201,9 +201,11 @@ int gp_pool_tiles_apply(const float *x, int64_t ld_x, const int64_t *tile_off, c
 /* bu_off i64 [nblocks+1] (padded union rows, multiples of 32), bu_n i32 [nblocks] (unpadded sizes),     */
 /* bu_row i32 [total], wa_hi/wa_lo f16 [total/32 * nw * 64 * 8] (weights x 2^10 in MFMA A-fragment order).*/
 /* apply: x_hi/x_lo f16 [*, ld_x] -> y_hi/y_lo f16 (nullable pair) and/or y_f32 (nullable).              */
+/* min_steps: every row block is padded (zero weights) to at least this many 32-row steps; 0 unless the   */
+/* operator is built for gp_pool_mfma_apply_persistent, which needs 9.                                    */
 size_t gp_pool_mfma_workspace_bytes(int64_t nv, int32_t block_rows);
-int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t block_rows, int64_t *bu_off,
-                       int32_t *bu_n, void *workspace, size_t workspace_bytes, void *stream);
+int gp_pool_mfma_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t block_rows, int32_t min_steps,
+                       int64_t *bu_off, int32_t *bu_n, void *workspace, size_t workspace_bytes, void *stream);
 int gp_pool_mfma_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t block_rows,
                       const int64_t *bu_off, const int32_t *bu_n, int64_t total_rows, int32_t *bu_row,
                       void *wa_hi, void *wa_lo, void *stream);

@@ -84,8 +84,8 @@ for R in (4, 8, 16):
 variants = [v for v in variants if v[1] is None or v[1][0] == 8 and v[1][2] == 4]
 mf = {}
 for BR in (64, 128):
-    mf[BR] = ops.pool_mfma_build(nbr, w, BR); torch.cuda.synchronize()
-    t0 = time.time(); mf[BR] = ops.pool_mfma_build(nbr, w, BR); torch.cuda.synchronize()
+    mf[BR] = ops.pool_mfma_build(nbr, w, BR, min_steps=9); torch.cuda.synchronize()
+    t0 = time.time(); mf[BR] = ops.pool_mfma_build(nbr, w, BR, min_steps=9); torch.cuda.synchronize()
     print(f"mfma BR={BR}: union rows/row (padded) {mf[BR].total / Nv:.2f}  build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
 for R in (8,):
     t0 = time.time(); ops.pool_tiles_build(nbr, w, R); torch.cuda.synchronize()

@@ -549,6 +549,12 @@ def test_error_paths(ops):
         ops.sparse_conv_f16x3(xin, pairs, hi, lo)
     pairs.chunk_rows = 256
     assert torch.equal(ops.sparse_conv_f16x3(xin, pairs, hi, lo), good)
+    # the matrix-core pooling builder pads row blocks only on request: 0 by default, 9 for the persistent kernel
+    nb2 = torch.randint(0, 200, (200, 16), dtype=torch.int32, device="cuda")
+    w2 = torch.rand(200, 16, device="cuda")
+    assert ops.pool_mfma_build(nb2, w2, 64).min_steps < 9 <= ops.pool_mfma_build(nb2, w2, 64, min_steps=9).min_steps
+    with pytest.raises(GeoPurifyHipError, match="min_steps"):
+        ops.pool_mfma_build(nb2, w2, 64, min_steps=65)
 
 
 # ------------------------------------------------------------------------------------------ row 9 fast path
