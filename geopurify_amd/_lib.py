@@ -110,6 +110,8 @@ SIGNATURES = {
     "gp_adamw_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "gp_knn_points_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "gp_iou_hist_i64": (c_int32, [_P, _P, c_int64, c_int32, POINTER(c_int64), c_int32, _P, _P]),
+    "gp_fused_decode_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gp_fused_decode": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 _lib = None

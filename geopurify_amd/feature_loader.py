@@ -8,6 +8,10 @@ On-disk formats: scene `.pth` = (coords, colors in [-1,1], labels) (dataset/scri
 preprocess_3d_scannet.py:19-25); features `{scene}_{k}.pt` = {"feat": [n_seen,D], "mask_full": [N] bool}
 or the three-key form with an extra "mask".  Out of scope: the SharedArray
 /dev/shm cache (memcache_init) and the train-time colour/elastic augmentations (aug=True).
+
+`device=` (not in the reference): the item is decoded ON the device -- the file contents are
+uploaded once, the voxelizer's outputs stay there, the chunk-mask bookkeeping and the feature-row selection are
+gp_fused_decode (csrc/fused_decode.hip) -- and returned as device tensors with the same values, shapes and dtypes.
 """
 import copy
 from glob import glob
@@ -21,8 +25,9 @@ from .voxelizer import default_voxelizer
 
 class FusedFeatureLoader(torch.utils.data.Dataset):
     def __init__(self, datapath_prefix, datapath_prefix_feat, voxel_size=0.05, split="train", aug=False,
-                 memcache_init=False, identifier=7791, loop=1, eval_all=False, input_color=False):
+                 memcache_init=False, identifier=7791, loop=1, eval_all=False, input_color=False, device=None):
         super().__init__()
+        self.device = torch.device(device) if device is not None else None
         if aug:
             raise NotImplementedError("train-time augmentations (dataset/augmentation.py) are out of scope")
         if memcache_init:
@@ -82,6 +87,8 @@ class FusedFeatureLoader(torch.utils.data.Dataset):
             processed = torch.load(join(self.datapath_feat, scene_name + "_%d.pt" % nn_occur), weights_only=False)
         else:
             processed = torch.load(join(self.datapath_feat, scene_name + ".pt"), weights_only=False)
+        if self.device is not None:
+            return self._item_on_device(locs_in, feats_in, labels_in, processed)
 
         two_key = len(processed.keys()) == 2
         if two_key:
@@ -126,6 +133,60 @@ class FusedFeatureLoader(torch.utils.data.Dataset):
         if self.eval_all:
             return coords, feats, labels, feat_3d, mask, torch.from_numpy(inds_reconstruct).long()
         return coords, feats, labels, feat_3d, mask
+
+
+def _as_bool(x):
+    return torch.from_numpy(x).bool() if isinstance(x, np.ndarray) else x.bool()
+
+
+def _item_on_device(self, locs_in, feats_in, labels_in, processed):
+    """__getitem__ past the file reads, on self.device (same np.random draws: the voxelizer's matrices only)."""
+    from . import ops
+    dev = self.device
+    two_key = len(processed.keys()) == 2
+    train = self.split == "train"
+    feat = processed["feat"]
+    if feat.dim() > 2:
+        feat = feat[..., 0]
+    feat = feat.to(dev)
+    mask_chunk = _as_bool(processed["mask_full"]).to(dev)
+    row_keep = None
+    if not two_key:                                            # "mask": the chunk rows a camera saw (index list or bool mask)
+        row_keep = torch.zeros(feat.shape[0], dtype=torch.bool, device=dev)
+        mv = processed["mask"]
+        row_keep[(torch.from_numpy(mv) if isinstance(mv, np.ndarray) else mv).to(dev)] = True
+    chunk_only = not train and not two_key                   # feature_loader.py:183-187: only the chunk's points are voxelized
+    M_v, M_r = self.voxelizer.get_transformation_matrix()
+    pts = torch.as_tensor(np.ascontiguousarray(locs_in, dtype=np.float64)).to(dev)
+    cols = torch.as_tensor(np.ascontiguousarray(feats_in)).to(dev)
+    labs = torch.as_tensor(np.ascontiguousarray(labels_in)).to(dev)
+    if chunk_only:
+        pts, cols, labs_v = pts[mask_chunk], cols[mask_chunk], labs[mask_chunk]
+    else:
+        labs_v = labs
+    r = ops.voxelize(pts.contiguous(), M_r @ M_v)
+    inds = r["inds"]
+    if train:
+        feat_3d, mask = ops.fused_decode(mask_chunk, feat, inds, 0, row_keep)
+    elif two_key:
+        feat_3d, mask = ops.fused_decode(mask_chunk, feat, inds, 1)
+    else:
+        feat_3d, mask = ops.fused_decode(torch.ones(feat.shape[0], dtype=torch.bool, device=dev), feat, inds, 1, row_keep)
+    coords = r["coords_aug"].to(torch.int32)
+    coords = torch.cat((torch.ones((coords.shape[0], 1), dtype=torch.int32, device=dev), coords), dim=1)
+    if self.input_color:
+        # tensor / tensor: an IEEE division, as on the host (torch's tensor / Python-scalar on the GPU multiplies by the reciprocal)
+        c = cols[inds].float()
+        feats = c / torch.full_like(c, 127.5) - 1.0
+    else:
+        feats = torch.ones((coords.shape[0], 3), device=dev)
+    labels = (labs if self.eval_all else labs_v[inds]).long()
+    if self.eval_all:
+        return coords, feats, labels, feat_3d, mask, r["inds_reconstruct"].long()
+    return coords, feats, labels, feat_3d, mask
+
+
+FusedFeatureLoader._item_on_device = _item_on_device
 
 
 def collation_fn(batch):

@@ -862,3 +862,28 @@ def conv_wgrad_f16x3(x_split, y_split, plan, cin_pad, cin_out, cout, inv_scale=N
                                   int(cin_out), int(cout), _ptr(inv_scale), _ptr(dw), _ptr(plan.workspace), plan.workspace.numel(),
                                   _stream()), "gp_conv_wgrad_f16x3")
     return dw
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8(f)-3
+def fused_decode(mask_chunk, feat, vox_ind, mode, row_keep=None):
+    """Rows of a fused-feature file for the voxel representatives (gp_fused_decode; dataset/feature_loader.py:113-192).
+    mask_chunk bool/u8 [N], feat [rows, D] (fp16 or fp32), vox_ind i64 [Nv], row_keep bool/u8 [rows] or None.
+    mode 0: (feat rows of the kept voxels, compact [n_sel, D]; mask bool [Nv]) -- one host sync for n_sel;
+    mode 1: (one row per voxel [Nv, D], zeros outside the chunk; mask bool [Nv])."""
+    lib = _lib.load()
+    dev = feat.device
+    mc = mask_chunk.to(torch.uint8).contiguous()
+    rk = row_keep.to(torch.uint8).contiguous() if row_keep is not None else None
+    feat = feat.contiguous()
+    vox_ind = vox_ind.to(torch.int64).contiguous()
+    n, nv = mc.shape[0], vox_ind.shape[0]
+    out = torch.empty((nv,) + tuple(feat.shape[1:]), dtype=feat.dtype, device=dev)
+    mask_out = torch.empty(nv, dtype=torch.uint8, device=dev)
+    n_sel = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _ws(lib.gp_fused_decode_workspace_bytes(n, nv), dev)
+    row_bytes = feat[0].numel() * feat.element_size()
+    check(lib.gp_fused_decode(_ptr(mc), n, _ptr(rk), _ptr(feat), feat.shape[0], row_bytes, _ptr(vox_ind), nv, int(mode), _ptr(out),
+                              _ptr(mask_out), _ptr(n_sel), _ptr(ws), ws.numel(), _stream()), "gp_fused_decode")
+    if mode == 0:
+        out = out[: int(n_sel.item())]
+    return out, mask_out.bool()

@@ -414,6 +414,22 @@ int gp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_av
 int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *queries, int64_t num_queries, int32_t k,
                       int64_t *out, int32_t *flag_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* decode of a fused-feature file on the device (dataset/feature_loader.py:113-192). */
+/* feat [feat_rows, row_bytes] holds one row per True of mask_chunk u8 [n], in point order (fp16 or  */
+/* fp32 elements: rows are copied as bytes); row_keep u8 [feat_rows] (nullable: the three-key form's  */
+/* "mask"); vox_ind i64 [nv] = representative point of each voxel.  With p = vox_ind[v],             */
+/* in = mask_chunk[p], r = #True in mask_chunk[0..p), keep = in && (row_keep ? row_keep[r] : 1):      */
+/*   mode 0 (training forms):   mask_out[v] = keep; out[j] = feat[r] for the j-th kept voxel (compact, */
+/*                              voxel order); n_sel[0] (device i64) = number of kept voxels.          */
+/*   mode 1 (evaluation forms): mask_out[v] = keep; out[v] = in ? feat[r] : 0 for every voxel.        */
+/* out holds nv rows in both modes.                                                                  */
+size_t gp_fused_decode_workspace_bytes(int64_t n, int64_t nv);
+int gp_fused_decode(const uint8_t *mask_chunk, int64_t n, const uint8_t *row_keep, const void *feat,
+                    int64_t feat_rows, int64_t row_bytes, const int64_t *vox_ind, int64_t nv, int32_t mode,
+                    void *out, uint8_t *mask_out, int64_t *n_sel, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

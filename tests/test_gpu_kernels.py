@@ -890,3 +890,36 @@ def test_c_abi_example_runs_without_python_or_torch(ops, tmp_path):
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8(f)-3
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,d", [(torch.float16, 768), (torch.float32, 512), (torch.float16, 3)])
+def test_fused_decode_vs_index_arithmetic(ops, dtype, d):
+    """gp_fused_decode against the reference's own index arithmetic (dataset/feature_loader.py:141-190: nonzero / cumsum /
+    fancy indexing) on random masks: both modes, with and without the three-key form's row mask, 16-byte and 2-byte rows."""
+    g = torch.Generator().manual_seed(5)
+    n, nv = 5000, 1700
+    mask_chunk = torch.rand(n, generator=g) < 0.6
+    rows = int(mask_chunk.sum())
+    feat = torch.randn(rows, d, generator=g).to(dtype)
+    row_keep = torch.rand(rows, generator=g) < 0.7
+    vox_ind = torch.randperm(n, generator=g)[:nv].sort().values
+    rank = torch.cumsum(mask_chunk.long(), 0) - 1
+    for rk in (None, row_keep):
+        # training forms: feat' = feat[rk], mask_chunk' = chunk & seen, rows of the representatives inside mask_chunk'
+        mc2 = mask_chunk.clone()
+        if rk is not None:
+            mc2[mask_chunk.clone()] = rk
+        want_mask = mc2[vox_ind]
+        want_rows = feat[rank[vox_ind[want_mask]]]
+        got, gm = ops.fused_decode(mask_chunk.cuda(), feat.cuda(), vox_ind.cuda(), 0, None if rk is None else rk.cuda())
+        assert got.dtype == dtype and torch.equal(gm.cpu(), want_mask) and torch.equal(got.cpu(), want_rows)
+        # evaluation form (two keys): scatter to all points, then one row per representative
+        full = torch.zeros((n, d), dtype=dtype)
+        full[mask_chunk] = feat
+        got, gm = ops.fused_decode(mask_chunk.cuda(), feat.cuda(), vox_ind.cuda(), 1, None if rk is None else rk.cuda())
+        assert torch.equal(got.cpu(), full[vox_ind]) and torch.equal(gm.cpu(), want_mask)
+    from geopurify_amd._lib import GeoPurifyHipError
+    with pytest.raises(GeoPurifyHipError, match="mode"):
+        ops.fused_decode(mask_chunk.cuda(), feat.cuda(), vox_ind.cuda(), 2)
