@@ -8,8 +8,10 @@ What runs where:
     V[k] = W[26-k]^T; gradients are scaled by a power of two before the f16 hi/lo split so that they stay normal);
   * BatchNorm(training), ReLU masks, InfoNCE forward+backward, AdamW, anchors' K nearest points: train.hip;
   * weight gradients dW[k] = X[in_k]^T dY[out_k]: gp_conv_wgrad_f16x3 (wgrad.hip); the anchors x points similarity:
-    the convolution operator with one offset (_anchor_similarities); the 512->128 output layer (plain dense GEMMs,
-    forward and backward) and unsupported shapes: torch.matmul (rocBLAS);
+    the convolution operator with one offset (_anchor_similarities); the 512->128 output layer is the convolution operator
+    with one offset and the identity map (forward and data gradient: gp_sparse_conv, true-fp32 MFMA; weight gradient:
+    gp_conv_wgrad_f16x3 over identity pairs with the gradient padded to 256 columns); shapes those kernels do not take
+    (hidden width < 256, CPU tensors): torch.matmul;
   * set logic (unique / argmax / topk of the sampler): torch device ops, as in the reference.
 The teacher (Sonata) is not available offline: its per-point features are an input tensor.
 Deviation: the voxel input is [mean lifted feature | mean geometry] (518 channels) as in
@@ -222,13 +224,26 @@ class StudentTrainer:
             h2, h2s, st2 = bn_fwd(y2, f"res_blocks.{i}.norm2", residual=h)
             blocks.append((h, y1, a1, st1, y2, st2, h2, hs, a1s))
             h, hs = h2, h2s
-        E = h @ P["output_layer.kernel"]
+        Wo = P["output_layer.kernel"]
+        dense_hip = self.fast and hs is not None and Wo.shape[0] % 32 == 0 and Wo.shape[0] >= 256 and Wo.shape[1] % 128 == 0 and Wo.shape[1] <= 256
+        E = ops.sparse_conv(h, None, Wo.unsqueeze(0).contiguous()) if dense_hip else h @ Wo
         loss, dE = ops.infonce_fwd_bwd(E, sample_to_voxel, point_to_batch, num_anchors, num_negatives, self.temperature)
 
         # ---------------- backward
         g = {}
-        g["output_layer.kernel"] = h.t() @ dE
-        dh = dE @ P["output_layer.kernel"].t()
+        if dense_hip:
+            # dW = h^T dE on the weight-gradient kernel: one "offset" whose pairs are the identity; the gradient rides in a
+            # 256-column operand (columns >= embed are zero) because the kernel's tiles are 256 x 256
+            ident = torch.arange(Nv, device=dev)
+            plan = ops.wgrad_plan_build([(ident, ident)], Nv)
+            dEp = torch.zeros((Nv, 256), dtype=torch.float32, device=dev)
+            dEp[:, :Wo.shape[1]] = dE
+            _, ysplit, inv_s = self._grad_split(dEp)
+            g["output_layer.kernel"] = ops.conv_wgrad_f16x3(hs, ysplit, plan, Wo.shape[0], Wo.shape[0], 256, inv_scale=inv_s)[0, :, :Wo.shape[1]].contiguous()
+            dh = ops.sparse_conv(dE.contiguous(), None, Wo.t().contiguous().unsqueeze(0))
+        else:
+            g["output_layer.kernel"] = h.t() @ dE
+            dh = dE @ Wo.t()
         for i in reversed(range(self.num_blocks)):
             h_in, y1, a1, st1, y2, st2, h_out, h_in_s, a1_s = blocks[i]
             dy2, dg2, db2, dz = bn_bwd(dh, h_out, y2, st2, P[f"res_blocks.{i}.norm2.bn.weight"], want_dz=True)
