@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o c --output-format csv -
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $O/tcc -o c --output-format csv -- $B > $O/tcc.json 2> $O/tcc.log
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d $O/sq -o c --output-format csv -- $B > $O/sq.json 2> $O/sq.log
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/grbm -o c --output-format csv -- $B > $O/grbm.json 2> $O/grbm.log
-python3 $R/scripts/pmc_summarize.py $O cs_pool > $O/pool_pmc_summary.json
+python3 $R/scripts/pmc_summarize.py $O cs_pool_kernel > $O/pool_pmc_summary.json
 python3 $R/scripts/pmc_summarize.py $O conv_phase > $O/conv_pmc_summary.json
 # keep the summaries only: per-dispatch traces and counter dumps are tens of MiB (gpurun_out/ is capped at 64 MiB)
 find $O -name "*_kernel_trace.csv" -delete
