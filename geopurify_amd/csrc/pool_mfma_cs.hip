@@ -528,213 +528,6 @@ __global__ void __launch_bounds__(512, 2) cs_pool_tuning_kernel(CS_POOL_PARAMS) 
 #undef CS_POOL_PARAMS
 #undef CS_POOL_FWD
 
-// ------------------------------------------------------------------------------------------------ row-sliced quarters
-// EXPERIMENT ("rs"): one workgroup = 128 rows x 128 columns (column quarters: the XCD's 32 workgroups cover 8 row blocks, a
-// 1 024-row window), wave g owns ROW GROUP g (16 rows) x all 128 columns.  A wave then needs only ITS group's weight fragment
-// per step: the fragments never pass through LDS -- each wave loads its own (two 1-KiB loads per step, RS_D steps ahead, into
-// a register ring) and skips a step whose fragment is empty (no LDS reads, no MFMAs; the union order keeps about half of the
-// groups busy per step, one per SIMD).  The ring holds staged rows only (16 KiB per stage), six stages deep.
-constexpr int RS_NC = 128;
-constexpr int RS_RB = RS_NC * 2;
-constexpr int RS_PLANE = CS_KS * RS_RB;             // 8 KiB
-constexpr int RS_STAGE = 2 * RS_PLANE;              // 16 KiB: hi plane | lo plane
-constexpr int RS_NST = 4;                           // ring slots = weight-fragment register sets
-constexpr int RS_D = 3;                             // stages issued ahead
-constexpr int RS_OPS = 4;                           // vector-memory operations per wave and step: 2 row DMA + 2 fragment loads
-constexpr int RS_EP = RS_NC + 4;                    // epilogue staging pitch (floats)
-constexpr size_t RS_STG = (size_t)CS_NW * 16 * RS_EP * sizeof(float);     // epilogue staging (over the drained ring)
-constexpr size_t RS_SMEM = (size_t)RS_NST * RS_STAGE > RS_STG ? (size_t)RS_NST * RS_STAGE : RS_STG;
-
-struct RsRows { s16x4 f[8][2][2]; };                // one stage as B fragments: [column tile][hi, lo][k half]
-
-__device__ __forceinline__ void rs_gload16(f16x8 &d, const _Float16 *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void rs_handover_rt(int stages) {   // stages (0..3) of RS_OPS operations may stay in flight
-    if (stages >= 3) cs_handover<3 * RS_OPS>();
-    else if (stages == 2) cs_handover<2 * RS_OPS>();
-    else if (stages == 1) cs_handover<1 * RS_OPS>();
-    else cs_handover<0>();
-}
-
-__global__ void __launch_bounds__(512, 2)
-rs_pool_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
-               const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
-               const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
-               _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
-               int64_t per_xcd, const float *__restrict__ out_scale) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);    // XCD-contiguous order
-    const int64_t b = lb >> 2;
-    const int col0 = (int)(lb & 3) * RS_NC;
-    if (b >= nblocks) return;
-    const int64_t ub0 = bu_off[b];
-    const int n = (int)((bu_off[b + 1] - ub0) / CS_KS);
-    const int64_t ks0 = ub0 / CS_KS;
-    // ---- DMA role: rows 4 wv .. 4 wv + 3 of a stage, one 1-KiB instruction per plane (16 lanes per row)
-    const int du = lane >> 4, dc = lane & 15;
-    const int t0 = du | (((wv >> 1) & 1) << 2);
-    const int64_t dsrc = col0 + ((dc ^ (2 * t0)) * 8);
-    const int32_t *idg = bu_row + ub0 + 4 * wv;
-    const uint32_t *mkg = bu_mask + ks0;
-    const _Float16 *wah = wa_hi + (ks0 * CS_NG + wv) * 512, *wal = wa_lo + (ks0 * CS_NG + wv) * 512;   // group wv, step 0
-    auto issue_x = [&](i32x4 id, int slot) {
-        unsigned char *dst = smem_raw + slot * RS_STAGE;
-        const int idr = du == 0 ? id.x : du == 1 ? id.y : du == 2 ? id.z : id.w;
-        const int64_t s0 = (int64_t)idr * ld_x + dsrc;
-        cs_glds16(x_hi + s0, dst + (4 * wv) * RS_RB);
-        cs_glds16(x_lo + s0, dst + RS_PLANE + (4 * wv) * RS_RB);
-    };
-    auto load_ids = [&](int k) { return *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS); };
-    f16x8 ah[RS_NST], al[RS_NST];
-#pragma unroll
-    for (int i = 0; i < RS_NST; ++i) ah[i] = al[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    // an empty fragment is never used: its two loads read the first line of the block's fragments (keeps the count fixed)
-#define RS_LOAD_A(SLOT, K, MK)                                                                         \
-    {                                                                                                  \
-        const int64_t off_ = (((MK) >> wv) & 1u) ? (int64_t)(K) * (CS_NG * 512) + lane * 8 : 0;        \
-        rs_gload16(ah[SLOT], wah + off_);                                                              \
-        rs_gload16(al[SLOT], wal + off_);                                                              \
-    }
-    // ---- read role: B fragments of all 8 column tiles
-    const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
-    uint32_t addr[8];
-    {
-        const uint32_t t = (uint32_t)(q | ((gq & 1) << 2));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) addr[u] = lds0 + (uint32_t)(8 * gq + q) * RS_RB + (((uint32_t)u ^ t) << 5) + (uint32_t)(p * 8);
-    }
-    auto read_rows = [&](RsRows &o, int slot) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t au = addr[u] + slot * RS_STAGE;
-            cs_tr<0>(o.f[u][0][0], au);
-            cs_tr<4 * RS_RB>(o.f[u][0][1], au);
-            cs_tr<RS_PLANE>(o.f[u][1][0], au);
-            cs_tr<RS_PLANE + 4 * RS_RB>(o.f[u][1][1], au);
-        }
-    };
-    auto rows_landed = [&](RsRows &o) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(o.f[0][0][0]), "+v"(o.f[0][0][1]), "+v"(o.f[0][1][0]), "+v"(o.f[0][1][1]), "+v"(o.f[1][0][0]), "+v"(o.f[1][0][1]),
-                       "+v"(o.f[1][1][0]), "+v"(o.f[1][1][1]), "+v"(o.f[2][0][0]), "+v"(o.f[2][0][1]), "+v"(o.f[2][1][0]), "+v"(o.f[2][1][1]),
-                       "+v"(o.f[3][0][0]), "+v"(o.f[3][0][1]), "+v"(o.f[3][1][0]), "+v"(o.f[3][1][1]));
-        asm volatile(""
-                     : "+v"(o.f[4][0][0]), "+v"(o.f[4][0][1]), "+v"(o.f[4][1][0]), "+v"(o.f[4][1][1]), "+v"(o.f[5][0][0]), "+v"(o.f[5][0][1]),
-                       "+v"(o.f[5][1][0]), "+v"(o.f[5][1][1]), "+v"(o.f[6][0][0]), "+v"(o.f[6][0][1]), "+v"(o.f[6][1][0]), "+v"(o.f[6][1][1]),
-                       "+v"(o.f[7][0][0]), "+v"(o.f[7][0][1]), "+v"(o.f[7][1][0]), "+v"(o.f[7][1][1]));
-    };
-    f32x4 acc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    RsRows R0, R1;
-
-    // ---- prologue: stages 0 .. D - 1 in flight (a short block stages its last step again); mq[j] = mask of stage s + j
-    unsigned mq[RS_NST];
-    i32x4 idv;
-    const bool small = n <= RS_D;                            // (hand-over counts below assume the loop issues stages)
-#pragma unroll
-    for (int j = 0; j < RS_D; ++j) {
-        const int kj = j < n ? j : n - 1;
-        const i32x4 ij = load_ids(kj);
-        mq[j] = mkg[kj];
-        issue_x(ij, j);
-        RS_LOAD_A(j, kj, mq[j])
-    }
-    {
-        const int kd = RS_D < n ? RS_D : n - 1;
-        idv = load_ids(kd);
-        mq[RS_D] = mkg[kd];
-        asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mq[RS_D]));
-    }
-    asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]) : "n"((RS_D - 2) * RS_OPS) : "memory");   // stages 0, 1
-    if ((mq[0] >> wv) & 1u) read_rows(R0, 0);
-    for (int s0 = 0; s0 < n; s0 += RS_NST) {
-#pragma unroll
-        for (int J = 0; J < RS_NST; ++J) {
-            const int s = s0 + J;
-            if (s < n) {
-                const bool act = (mq[0] >> wv) & 1u, actn = s + 1 < n && ((mq[1] >> wv) & 1u);
-                if (s + RS_D < n) {
-                    issue_x(idv, (J + RS_D) % RS_NST);
-                    RS_LOAD_A((J + RS_D) % RS_NST, s + RS_D, mq[RS_D])
-                }
-                if (act) { if (J & 1) rows_landed(R1); else rows_landed(R0); }
-                const int kn = s + RS_D + 1 < n ? s + RS_D + 1 : n - 1;
-                const i32x4 idn = load_ids(kn);
-                const unsigned mN = mkg[kn];
-                if (actn) { if (J & 1) read_rows(R0, (J + 1) % RS_NST); else read_rows(R1, (J + 1) % RS_NST); }
-                if (act) {
-#define RS_MMA(RR)                                                                                                       \
-                    {                                                                                                    \
-                        f16x8 bh[8], bl[8];                                                                              \
-                        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
-                            bh[u] = cs_cat(RR.f[u][0][0], RR.f[u][0][1]);                                                \
-                            bl[u] = cs_cat(RR.f[u][1][0], RR.f[u][1][1]);                                                \
-                        }                                                                                                \
-                        _Pragma("unroll") for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[J], bh[u], acc[u], 0, 0, 0); \
-                        _Pragma("unroll") for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[J], bl[u], acc[u], 0, 0, 0); \
-                        _Pragma("unroll") for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[J], bh[u], acc[u], 0, 0, 0); \
-                    }
-                    if (J & 1) RS_MMA(R1) else RS_MMA(R0)
-#undef RS_MMA
-                }
-                asm volatile("" ::"s"(idn.x), "s"(idn.y), "s"(idn.z), "s"(idn.w), "s"(mN));
-                // hand-over: stage s + 2 (rows and this wave's fragment) has landed; younger stages stay in flight
-                {
-                    int left = (s + RS_D < n ? s + RS_D : n - 1) - (s + 2);
-                    left = small ? 0 : (left < 0 ? 0 : left);
-                    const int JN = (J + 2) % RS_NST;            // (a constant after unrolling)
-                    asm volatile("" : "+v"(ah[JN]), "+v"(al[JN]));
-                    rs_handover_rt(left);
-                    asm volatile("" : "+v"(ah[JN]), "+v"(al[JN]));
-                }
-#pragma unroll
-                for (int j = 0; j < RS_D; ++j) mq[j] = mq[j + 1];
-                mq[RS_D] = mN;
-                idv = idn;
-            }
-        }
-    }
-#undef RS_LOAD_A
-    // ---- epilogue: the wave's 16 rows x 128 columns through its private staging area (the ring is drained), full 256-byte rows
-    const float inv = 1.f / CS_WSCALE;
-    const float so = (y_f32 && out_scale) ? out_scale[0] : 1.f;
-    float *stg = reinterpret_cast<float *>(smem_raw) + wv * (16 * RS_EP);
-    const int fl = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * RS_EP + u * 16 + fl] = acc[u][r] * inv;
-    gp_wave_sync();
-    const int er = lane >> 2, ec = (lane & 3) * 32;          // lane -> 32 consecutive columns of row er
-    const int64_t grow = b * CS_BR + wv * 16 + er;
-    if (grow < nv) {
-#pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
-            const float *sp = stg + er * RS_EP + ec + c8 * 8;
-            const float4 v0 = *reinterpret_cast<const float4 *>(sp), v1 = *reinterpret_cast<const float4 *>(sp + 4);
-            const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const int col = col0 + ec + c8 * 8;
-            if (y_hi) {
-                f16x8 h, l;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { h[i] = (_Float16)xv[i]; l[i] = (_Float16)(xv[i] - (float)h[i]); }
-                *reinterpret_cast<f16x8 *>(y_hi + grow * ld_y + col) = h;
-                *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + col) = l;
-            }
-            if (y_f32) {
-                float *yp = y_f32 + grow * ld_yf + col;
-                *reinterpret_cast<float4 *>(yp) = make_float4(xv[0] * so, xv[1] * so, xv[2] * so, xv[3] * so);
-                *reinterpret_cast<float4 *>(yp + 4) = make_float4(xv[4] * so, xv[5] * so, xv[6] * so, xv[7] * so);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ engine
 // Producer / consumer form of the same operator ("engine"): ONE persistent 512-thread workgroup per CU.
 //   waves 4-7 = loaders: nothing but LDS-DMA.  They fill a ring of four 32-KiB slots (32 union rows x 128 columns x
@@ -1113,19 +906,6 @@ extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x
         if (stamp) cs_engine_kernel<true><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
         else cs_engine_kernel<false><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
 #undef EG_ARGS
-        GP_CHECK_LAUNCH();
-        return GP_OK;
-    }
-    if (g_gp_knobs[11] == 31) {                            // experiment: row-sliced quarters
-        static bool ra = false;
-        if (!ra) {
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rs_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_SMEM));
-            ra = true;
-        }
-        const int64_t pq = (nb * 4 + 7) / 8;
-        rs_pool_kernel<<<(unsigned)(pq * 8), 512, RS_SMEM, s>>>(static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
-                bu_mask, static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
-                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, pq, out_scale);
         GP_CHECK_LAUNCH();
         return GP_OK;
     }
