@@ -10,20 +10,25 @@ from . import ops
 
 
 def make_intrinsic(fx, fy, mx, my):
-    intrinsic = np.eye(4)
-    intrinsic[0][0], intrinsic[1][1], intrinsic[0][2], intrinsic[1][2] = fx, fy, mx, my
-    return intrinsic
+    """4x4 pinhole matrix: focal lengths on the diagonal, principal point in the third column."""
+    K = np.eye(4)
+    K[(0, 1, 0, 1), (0, 1, 2, 2)] = (fx, fy, mx, my)
+    return K
 
 
 def adjust_intrinsic(intrinsic, intrinsic_image_dim, image_dim):
-    """models/utils/fusion_util.py:18-33."""
+    """Rescale a pinhole matrix IN PLACE from images of intrinsic_image_dim (w, h) to image_dim (models/utils/fusion_util.py:18-33,
+    same arithmetic): fy by the height ratio, fx by the aspect-preserving width over the old width, the principal point by the
+    ratios of the last pixel indices."""
     if intrinsic_image_dim == image_dim:
         return intrinsic
-    resize_width = int(math.floor(image_dim[1] * float(intrinsic_image_dim[0]) / float(intrinsic_image_dim[1])))
-    intrinsic[0, 0] *= float(resize_width) / float(intrinsic_image_dim[0])
-    intrinsic[1, 1] *= float(image_dim[1]) / float(intrinsic_image_dim[1])
-    intrinsic[0, 2] *= float(image_dim[0] - 1) / float(intrinsic_image_dim[0] - 1)
-    intrinsic[1, 2] *= float(image_dim[1] - 1) / float(intrinsic_image_dim[1] - 1)
+    w_src, h_src = float(intrinsic_image_dim[0]), float(intrinsic_image_dim[1])
+    w_keep_aspect = int(math.floor(image_dim[1] * w_src / h_src))
+    for r, c, factor in ((0, 0, float(w_keep_aspect) / w_src),
+                         (1, 1, float(image_dim[1]) / h_src),
+                         (0, 2, float(image_dim[0] - 1) / float(intrinsic_image_dim[0] - 1)),
+                         (1, 2, float(image_dim[1] - 1) / float(intrinsic_image_dim[1] - 1))):
+        intrinsic[r, c] *= factor
     return intrinsic
 
 
@@ -42,40 +47,33 @@ def _run(w2c, coords, depth, K, image_dim, cut, tau, want_weight):
     return out.cpu().numpy()
 
 
-class PointCloudToImageMappermatterport(object):
+class _Mapper(object):
+    """What both mappers keep: target image size (w, h), relative depth tolerance, border margin, optional global intrinsics."""
+
+    def __init__(self, image_dim, visibility_threshold=0.25, cut_bound=0, intrinsics=None):
+        self.image_dim, self.vis_thres, self.cut_bound, self.intrinsics = image_dim, visibility_threshold, cut_bound, intrinsics
+
+    def _K(self, intrinsic):
+        return self.intrinsics if self.intrinsics is not None else intrinsic
+
+
+class PointCloudToImageMappermatterport(_Mapper):
     """fusion_util.py:36-82: argument is a camera_to_world matrix (inverted on the host, as the reference)."""
 
-    def __init__(self, image_dim, visibility_threshold=0.25, cut_bound=0, intrinsics=None):
-        self.image_dim = image_dim
-        self.vis_thres = visibility_threshold
-        self.cut_bound = cut_bound
-        self.intrinsics = intrinsics
-
     def compute_mapping(self, camera_to_world, coords, depth=None, intrinsic=None):
-        if self.intrinsics is not None:
-            intrinsic = self.intrinsics
-        w2c = np.linalg.inv(camera_to_world)
-        return _run(w2c, coords, depth, intrinsic, self.image_dim, self.cut_bound, self.vis_thres, False)
+        return _run(np.linalg.inv(camera_to_world), coords, depth, self._K(intrinsic), self.image_dim, self.cut_bound, self.vis_thres, False)
 
 
-class PointCloudToImageMapper(object):
-    """fusion_util.py:85-147 (ScanNet): argument is world_view_transform = W2C^T; intrinsics are
-    rescaled to image_dim in the constructor."""
+class PointCloudToImageMapper(_Mapper):
+    """fusion_util.py:85-147 (ScanNet): argument is world_view_transform = W2C^T; the constructor rescales the intrinsics to
+    image_dim on the reference's assumption that the principal point sits at half the source size (:91-96)."""
 
     def __init__(self, image_dim, visibility_threshold=0.25, cut_bound=0, intrinsics=None):
-        self.image_dim = image_dim
-        self.vis_thres = visibility_threshold
-        self.cut_bound = cut_bound
-        self.intrinsics = np.array(intrinsics).copy()
-        scale_x = self.image_dim[0] / (self.intrinsics[0, 2] * 2)
-        scale_y = self.image_dim[1] / (self.intrinsics[1, 2] * 2)
-        self.intrinsics[0, 0] *= scale_x
-        self.intrinsics[1, 1] *= scale_y
-        self.intrinsics[0, 2] = self.image_dim[0] / 2
-        self.intrinsics[1, 2] = self.image_dim[1] / 2
+        K = np.array(intrinsics).copy()
+        for axis in (0, 1):
+            K[axis, axis] *= image_dim[axis] / (K[axis, 2] * 2)
+            K[axis, 2] = image_dim[axis] / 2
+        super().__init__(image_dim, visibility_threshold, cut_bound, K)
 
     def compute_mapping(self, world_to_camera, coords, depth=None, intrinsic=None):
-        if self.intrinsics is not None:
-            intrinsic = self.intrinsics
-        w2c = np.asarray(world_to_camera).T
-        return _run(w2c, coords, depth, intrinsic, self.image_dim, self.cut_bound, self.vis_thres, True)
+        return _run(np.asarray(world_to_camera).T, coords, depth, self._K(intrinsic), self.image_dim, self.cut_bound, self.vis_thres, True)

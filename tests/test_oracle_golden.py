@@ -339,3 +339,18 @@ def test_fused_feature_loader_vs_reference_fixture(golden_dir, case):
     for j, x in enumerate(r):
         want = g[f"{case}_out_{j}"]
         assert x.shape == want.shape and np.array_equal(np.asarray(x, dtype=want.dtype), want), (case, j)
+
+
+def test_intrinsics_helpers_vs_reference_fixture(golden_dir):
+    """geopurify_amd.fusion_util.make_intrinsic / adjust_intrinsic and the ScanNet mapper's constructor against the matrices the
+    reference's own functions return (models/utils/fusion_util.py:7-33, :86-98; make_golden_intrinsics.py): bit for bit."""
+    from geopurify_amd import fusion_util as fu
+    g = np.load(os.path.join(golden_dir, "ref_intrinsics.npz"))
+    for i, p in enumerate(g["params"]):
+        src, dst = [int(a) for a in g["dim_src"][i]], [int(a) for a in g["dim_dst"][i]]
+        assert np.array_equal(fu.make_intrinsic(*p), g["made"][i])
+        assert np.array_equal(fu.adjust_intrinsic(fu.make_intrinsic(*p), src, dst), g["adjusted"][i])
+        m = fu.PointCloudToImageMapper(dst, 0.05, 10, fu.make_intrinsic(*p))
+        assert np.array_equal(m.intrinsics, g["mapper"][i]) and m.image_dim == dst and m.vis_thres == 0.05 and m.cut_bound == 10
+    mm = fu.PointCloudToImageMappermatterport([640, 512], 0.02, 2)
+    assert mm.intrinsics is None and mm.image_dim == [640, 512] and mm.vis_thres == 0.02 and mm.cut_bound == 2
