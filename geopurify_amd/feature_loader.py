@@ -13,7 +13,6 @@ or the three-key form with an extra "mask".  Out of scope (SURVEY.md section 2 #
 uploaded once, the voxelizer's outputs stay there, the chunk-mask bookkeeping and the feature-row selection are
 gp_fused_decode (csrc/fused_decode.hip) -- and returned as device tensors with the same values, shapes and dtypes.
 """
-import copy
 from glob import glob
 from os.path import join
 
@@ -63,14 +62,6 @@ class FusedFeatureLoader(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data_paths) * self.loop
 
-    @staticmethod
-    def _rows_of_masked(mask_chunk, vox_ind):
-        """Row in `feat` (one row per True of mask_chunk, in order) of every voxel-representative point
-        that is inside the chunk (feature_loader.py:147-160)."""
-        rep_in_chunk = vox_ind[mask_chunk[vox_ind]]
-        rank = torch.cumsum(mask_chunk.to(torch.int64), dim=0) - 1
-        return rank[rep_in_chunk]
-
     def __getitem__(self, index_long):
         index = index_long % len(self.data_paths)
         locs_in, feats_in, labels_in = torch.load(self.data_paths[index], weights_only=False)
@@ -87,60 +78,31 @@ class FusedFeatureLoader(torch.utils.data.Dataset):
             processed = torch.load(join(self.datapath_feat, scene_name + "_%d.pt" % nn_occur), weights_only=False)
         else:
             processed = torch.load(join(self.datapath_feat, scene_name + ".pt"), weights_only=False)
-        if self.device is not None:
-            return self._item_on_device(locs_in, feats_in, labels_in, processed)
-
-        two_key = len(processed.keys()) == 2
-        if two_key:
-            feat_3d, mask_chunk = processed["feat"], processed["mask_full"]
-            if isinstance(mask_chunk, np.ndarray):
-                mask_chunk = torch.from_numpy(mask_chunk)
-            mask = copy.deepcopy(mask_chunk)
-            if self.split != "train":                         # evaluation: scatter to all points, keep every point
-                full = torch.zeros((locs_in.shape[0], feat_3d.shape[1]), dtype=feat_3d.dtype)
-                full[mask] = feat_3d
-                feat_3d, mask_chunk = full, torch.ones_like(mask_chunk)
-        else:
-            feat_3d, mask_visible, mask_chunk = processed["feat"], processed["mask"], processed["mask_full"]
-            mask = torch.zeros(feat_3d.shape[0], dtype=torch.bool)
-            mask[mask_visible] = True
-        if feat_3d.dim() > 2:
-            feat_3d = feat_3d[..., 0]
-
-        if self.split == "train":
-            if not two_key:
-                feat_3d = feat_3d[mask]
-                mask_chunk[mask_chunk.clone()] = mask
-            locs, feats, labels, inds_reconstruct, vox_ind = self.voxelizer.voxelize(locs_in, feats_in, labels_in,
-                                                                                     return_ind=True)
-            vox_ind = torch.from_numpy(vox_ind)
-            mask = mask_chunk[vox_ind]
-            feat_3d = feat_3d[self._rows_of_masked(mask_chunk, vox_ind)]
-        else:
-            mc = mask_chunk.numpy().astype(bool)
-            locs, feats, labels, inds_reconstruct, vox_ind = self.voxelizer.voxelize(locs_in[mc], feats_in[mc],
-                                                                                     labels_in[mc], return_ind=True)
-            vox_ind = torch.from_numpy(vox_ind)
-            feat_3d = feat_3d[vox_ind]
-            mask = mask[vox_ind]
-
-        if self.eval_all:
-            labels = labels_in
-        coords = torch.from_numpy(locs).int()
-        coords = torch.cat((torch.ones(coords.shape[0], 1, dtype=torch.int), coords), dim=1)
-        feats = torch.from_numpy(feats).float() / 127.5 - 1.0 if self.input_color else torch.ones(coords.shape[0], 3)
-        labels = torch.from_numpy(labels).long()
-        if self.eval_all:
-            return coords, feats, labels, feat_3d, mask, torch.from_numpy(inds_reconstruct).long()
-        return coords, feats, labels, feat_3d, mask
+        return self._item(locs_in, feats_in, labels_in, processed)
 
 
 def _as_bool(x):
     return torch.from_numpy(x).bool() if isinstance(x, np.ndarray) else x.bool()
 
 
-def _item_on_device(self, locs_in, feats_in, labels_in, processed):
-    """__getitem__ past the file reads, on self.device (same np.random draws: the voxelizer's matrices only)."""
+def _decode_host(mask_chunk, feat, vox_ind, mode, row_keep=None):
+    """Host form of gp_fused_decode (same contract: csrc/fused_decode.hip): rank(p) = row of point p in `feat`."""
+    rank = torch.cumsum(mask_chunk.to(torch.int64), dim=0) - 1
+    inside = mask_chunk[vox_ind]
+    rows = rank[vox_ind]
+    keep = inside if row_keep is None else inside & row_keep[rows.clamp(min=0)]
+    if mode == 0:
+        return feat[rows[keep]], keep
+    out = torch.zeros((vox_ind.shape[0],) + tuple(feat.shape[1:]), dtype=feat.dtype)
+    out[inside] = feat[rows[inside]]
+    return out, keep
+
+
+def _item(self, locs_in, feats_in, labels_in, processed):
+    """__getitem__ past the file reads (dataset/feature_loader.py:113-218), on the host or -- with device= -- on the device.
+    One formulation for the four cases (two-key / three-key file, training / evaluation): with rank(p) = row of point p in
+    `feat`, a voxel keeps its representative's row if the representative is in the chunk (and, three-key form, was seen).
+    np.random is drawn by the voxelizer's matrices only, as in the reference."""
     from . import ops
     dev = self.device
     two_key = len(processed.keys()) == 2
@@ -148,45 +110,60 @@ def _item_on_device(self, locs_in, feats_in, labels_in, processed):
     feat = processed["feat"]
     if feat.dim() > 2:
         feat = feat[..., 0]
-    feat = feat.to(dev)
-    mask_chunk = _as_bool(processed["mask_full"]).to(dev)
+    mask_chunk = _as_bool(processed["mask_full"])
     row_keep = None
     if not two_key:                                            # "mask": the chunk rows a camera saw (index list or bool mask)
-        row_keep = torch.zeros(feat.shape[0], dtype=torch.bool, device=dev)
         mv = processed["mask"]
-        row_keep[(torch.from_numpy(mv) if isinstance(mv, np.ndarray) else mv).to(dev)] = True
-    chunk_only = not train and not two_key                   # feature_loader.py:183-187: only the chunk's points are voxelized
-    M_v, M_r = self.voxelizer.get_transformation_matrix()
-    pts = torch.as_tensor(np.ascontiguousarray(locs_in, dtype=np.float64)).to(dev)
-    cols = torch.as_tensor(np.ascontiguousarray(feats_in)).to(dev)
-    labs = torch.as_tensor(np.ascontiguousarray(labels_in)).to(dev)
-    if chunk_only:
-        pts, cols, labs_v = pts[mask_chunk], cols[mask_chunk], labs[mask_chunk]
+        row_keep = torch.zeros(feat.shape[0], dtype=torch.bool)
+        row_keep[torch.from_numpy(mv) if isinstance(mv, np.ndarray) else mv] = True
+    chunk_only = not train and not two_key                   # :183-187: the evaluation form of a three-key file voxelizes the chunk only
+    if dev is None:
+        mc = mask_chunk.numpy().astype(bool)
+        pts, cols, labs = (locs_in[mc], feats_in[mc], labels_in[mc]) if chunk_only else (locs_in, feats_in, labels_in)
+        locs, feats, labels, inds_reconstruct, vox_ind = self.voxelizer.voxelize(pts, cols, labs, return_ind=True)
+        vox_ind = torch.from_numpy(vox_ind)
+        decode = _decode_host
+        coords = torch.from_numpy(locs).int()
+        feats = torch.from_numpy(feats).float() / 127.5 - 1.0 if self.input_color else torch.ones(coords.shape[0], 3)
+        labels = torch.from_numpy(labels_in if self.eval_all else labels).long()
+        inds_reconstruct = torch.from_numpy(inds_reconstruct).long()
+        ones = torch.ones((coords.shape[0], 1), dtype=torch.int)
     else:
+        feat, mask_chunk = feat.to(dev), mask_chunk.to(dev)
+        row_keep = row_keep.to(dev) if row_keep is not None else None
+        M_v, M_r = self.voxelizer.get_transformation_matrix()
+        pts = torch.as_tensor(np.ascontiguousarray(locs_in, dtype=np.float64)).to(dev)
+        cols = torch.as_tensor(np.ascontiguousarray(feats_in)).to(dev)
+        labs = torch.as_tensor(np.ascontiguousarray(labels_in)).to(dev)
         labs_v = labs
-    r = ops.voxelize(pts.contiguous(), M_r @ M_v)
-    inds = r["inds"]
+        if chunk_only:
+            pts, cols, labs_v = pts[mask_chunk], cols[mask_chunk], labs[mask_chunk]
+        r = ops.voxelize(pts.contiguous(), M_r @ M_v)
+        vox_ind = r["inds"]
+        decode = ops.fused_decode
+        coords = r["coords_aug"].to(torch.int32)
+        if self.input_color:
+            # tensor / tensor: an IEEE division, as on the host (torch's tensor / Python-scalar on the GPU multiplies by the reciprocal)
+            c = cols[vox_ind].float()
+            feats = c / torch.full_like(c, 127.5) - 1.0
+        else:
+            feats = torch.ones((coords.shape[0], 3), device=dev)
+        labels = (labs if self.eval_all else labs_v[vox_ind]).long()
+        inds_reconstruct = r["inds_reconstruct"].long()
+        ones = torch.ones((coords.shape[0], 1), dtype=torch.int32, device=dev)
     if train:
-        feat_3d, mask = ops.fused_decode(mask_chunk, feat, inds, 0, row_keep)
+        feat_3d, mask = decode(mask_chunk, feat, vox_ind, 0, row_keep)
     elif two_key:
-        feat_3d, mask = ops.fused_decode(mask_chunk, feat, inds, 1)
+        feat_3d, mask = decode(mask_chunk, feat, vox_ind, 1)
     else:
-        feat_3d, mask = ops.fused_decode(torch.ones(feat.shape[0], dtype=torch.bool, device=dev), feat, inds, 1, row_keep)
-    coords = r["coords_aug"].to(torch.int32)
-    coords = torch.cat((torch.ones((coords.shape[0], 1), dtype=torch.int32, device=dev), coords), dim=1)
-    if self.input_color:
-        # tensor / tensor: an IEEE division, as on the host (torch's tensor / Python-scalar on the GPU multiplies by the reciprocal)
-        c = cols[inds].float()
-        feats = c / torch.full_like(c, 127.5) - 1.0
-    else:
-        feats = torch.ones((coords.shape[0], 3), device=dev)
-    labels = (labs if self.eval_all else labs_v[inds]).long()
+        feat_3d, mask = decode(torch.ones(feat.shape[0], dtype=torch.bool, device=feat.device), feat, vox_ind, 1, row_keep)
+    coords = torch.cat((ones, coords), dim=1)
     if self.eval_all:
-        return coords, feats, labels, feat_3d, mask, r["inds_reconstruct"].long()
+        return coords, feats, labels, feat_3d, mask, inds_reconstruct
     return coords, feats, labels, feat_3d, mask
 
 
-FusedFeatureLoader._item_on_device = _item_on_device
+FusedFeatureLoader._item = _item
 
 
 def collation_fn(batch):
