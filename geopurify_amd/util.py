@@ -8,29 +8,27 @@ from . import ops
 
 
 class AverageMeter:
-    """util/util.py:108-124."""
+    """Last value, weighted sum, count and mean of a stream of values (util/util.py:108-124): update(val, n) weighs val by n."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self.val = self.avg = self.sum = self.count = 0
 
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
         self.avg = self.sum / self.count
 
 
 def poly_learning_rate(base_lr, curr_iter, max_iter, power=0.9):
-    return base_lr * (1 - float(curr_iter) / max_iter) ** power
+    """base_lr * (1 - t)^power, t = curr_iter / max_iter."""
+    t = float(curr_iter) / max_iter
+    return base_lr * (1 - t) ** power
 
 
 def cosine_learning_rate(base_lr, curr_iter, max_iter):
+    """Half a cosine period from base_lr down to 0."""
     return base_lr * 0.5 * (1 + math.cos(math.pi * curr_iter / max_iter))
 
 
@@ -48,15 +46,13 @@ def intersection_union_counts(output, target, K, ignore_indexs=(255,), counts=No
 def intersectionAndUnionGPU(output, target, K, ignore_indexs=[255]):
     """util/util.py:160-177.  Same return convention (three fp32 [K] tensors on the GPU); like the
     reference it overwrites `output` in place where the target is an ignore id."""
-    assert output.dim() in [1, 2, 3, 4]
-    assert output.shape == target.shape
-    output = output.view(-1)
-    target = target.view(-1).to(output.device)
-    for ig in ignore_indexs:
-        output[target == ig] = ig
-    c = intersection_union_counts(output, target, K, ignore_indexs)
-    inter, out, tgt = c[0].float(), c[1].float(), c[2].float()
-    return inter, out + tgt - inter, tgt
+    if not (1 <= output.dim() <= 4 and output.shape == target.shape):
+        raise AssertionError("intersectionAndUnionGPU: prediction and target need the same shape (1 to 4 dimensions)")
+    flat_out, flat_tgt = output.view(-1), target.view(-1).to(output.device)
+    for ig in ignore_indexs:                                  # (the reference's in-place edit of the caller's predictions)
+        flat_out[flat_tgt == ig] = ig
+    inter, n_out, n_tgt = (h.float() for h in intersection_union_counts(flat_out, flat_tgt, K, ignore_indexs))
+    return inter, n_out + n_tgt - inter, n_tgt
 
 
 def save_checkpoint(state, is_best, sav_path, filename="model_last.pth.tar"):
