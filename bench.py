@@ -365,20 +365,62 @@ def val_scene_sizes(per_gpu, world):
     return [sizes[(i * len(sizes)) // n] for i in range(n)]
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks HERE.  The parent never touches
+    the GPU (no HIP call, no torch.cuda.is_available()): it starts `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a CHILD process (never an exec of itself), passes stderr through, relays rank 0's single JSON line
+    and exits non-zero if the launcher does or if the line does not say n_gpus == N.  One process per GPU, scenes sharded by
+    the split rule of run/validation.py:269-286, ONE all-reduce of the IoU counts (:441-450) over RCCL (backend "nccl")."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        log(f"the launcher exited with {p.returncode}")
+        sys.exit(p.returncode)
+    if line is None:
+        log("no JSON line from rank 0")
+        sys.exit(1)
+    got = json.loads(line).get("n_gpus")
+    if got != n:
+        log(f"rank 0 reports n_gpus={got}, asked for {n}")
+        sys.exit(1)
+    print(line, flush=True)
+    sys.exit(0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                           # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        args.gpus = world
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
+    backend = os.environ.get("GP_BENCH_BACKEND", "nccl")      # nccl = RCCL; "gloo" lets a test run two ranks on ONE GPU
+    if world > torch.cuda.device_count() and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible")
     local = local % torch.cuda.device_count()         # more ranks than GPUs only happens in the gloo test (two ranks, one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("GP_BENCH_BACKEND", "nccl")      # nccl = RCCL; "gloo" lets a test run two ranks on ONE GPU
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import dataclasses

@@ -189,11 +189,22 @@ def test_bench_config_v_two_ranks_shard_record(tmp_path):
     env = dict(os.environ, GP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     recs = {}
     for policy in ("lpt", "contiguous"):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--warmup", "1", "--config", "V",
-               "--val-scenes", "2", "--shard-policy", policy, "--no-cpu-baseline", "--no-train", "--api", "device"]
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
-        assert out.returncode == 0, out.stderr[-3000:]
+        tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--warmup", "1", "--config", "V",
+                "--val-scenes", "2", "--shard-policy", policy, "--no-cpu-baseline", "--no-train", "--api", "device"]
+        if policy == "lpt":
+            # the driver's own command form: `python bench.py --gpus 2 ...` with NO launcher -- bench.py
+            # starts its two ranks itself (a child torch.distributed.run, before any GPU call) and relays rank 0's line
+            env_direct = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            out = subprocess.run([sys.executable] + tail, env=env_direct, capture_output=True, text=True, timeout=900, cwd=root)
+            assert out.returncode == 0, out.stderr[-3000:]
+            assert "starting 2 ranks" in out.stderr
+            lines = [l for l in out.stdout.splitlines() if l.strip()]
+            assert len(lines) == 1 and lines[0].startswith("{"), lines          # ONE JSON line on stdout, nothing else
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port)] + tail
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+            assert out.returncode == 0, out.stderr[-3000:]
         recs[policy] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     for policy, rec in recs.items():
         sh = rec["shard"]

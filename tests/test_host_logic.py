@@ -244,3 +244,28 @@ def test_bench_helpers_traffic_and_schedule():
     assert bench.pmc_traffic("cs_pool_kernel", rec["nv"] // 2)["traffic"] == int((2 * rec["fetch_kib"] + rec["write_kib"]) * 1024 * (rec["nv"] // 2) / rec["nv"])
     assert bench.pmc_traffic("no_such_kernel", 1000) == {"traffic": None}
     assert 1 <= bench.host_threads() <= 16
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment must start TWO ranks by itself (a child
+    torch.distributed.run, started before the parent's first GPU call) and fail loudly when they do.  On this GPU-less
+    container every rank stops at bench.py's "needs a GPU" assertion: the parent must relay a non-zero exit code, print no
+    JSON line, and the launcher's log must show both ranks (the GPU-side twin of this test runs the same command to the end:
+    tests/test_gpu_configs.py::test_bench_config_v_two_ranks_shard_record)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_gpu_configs.py")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "T", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0
+    assert "starting 2 ranks" in out.stderr and "--nproc-per-node=2" in out.stderr
+    assert "bench.py needs a GPU" in out.stderr                      # the ranks ran bench.py's main() and said why they stopped
+    assert "rank: 1" in out.stderr or "local_rank: 1" in out.stderr or "[rank1]" in out.stderr or "rank      : 1" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # a launcher environment whose size contradicts --gpus is an error, not a silent one-rank run
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--config", "T"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120, cwd=root)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
