@@ -18,7 +18,7 @@ SIGNATURES = {
     "gp_version": (c_int32, []),
     "gp_last_error": (c_char_p, []),
     "gp_debug_set": (c_int32, [c_int32, c_int32]),
-    "gp_debug_ptr": (c_int32, [c_int32, _P]),
+    "gp_debug_ptr": (c_int32, [c_int32, _P, c_size_t]),
     "gp_voxelize_workspace_bytes": (c_size_t, [c_int64]),
     "gp_voxelize_f64": (c_int32, [_P, c_int64, POINTER(c_double), _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gp_fnv_hash_f64": (c_int32, [_P, c_int64, _P, _P]),
@@ -64,6 +64,7 @@ SIGNATURES = {
     "gp_pool_cs_count": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
     "gp_pool_cs_fill": (c_int32, [_P, _P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "gp_pool_cs_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
+    "gp_pool_cs_apply_engine": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_lift_dense_bilinear_accum": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P,
                                                c_int64, _P, _P]),

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/geopurify_hip.h"
 
 #define GP_WAVE 64
@@ -32,6 +34,34 @@ extern "C" void gp_set_error(const char *fmt, ...);
 #define GP_CHECK_LAUNCH() GP_CHECK_HIP(hipGetLastError())
 
 static inline hipStream_t gp_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, DEVICE): the attribute belongs to the device's code object, so a
+// process that drives several GPUs (or first calls from two threads) needs it on each of them -- a function-local `static bool`
+// is neither.  One bit per device id in an atomic word per call site; a lost race sets the attribute twice (harmless).
+#define GP_SMEM_ATTR(func, bytes)                                                                                          \
+    do {                                                                                                                   \
+        static std::atomic<uint64_t> gp_attr_done_{0};                                                                     \
+        int gp_dev_ = 0;                                                                                                   \
+        GP_CHECK_HIP(hipGetDevice(&gp_dev_));                                                                              \
+        const uint64_t gp_bit_ = 1ull << (gp_dev_ & 63);                                                                   \
+        if (!(gp_attr_done_.load(std::memory_order_acquire) & gp_bit_)) {                                                  \
+            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(func), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                             (int)(bytes)));                                                               \
+            gp_attr_done_.fetch_or(gp_bit_, std::memory_order_release);                                                    \
+        }                                                                                                                  \
+    } while (0)
+
+// compute units of the CURRENT device (cached per device id; 0 on error)
+static inline int gp_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int n = cache[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cache[dev & 63].store(n, std::memory_order_relaxed);
+    return n;
+}
 
 static inline size_t gp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

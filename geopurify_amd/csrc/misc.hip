@@ -699,11 +699,7 @@ extern "C" int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int6
     const bool fast = d % 64 == 0 && d <= 64 * CL_MAXJ && ld % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)text_norm % 16 == 0;
     const size_t text_bytes = (size_t)c * d * sizeof(float);
     if (fast && text_bytes <= 64 * 1024 && !g_gp_knobs[14]) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(classify16_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr_set = true;
-        }
+        GP_SMEM_ATTR(classify16_lds_kernel, 64 * 1024);
         const int64_t groups = (n + 16 * CL_Q - 1) / (16 * CL_Q);
         classify16_lds_kernel<<<(int)(groups < 2048 ? groups : 2048), 256, text_bytes, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
                                                                                                      pred, zero_row);

@@ -375,14 +375,8 @@ extern "C" int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, cons
     int blocks = (int)((nv * 64 + 255) / 256);
     hipStream_t s = gp_stream(stream_);
     if (d == 128 && g_gp_knobs[15] != 1) {              // block form: distinct neighbour rows of R rows staged once in LDS
-        static bool attr_set = false;
-        if (!attr_set) {
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(affinity_block_kernel<16>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeo<16>::SMEM));
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(affinity_block_kernel<8>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AbGeo<8>::SMEM));
-            attr_set = true;
-        }
+        GP_SMEM_ATTR(affinity_block_kernel<16>, AbGeo<16>::SMEM);
+        GP_SMEM_ATTR(affinity_block_kernel<8>, AbGeo<8>::SMEM);
         if (g_gp_knobs[15] == 2)                        // measured on config S: 16 rows 0.49 ms, 8 rows 0.55 ms, wave form 0.81 ms
             affinity_block_kernel<8><<<(unsigned)((nv + 7) / 8), 512, AbGeo<8>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w);
         else

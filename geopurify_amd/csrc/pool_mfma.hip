@@ -20,6 +20,7 @@
 
 extern int g_gp_knobs[16];
 extern void *g_gp_debug_ptr[4];
+extern size_t g_gp_debug_bytes[4];
 
 namespace {
 
@@ -430,7 +431,7 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
                          const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
                          const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nblocks,
                          _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
-                         int64_t ld_yf, const float *__restrict__ out_scale, int knobs, unsigned *__restrict__ queue) {
+                         int64_t ld_yf, const float *__restrict__ out_scale, unsigned *__restrict__ queue) {
     using P = PgGeo<MT, XD>;
     using G = typename P::Q;
     static_assert(MT == 1, "the staged epilogue is written for 16 rows x 128 columns per wave");
@@ -475,7 +476,7 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
     PgTile nx1 = cur;
     bool has1 = false;
     int64_t claimed = 0;                                     // wave 0: the tile its last claim returned
-    const bool late_issue = !(knobs & 32) && wv >= 4;
+    const bool late_issue = wv >= 4;
 
     // ---- DMA roles (same staging geometry as PqGeo<8,256,..>: 4 rows per wave, two 1-KiB instructions per plane)
     const int du = lane / (64 / G::RPI), dc = lane % (G::RB / 16);
@@ -715,14 +716,23 @@ pool_mfma_persist_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__re
     leave();
 }
 
-template <int NW, int NC, int MT, int CGN, bool STAMP = false>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1)
-pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
-                 const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
-                 const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
-                 _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
-                 int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp = nullptr) {
+// TUNE: the tuning bits of `ablate_` are honoured; the PRODUCT instantiation (TUNE = false) compiles them out.
+// Round-3 finding (three memory access faults in scripts/bench_pool.py, masks 8 / 8 / 9): the bits used to be live in the product
+// kernel and bits 1 / 3 DROPPED LDS-DMA instructions from a stage while the hand-over kept waiting `vmcnt(DMA_PER_STAGE)`.  With
+// bit 3 a stage had 5 instructions instead of 7, so the wait released the barrier with the two youngest instructions of the OLDER
+// stage still in flight -- one of them the stage's row-id load (issued last).  pq_rd64 then read stale ids from the ring slot
+// and the next issue() gathered from garbage row numbers.  Now a tuning bit never changes the NUMBER of DMA instructions: it
+// replaces the instruction's source by one hot 16-byte piece (all lanes the same address), so every hand-counted wait keeps
+// its meaning in every mask.
+template <int NW, int NC, int MT, int CGN, bool STAMP, bool TUNE>
+__device__ __forceinline__ void
+pq_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
+        const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row,
+        const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
+        _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,
+        int64_t ld_yf, int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
     using G = PqGeo<NW, NC, MT, CGN>;
+    const int ablate = TUNE ? ablate_ : 0;
     static_assert(G::BR / 16 == NW, "one weight fragment group per wave to stage");
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
     if constexpr (STAMP) { st_t0 = pq_now(); st_r0 = pq_real(); }
@@ -750,17 +760,16 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
     // stage k -> ring slot: rows(k), weights(k), ids(min(k+2, n-1))
     auto issue = [&](int2 id, int k, int slot) {
         unsigned char *dst = smem_raw + slot * G::STAGE;
-        const int64_t s0 = (int64_t)id.x * ld_x + dsrc0, s1 = (int64_t)id.y * ld_x + dsrc1;
-        if (!(ablate & 2)) {                               // tuning aid: bit 1 skips the row gather
-            glds16(x_hi + s0, dst + (G::RPW * wv) * G::RB);
-            glds16(x_lo + s0, dst + G::PLANE + (G::RPW * wv) * G::RB);
-            glds16(x_hi + s1, dst + (G::RPW * wv) * G::RB + 1024);
-            glds16(x_lo + s1, dst + G::PLANE + (G::RPW * wv) * G::RB + 1024);
-        }
-        if (!(ablate & 8)) {                               // tuning aid: bit 3 skips the weight fragments
-            glds16(wah + (int64_t)k * WSTEP, dst + G::OFF_W + wv * 1024);
-            glds16(wal + (int64_t)k * WSTEP, dst + G::OFF_W + NW * 1024 + wv * 1024);
-        }
+        // tuning aids (TUNE only): bit 1 fetches one hot piece instead of the gathered rows, bit 3 instead of the weight
+        // fragments -- the same 7 instructions per stage either way (see the note above the kernel)
+        const bool hot_x = (ablate & 2) != 0, hot_w = (ablate & 8) != 0;
+        const int64_t s0 = hot_x ? 0 : (int64_t)id.x * ld_x + dsrc0, s1 = hot_x ? 0 : (int64_t)id.y * ld_x + dsrc1;
+        glds16(x_hi + s0, dst + (G::RPW * wv) * G::RB);
+        glds16(x_lo + s0, dst + G::PLANE + (G::RPW * wv) * G::RB);
+        glds16(x_hi + s1, dst + (G::RPW * wv) * G::RB + 1024);
+        glds16(x_lo + s1, dst + G::PLANE + (G::RPW * wv) * G::RB + 1024);
+        glds16(hot_w ? wa_hi : wah + (int64_t)k * WSTEP, dst + G::OFF_W + wv * 1024);
+        glds16(hot_w ? wa_lo : wal + (int64_t)k * WSTEP, dst + G::OFF_W + NW * 1024 + wv * 1024);
         const int kid = k + 2 < n ? k + 2 : n - 1;
         // 64 lanes x 4 B: the wave's RPW ids, repeated (lane & (RPW-1)): always inside the block's padded union
         __builtin_amdgcn_global_load_lds(
@@ -904,6 +913,20 @@ pool_mfma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
     }
 }
 
+#define PQ_PARAMS const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x, const int64_t *__restrict__ bu_off, \
+                  const int32_t *__restrict__ bu_row, const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, \
+                  int64_t nblocks, _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32,   \
+                  int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp
+#define PQ_FWD x_hi, x_lo, ld_x, bu_off, bu_row, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp
+// the product kernel: no tuning bits, no stamps
+template <int NW, int NC, int MT, int CGN>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) pool_mfma_kernel(PQ_PARAMS) { pq_body<NW, NC, MT, CGN, false, false>(PQ_FWD); }
+// the same body with the tuning bits live (and, STAMP, the in-kernel time stamps), under its own name in a kernel trace
+template <int NW, int NC, int MT, int CGN, bool STAMP>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) pool_mfma_tuning_kernel(PQ_PARAMS) { pq_body<NW, NC, MT, CGN, STAMP, true>(PQ_FWD); }
+#undef PQ_PARAMS
+#undef PQ_FWD
+
 size_t pm_scan_tmp(int64_t n) {
     size_t t = 0;
     (void)rocprim::exclusive_scan(nullptr, t, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0);
@@ -917,39 +940,28 @@ int pm_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
               const void *wa_lo, int64_t nv, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale,
               hipStream_t s) {
     using G = PqGeo<NW, NC, MT, CGN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel<NW, NC, MT, CGN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
-        attr_set = true;
-    }
     int64_t nb = (nv + G::BR - 1) / G::BR;
     int64_t per_xcd = (nb * (PM_D / NC) + 7) / 8;
-    size_t smem = G::SMEM;
-    if (g_gp_knobs[9] > 0 && G::SMEM < 90 * 1024) {       // tuning aid: force one workgroup per CU
-        smem = 90 * 1024;
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel<NW, NC, MT, CGN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    // tuning aid (knob 9): one workgroup per CU by asking for more LDS than two workgroups could share
+    const size_t smem = (g_gp_knobs[9] > 0 && G::SMEM < 90 * 1024) ? 90 * 1024 : G::SMEM;
+    uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
+    GP_CHECK_ARG(!stamp || g_gp_debug_bytes[0] >= (size_t)(per_xcd * 8) * NW * 10 * sizeof(uint64_t),
+                 "gp_pool_mfma_apply: the stamp buffer of gp_debug_ptr(0) holds %zu bytes, this launch writes %zu",
+                 g_gp_debug_bytes[0], (size_t)(per_xcd * 8) * NW * 10 * sizeof(uint64_t));
+#define PM_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,                        \
+                static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale, stamp
+    if (stamp) {                                          // tuning aid: the instantiation with in-kernel time stamps
+        GP_SMEM_ATTR((pool_mfma_tuning_kernel<NW, NC, MT, CGN, true>), 90 * 1024 > G::SMEM ? 90 * 1024 : G::SMEM);
+        pool_mfma_tuning_kernel<NW, NC, MT, CGN, true><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(PM_ARGS);
+    } else if (g_gp_knobs[4] != 0) {                      // tuning aid: parts of the kernel switched off (never the product kernel)
+        GP_SMEM_ATTR((pool_mfma_tuning_kernel<NW, NC, MT, CGN, false>), 90 * 1024 > G::SMEM ? 90 * 1024 : G::SMEM);
+        pool_mfma_tuning_kernel<NW, NC, MT, CGN, false><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(PM_ARGS);
+    } else {
+        GP_SMEM_ATTR((pool_mfma_kernel<NW, NC, MT, CGN>), 90 * 1024 > G::SMEM ? 90 * 1024 : G::SMEM);
+        pool_mfma_kernel<NW, NC, MT, CGN><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(PM_ARGS);
     }
-    if (g_gp_debug_ptr[0]) {                              // tuning aid: the instantiation with in-kernel time stamps
-        static bool sattr = false;
-        if (!sattr) {
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_kernel<NW, NC, MT, CGN, true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem > G::SMEM ? smem : G::SMEM)));
-            sattr = true;
-        }
-        pool_mfma_kernel<NW, NC, MT, CGN, true><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(
-            static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
-            static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
-            static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale,
-            static_cast<uint64_t *>(g_gp_debug_ptr[0]));
-        GP_CHECK_LAUNCH();
-        return GP_OK;
-    }
-    pool_mfma_kernel<NW, NC, MT, CGN><<<(unsigned)(per_xcd * 8), NW * 64, smem, s>>>(
-        static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
-        static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),
-        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale);
+#undef PM_ARGS
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -959,22 +971,15 @@ int pg_launch(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *b
               const void *wa_lo, int64_t nblocks, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
               const float *out_scale, unsigned *queue, hipStream_t s) {
     using P = PgGeo<MT, XD>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_mfma_persist_kernel<MT, XD, F32OUT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::SMEM));
-        int dev = 0;
-        GP_CHECK_HIP(hipGetDevice(&dev));
-        GP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
+    GP_SMEM_ATTR((pool_mfma_persist_kernel<MT, XD, F32OUT>), P::SMEM);
+    const int n_cu = gp_cu_count();
+    GP_CHECK_ARG(n_cu > 0, "gp_pool_mfma_apply_persistent: cannot read the device's compute-unit count");
     int per_label = g_gp_knobs[10] > 0 ? g_gp_knobs[10] : (n_cu >= 8 ? n_cu / 8 : 1);      // workgroups per XCD label
     if (g_gp_knobs[12] == 1) queue = nullptr;                                              // tuning aid: the static tile lists
     pool_mfma_persist_kernel<MT, XD, F32OUT><<<(unsigned)(per_label * 8), 512, P::SMEM, s>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row,
         static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nblocks, static_cast<_Float16 *>(y_hi),
-        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, out_scale, g_gp_knobs[4], queue);
+        static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, out_scale, queue);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -24,6 +24,7 @@
 
 extern int g_gp_knobs[16];
 extern void *g_gp_debug_ptr[4];
+extern size_t g_gp_debug_bytes[4];
 
 namespace {
 
@@ -301,19 +302,21 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
     auto issue = [&](i32x4 id, unsigned mk, int k, int slot) {
         unsigned char *dst = smem_raw + slot * CS_STAGE;
         const int ida = du ? id.y : id.x, idb = du ? id.w : id.z;
-        const int64_t s0 = (int64_t)ida * ld_x + dsrc0, s1 = (int64_t)idb * ld_x + dsrc1;
-        if (!(ablate & 2)) {                               // tuning aid: bit 1 skips the row gather
-            cs_glds16(x_hi + s0, dst + (4 * wv) * CS_RB);
-            cs_glds16(x_lo + s0, dst + CS_PLANE + (4 * wv) * CS_RB);
-            cs_glds16(x_hi + s1, dst + (4 * wv) * CS_RB + 1024);
-            cs_glds16(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
-        }
-        if (!(ablate & 8)) {                               // tuning aid: bit 3 skips the weight fragments
-            // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line) to keep the DMA count fixed
-            const int lo = ((mk >> wv) & 1u) ? lane * 8 : 0;
-            cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
-            cs_glds16(wal + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + CS_WPL + wv * 1024);
-        }
+        // Every stage is EXACTLY CS_DMA = 6 LDS-DMA instructions per wave, in every tuning mask: the hand-over's hand-counted
+        // `vmcnt(CS_DMA)` means "the older stage has landed" only then.  Tuning bit 1 (no row gather) and bit 3 (no weight
+        // fragments) therefore do not drop instructions, they make all lanes fetch ONE hot 16-byte piece instead (round 3
+        // dropped them: the ceiling launches of bench.py handed a slot over with half of the older stage in flight, and the
+        // 64-row kernel of pool_mfma.hip, whose row ids ride in the ring, read stale ids and faulted).
+        const bool hot_x = (ablate & 2) != 0, hot_w = (ablate & 8) != 0;
+        const int64_t s0 = hot_x ? 0 : (int64_t)ida * ld_x + dsrc0, s1 = hot_x ? 0 : (int64_t)idb * ld_x + dsrc1;
+        cs_glds16(x_hi + s0, dst + (4 * wv) * CS_RB);
+        cs_glds16(x_lo + s0, dst + CS_PLANE + (4 * wv) * CS_RB);
+        cs_glds16(x_hi + s1, dst + (4 * wv) * CS_RB + 1024);
+        cs_glds16(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
+        // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line)
+        const int lo = (((mk >> wv) & 1u) && !hot_w) ? lane * 8 : 0;
+        cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
+        cs_glds16(wal + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + CS_WPL + wv * 1024);
     };
     auto load_ids = [&](int k) { return *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS); };
 
@@ -569,14 +572,17 @@ __device__ __forceinline__ void eg_signal(uint32_t flag_addr) {
     }
 }
 
-template <bool STAMP>
-__global__ void __launch_bounds__(512, 2)
-cs_engine_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
-                 const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
-                 const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
-                 _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
-                 int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
+// (TUNE: the tuning bits of `ablate_` are honoured; the product instantiation compiles them out.  The loaders wait vmcnt(0)
+// for their own stage, so a dropped instruction cannot mis-time a hand-over here.)
+template <bool STAMP, bool TUNE>
+__device__ __forceinline__ void
+cs_engine_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
+               const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
+               const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
+               _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
+               int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int ablate = TUNE ? ablate_ : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
@@ -805,6 +811,18 @@ cs_engine_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__
     }
 }
 
+#define EG_PARAMS const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x, const int64_t *__restrict__ bu_off,            \
+                  const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask, const _Float16 *__restrict__ wa_hi,                      \
+                  const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks, _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo,         \
+                  int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp
+#define EG_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, ablate, out_scale, stamp
+// the product engine (no tuning bits, no stamps) and the same body with both live, under its own name in a kernel trace
+__global__ void __launch_bounds__(512, 2) cs_engine_kernel(EG_PARAMS) { cs_engine_body<false, false>(EG_FWD); }
+template <bool STAMP>
+__global__ void __launch_bounds__(512, 2) cs_engine_tuning_kernel(EG_PARAMS) { cs_engine_body<STAMP, true>(EG_FWD); }
+#undef EG_PARAMS
+#undef EG_FWD
+
 size_t cs_scan_tmp(int64_t n) {
     size_t t = 0;
     (void)rocprim::exclusive_scan(nullptr, t, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0);
@@ -864,9 +882,12 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
 }
 
 // One application y = A x on pre-split operands (see gp_pool_mfma_apply for the operand conventions).  d must be 512.
-extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
-                                const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
-                                void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream_) {
+// engine = false: cs_pool_kernel (one tile per workgroup, the default); engine = true: cs_engine_kernel (persistent producer /
+// consumer form, one workgroup per CU).  The choice is an ARGUMENT of the call (round 3 selected the engine through the
+// process-global debug knob 11: a raised error left every later launch on the engine, and two host threads raced on it).
+static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                    const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
+                    void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, bool engine, void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0, "gp_pool_cs_apply: null/empty argument");
     GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply: d=%d (kernel specialised for %d columns)", d, CS_D);
     GP_CHECK_ARG((y_hi && y_lo) || y_f32, "gp_pool_cs_apply: no output requested");
@@ -875,44 +896,65 @@ extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x
                  "gp_pool_cs_apply: y rows must be 16-byte aligned and must not alias x");
     GP_CHECK_ARG(!y_f32 || (ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0), "gp_pool_cs_apply: fp32 output rows must be 16-byte aligned");
     hipStream_t s = gp_stream(stream_);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_SMEM));
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_SMEM));
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_pool_tuning_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_SMEM));
-        attr_set = true;
-    }
     const int64_t nb = (nv + CS_BR - 1) / CS_BR;
     const int64_t per_xcd = (nb * (CS_D / CS_NC) + 7) / 8;
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
-#define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
-                static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
-                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, g_gp_knobs[4], out_scale, stamp
-    if (g_gp_knobs[11] == 8) {                            // the producer / consumer engine (persistent, one workgroup per CU)
-        static bool eattr = false;
-        static int n_cu = 0;
-        if (!eattr) {
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_engine_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EG_SMEM));
-            GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_engine_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EG_SMEM));
-            int dev = 0;
-            GP_CHECK_HIP(hipGetDevice(&dev));
-            GP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-            eattr = true;
-        }
+    const int tune = g_gp_knobs[4];                       // tuning bits: only ever handed to the *_tuning_kernel twins
+    if (engine) {
+        const int n_cu = gp_cu_count();
+        GP_CHECK_ARG(n_cu > 0, "gp_pool_cs_apply_engine: cannot read the device's compute-unit count");
         const unsigned grid = (unsigned)((n_cu >= 8 ? n_cu / 8 : 1) * 8);
+        GP_CHECK_ARG(!stamp || g_gp_debug_bytes[0] >= (size_t)grid * 4 * 10 * sizeof(uint64_t),
+                     "gp_pool_cs_apply_engine: the stamp buffer of gp_debug_ptr(0) holds %zu bytes, this launch writes %zu",
+                     g_gp_debug_bytes[0], (size_t)grid * 4 * 10 * sizeof(uint64_t));
 #define EG_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
-                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, g_gp_knobs[4], out_scale, stamp
-        if (stamp) cs_engine_kernel<true><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
-        else cs_engine_kernel<false><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, tune, out_scale, stamp
+        if (stamp) {
+            GP_SMEM_ATTR(cs_engine_tuning_kernel<true>, EG_SMEM);
+            cs_engine_tuning_kernel<true><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
+        } else if (tune != 0) {
+            GP_SMEM_ATTR(cs_engine_tuning_kernel<false>, EG_SMEM);
+            cs_engine_tuning_kernel<false><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
+        } else {
+            GP_SMEM_ATTR(cs_engine_kernel, EG_SMEM);
+            cs_engine_kernel<<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
+        }
 #undef EG_ARGS
         GP_CHECK_LAUNCH();
         return GP_OK;
     }
-    if (stamp) cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
-    else if (g_gp_knobs[4] != 0) cs_pool_tuning_kernel<<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
-    else cs_pool_kernel<false><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    GP_CHECK_ARG(!stamp || g_gp_debug_bytes[0] >= (size_t)(per_xcd * 8) * CS_NW * 10 * sizeof(uint64_t),
+                 "gp_pool_cs_apply: the stamp buffer of gp_debug_ptr(0) holds %zu bytes, this launch writes %zu",
+                 g_gp_debug_bytes[0], (size_t)(per_xcd * 8) * CS_NW * 10 * sizeof(uint64_t));
+#define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
+                static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp
+    if (stamp) {
+        GP_SMEM_ATTR(cs_pool_kernel<true>, CS_SMEM);
+        cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    } else if (tune != 0) {
+        GP_SMEM_ATTR(cs_pool_tuning_kernel, CS_SMEM);
+        cs_pool_tuning_kernel<<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    } else {
+        GP_SMEM_ATTR(cs_pool_kernel<false>, CS_SMEM);
+        cs_pool_kernel<false><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    }
 #undef CS_ARGS
     GP_CHECK_LAUNCH();
     return GP_OK;
+}
+
+extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                                const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
+                                void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream_) {
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, false, stream_);
+}
+
+// The same application through the persistent producer / consumer engine (cs_engine_kernel); bit-identical results.
+extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                                       const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
+                                       void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale,
+                                       void *stream_) {
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, true, stream_);
 }

@@ -200,12 +200,7 @@ extern "C" int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_m
     GP_CHECK_ARG(cout > 0 && cout % BN == 0, "gp_sparse_conv: cout=%d must be a multiple of %d", cout, BN);
     GP_CHECK_ARG(ld_x % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0, "gp_sparse_conv: x/w rows must be 16-byte aligned");
     GP_CHECK_ARG(x != y, "gp_sparse_conv: x and y must not alias");
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_conv_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ConvSmem)));
-        attr_set = true;
-    }
+    GP_SMEM_ATTR(sparse_conv_kernel, sizeof(ConvSmem));
     int m_tiles = (int)((nv + BM - 1) / BM), n_tiles = cout / BN;
     int blocks;
     if (n_tiles <= 8 && (8 % n_tiles) == 0) {

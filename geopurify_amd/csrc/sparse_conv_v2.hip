@@ -142,12 +142,15 @@ __device__ __forceinline__ void mma_step_f16x3(const V2Smem &sm, int buf, int wm
     }
 }
 // grid.x = (#m-tiles upper bound) * n_tiles ; tile -> offset k by a search in tile_off (device)
+// (TUNE: the tuning bits of `ablate_` -- knob 3 -- are honoured; the product instantiation compiles them out)
+template <bool TUNE>
 __global__ void __launch_bounds__(NT2)
 conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
                    const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc,
                    int nseg, int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
-                   float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base) {
+                   float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int ablate = TUNE ? ablate_ : 0;
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ---- which (offset, m-tile, n-tile)?
@@ -253,14 +256,16 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-__global__ void __launch_bounds__(NT2)
-conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
-                       const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
-                       const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
-                       const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
-                       float *__restrict__ P, int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base,
-                       const float *__restrict__ x_inv_scale) {
+template <bool TUNE>
+__device__ __forceinline__ void
+conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
+                     const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
+                     const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
+                     const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
+                     float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base,
+                     const float *__restrict__ x_inv_scale) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int ablate = TUNE ? ablate_ : 0;
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-contiguous tile order: blocks b, b+8, ... share an XCD; each XCD walks a contiguous range of
@@ -380,6 +385,18 @@ conv_phase1_dma_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__rest
         }
     }
 }
+
+#define P1_PARAMS const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh, const int32_t *__restrict__ pair_in, \
+                  const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg,  \
+                  int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, \
+                  int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base, const float *__restrict__ x_inv_scale
+#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale
+// the product kernel (tuning bits compiled out) and its twin with the bits of knob 3 live, under its own name in a trace
+// (bench.py's data-movement ceiling of the convolution and scripts/bench_conv.py's ablations launch the twin)
+__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true>(P1_FWD); }
+#undef P1_PARAMS
+#undef P1_FWD
 
 // sum of a voxel's partial rows in ASCENDING offset order (bitwise reproducible), NL independent loads in flight per round
 // (a voxel has 7.3 partial rows on average: one round of 8 for most voxels)
@@ -709,14 +726,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_CHECK_ARG(nv > 0 && num_pairs > 0 && (kv == 27 || kv == 1), "gp_sparse_conv_f16x3: bad sizes");
     GP_CHECK_ARG(cin % TK == 0, "gp_sparse_conv_f16x3: cin=%d must be a multiple of %d", cin, TK);
     GP_CHECK_ARG(x_hi || (ld_x % 4 == 0 && (uintptr_t)x % 16 == 0), "gp_sparse_conv_f16x3: x rows must be 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_phase1_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(V2Smem)));
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_phase1_dma_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(V2Smem)));
-        attr_set = true;
-    }
+    GP_SMEM_ATTR(conv_phase1_kernel<false>, sizeof(V2Smem));
+    GP_SMEM_ATTR(conv_phase1_kernel<true>, sizeof(V2Smem));
+    GP_SMEM_ATTR(conv_phase1_dma_kernel, sizeof(V2Smem));
+    GP_SMEM_ATTR(conv_phase1_tuning_kernel, sizeof(V2Smem));
     GP_CHECK_ARG(cout % TN == 0, "gp_sparse_conv_f16x3: cout=%d must be a multiple of %d on this path", cout, TN);
     hipStream_t s = gp_stream(stream_);
     int n_tiles = cout / TN;
@@ -753,18 +766,23 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         int64_t row_count = chunked ? ((row_begin + chunk_rows < nv) ? chunk_rows : nv - row_begin) : nv;
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            if (x_hi && !(g_conv_ablate & 16))
-                conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
-                    static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv,
-                    static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate,
-                    tile_begin, tile_count, pair_base, x_row_inv_scale);
-            else {
+            const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+#define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
+                reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
+                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale
+            if (x_hi && !(g_conv_ablate & 16)) {
+                if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+            } else {
                 GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
                 GP_CHECK_ARG(!x_row_inv_scale, "gp_sparse_conv_f16x3: the register-staged path splits unscaled fp32 rows");
-                conv_phase1_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(
-                    x, ld_x, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi),
-                    static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, g_conv_ablate, tile_begin, tile_count, pair_base);
+#define P1R_ARGS x, ld_x, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), \
+                 static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base
+                if (tune) conv_phase1_kernel<true><<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1R_ARGS);
+                else conv_phase1_kernel<false><<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1R_ARGS);
+#undef P1R_ARGS
             }
+#undef P1_ARGS
         }
         conv_phase2_kernel<<<(unsigned)((row_count * 64 + 255) / 256), 256, 0, s>>>(
             partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),

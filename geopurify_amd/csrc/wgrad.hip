@@ -236,11 +236,7 @@ extern "C" int gp_conv_wgrad_f16x3(const void *x_hi, const void *x_lo, int64_t l
     GP_CHECK_ARG(ld_x % 8 == 0 && ld_y % 8 == 0 && ld_x >= cin_pad && ld_y >= cout, "gp_conv_wgrad_f16x3: rows must be 16-byte aligned");
     if (workspace_bytes < gp_conv_wgrad_workspace_bytes(num_segments, cin_pad, cout)) { gp_set_error("gp_conv_wgrad_f16x3: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
-        attr_set = true;
-    }
+    GP_SMEM_ATTR(wgrad_kernel, WG_SMEM);
     const int ntn = cout / WG_T, ntm = (cin_pad + WG_T - 1) / WG_T, ntiles = ntn * ntm;
     float *part = static_cast<float *>(workspace);
     wgrad_kernel<<<(unsigned)(num_segments * ntiles), 512, WG_SMEM, s>>>(

@@ -458,19 +458,15 @@ def pool_cs_build(nbr, w):
 def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, engine=False):
     """x_split / out_split: (hi, lo) f16 [Nv, >=d] pairs; out_f32 fp32 [Nv, >=d]; at least one output.
     out_scale: device scalar multiplied into out_f32 (1/s of a pow2_scale()-scaled x_split).
-    engine: the producer / consumer form of the kernel (same results)."""
+    engine: the producer / consumer form of the kernel (gp_pool_cs_apply_engine; same results)."""
     lib = _lib.load()
-    if engine:
-        lib.gp_debug_set(11, 8)
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
     yh, yl = out_split if out_split is not None else (None, None)
-    check(lib.gp_pool_cs_apply(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
-                               _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
-                               _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()),
-          "gp_pool_cs_apply")
-    if engine:
-        lib.gp_debug_set(11, 0)
+    fn, name = (lib.gp_pool_cs_apply_engine, "gp_pool_cs_apply_engine") if engine else (lib.gp_pool_cs_apply, "gp_pool_cs_apply")
+    check(fn(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
+             _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
+             _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()), name)
     return out_f32 if out_f32 is not None else out_split
 
 

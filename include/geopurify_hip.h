@@ -34,8 +34,13 @@ extern "C" {
 #define GP_KNN_MAX_K 127  /* K+1 <= 128 */
 
 int gp_version(void);
-int gp_debug_set(int32_t key, int32_t value);   /* kernel tuning knobs for experiments (pool_tiles.hip) */
-int gp_debug_ptr(int32_t key, void *device_buffer); /* device buffers for experiments (0: pooling time stamps; NULL = off) */
+/* Tuning knobs for experiments (table in csrc/error.hip).  No knob reaches a PRODUCT kernel: the pooling / convolution  */
+/* tuning bits (knobs 4 / 3) are honoured only by the *_tuning_kernel twins, the others select a launch shape or a slower, */
+/* equally tested kernel.  Unknown keys and undefined values are GP_EINVAL.                                                */
+int gp_debug_set(int32_t key, int32_t value);
+/* Device buffers for experiments (0: pooling time stamps, 10 x uint64 per wave; NULL, 0 = off).  `bytes` is checked by    */
+/* every launch that writes into the buffer.                                                                               */
+int gp_debug_ptr(int32_t key, void *device_buffer, size_t bytes);
 const char *gp_last_error(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -245,6 +250,11 @@ int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, c
 int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                      const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
                      void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream);
+/* The same application through the persistent producer / consumer form of the kernel (cs_engine_kernel, one workgroup per */
+/* CU); bit-identical results.  Its own entry point: the choice of kernel is an argument of the call, not process state.   */
+int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                            const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
+                            void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */

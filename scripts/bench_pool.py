@@ -103,8 +103,7 @@ variants += [("cs128 column-sliced (split out)", ("cs", 0)), ("cs128 column-slic
              ("mfma64 column-sliced waves (split out)", ("mfmacs", 64, 0, 0)),
              ("mfma128 8w x (32r x 128c) (split out)", ("mfma", 128, 0, 0)),
              ("persist64 (split out)", ("persist", 64, 0, 0)), ("persist64 (fp32 out)", ("persist32", 64, 0, 0)),
-             ("persist64 static tile lists (split out)", ("persist", 64, 0, 0, 1)),
-             ("persist64 no-stagger (split out)", ("persist", 64, 32, 0))]
+             ("persist64 static tile lists (split out)", ("persist", 64, 0, 0, 1))]
 ysp = {br: tuple(torch.empty((mf[br].rows_padded, D), dtype=torch.float16, device="cuda") for _ in range(2)) for br in (64,)}
 Yp = {br: torch.empty((mf[br].rows_padded, D), device="cuda") for br in (64,)}
 print("min steps per row block:", {br: mf[br].min_steps for br in (64, 128)}, flush=True)
@@ -121,32 +120,24 @@ for rnd in range(3):
         elif v[0] == "cs":
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
         elif v[0] == "eng":
-            lib.gp_debug_set(11, 8)
-            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys))
-            lib.gp_debug_set(11, 0)
+            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_split=ys, engine=True))
         elif v[0] == "eng32":
-            lib.gp_debug_set(11, 8)
-            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
-            lib.gp_debug_set(11, 0)
+            t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y, engine=True))
         elif v[0] == "cs32":
             t = timeit(lambda: ops.pool_cs_apply(xs, cs, D, out_f32=Y))
         elif v[0] == "mfma":
-            lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
         elif v[0] == "mfmacs":
             lib.gp_debug_set(11, 4)
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_split=ys))
             lib.gp_debug_set(11, 0)
         elif v[0] == "persist":
-            lib.gp_debug_set(4, v[2]); lib.gp_debug_set(11, v[3]); lib.gp_debug_set(12, v[4] if len(v) > 4 else 0)
+            lib.gp_debug_set(12, v[4] if len(v) > 4 else 0)
             t = timeit(lambda: ops.pool_mfma_apply_persistent(xs, mf[v[1]], D, out_split=ysp[v[1]]))
-            lib.gp_debug_set(4, ABL); lib.gp_debug_set(11, 0); lib.gp_debug_set(12, 0)
+            lib.gp_debug_set(12, 0)
         elif v[0] == "persist32":
-            lib.gp_debug_set(4, v[2]); lib.gp_debug_set(11, v[3])
             t = timeit(lambda: ops.pool_mfma_apply_persistent(xs, mf[v[1]], D, out_f32=Yp[v[1]]))
-            lib.gp_debug_set(4, ABL); lib.gp_debug_set(11, 0)
         elif v[0] == "mfma32":
-            lib.gp_debug_set(7, v[2]); lib.gp_debug_set(8, v[3])
             t = timeit(lambda: ops.pool_mfma_apply(xs, mf[v[1]], D, out_f32=Y))
         else:
             R, nf4, un = v
@@ -160,10 +151,10 @@ yc = torch.empty((Nv, D), device="cuda"); ye = torch.empty((Nv, D), device="cuda
 ops.pool_cs_apply(xs, cs, D, out_f32=yc)
 ops.pool_ell(X, nbr, w, D, ye)
 print("cs128 vs ELL max |diff|:", float((yc - ye).abs().max()), flush=True)
-lib.gp_debug_set(11, 8)
 yg = torch.empty((Nv, D), device="cuda")
-ops.pool_cs_apply(xs, cs, D, out_f32=yg)
-lib.gp_debug_set(11, 0)
+lib.gp_debug_set(4, 0)                                   # the comparisons below run the product kernels
+ops.pool_cs_apply(xs, cs, D, out_f32=yc)
+ops.pool_cs_apply(xs, cs, D, out_f32=yg, engine=True)
 torch.cuda.synchronize()
 print("engine vs ELL max |diff|:", float((yg - ye).abs().max()), " engine == cs128 bitwise:", bool(torch.equal(yg, yc)), flush=True)
 # the column-sliced wave mapping computes the same sums in the same order per element: identical outputs

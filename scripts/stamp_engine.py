@@ -26,19 +26,18 @@ op = ops.pool_cs_build(nbr, w)
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
 buf = torch.zeros(256 * 4 * 10, dtype=torch.int64, device="cuda")
-lib.gp_debug_set(11, 8)
 for _ in range(3):
-    ops.pool_cs_apply(xs, op, D, out_split=ys)
+    ops.pool_cs_apply(xs, op, D, out_split=ys, engine=True)
 torch.cuda.synchronize()
 lib.gp_debug_set(4, ABL)
-lib.gp_debug_ptr(0, buf.data_ptr())
-ops.pool_cs_apply(xs, op, D, out_split=ys)
+lib.gp_debug_ptr(0, buf.data_ptr(), buf.numel() * 8)
+ops.pool_cs_apply(xs, op, D, out_split=ys, engine=True)
 torch.cuda.synchronize()
 buf.zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); ops.pool_cs_apply(xs, op, D, out_split=ys); e1.record()
+e0.record(); ops.pool_cs_apply(xs, op, D, out_split=ys, engine=True); e1.record()
 torch.cuda.synchronize()
-lib.gp_debug_ptr(0, None); lib.gp_debug_set(4, 0); lib.gp_debug_set(11, 0)
+lib.gp_debug_ptr(0, None, 0); lib.gp_debug_set(4, 0)
 s = buf.cpu().numpy().reshape(-1, 4, 10).astype(np.float64)
 tot, work, poll, epi, steps = s[..., 7], s[..., 3], s[..., 4], s[..., 6], s[..., 8]
 print(f"ablate={ABL} launch {e0.elapsed_time(e1) * 1e3:.1f} us (stamped); consumer waves {tot.size}; steps per wave {steps.mean():.1f} (min {steps.min():.0f}, max {steps.max():.0f})")

@@ -46,7 +46,7 @@ for _ in range(3):
     apply(xs, op, D, out_split=ys)
 torch.cuda.synchronize()
 lib.gp_debug_set(4, ABL)
-lib.gp_debug_ptr(0, buf.data_ptr())
+lib.gp_debug_ptr(0, buf.data_ptr(), buf.numel() * 8)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 apply(xs, op, D, out_split=ys)
 torch.cuda.synchronize()
@@ -55,7 +55,7 @@ e0.record()
 apply(xs, op, D, out_split=ys)
 e1.record()
 torch.cuda.synchronize()
-lib.gp_debug_ptr(0, None)
+lib.gp_debug_ptr(0, None, 0)
 lib.gp_debug_set(4, 0)
 ms = e0.elapsed_time(e1)
 s = buf.cpu().numpy().reshape(-1, NW, 10)

@@ -37,3 +37,20 @@ def test_size_queries_without_gpu():
     bad = (ctypes.c_int32 * 3)(0, 5, 5)
     assert lib.gp_grid_bytes(10, bad) == 0
     assert lib.gp_nn1_workspace_bytes(1000, 100) > 0
+
+
+def test_debug_knobs_reject_what_is_not_in_the_table():
+    """gp_debug_set is a declared export; a key or value outside the table of csrc/error.hip is GP_EINVAL
+    (host-side check, no GPU needed).  The engine is no longer a knob (11 = 8): it is gp_pool_cs_apply_engine."""
+    lib = _lib.load()
+    EINVAL = -22
+    for key, value in ((0, 0), (8, 1), (16, 0), (-1, 0),         # no such knob
+                       (4, 128), (4, 1024), (4, -1),             # pooling mask: bit 7 and bits >= 10 are undefined
+                       (3, 64), (11, 8), (11, 1), (7, 1), (5, 2), (15, 3), (1, 5), (10, 65)):
+        assert lib.gp_debug_set(key, value) == EINVAL, (key, value)
+        assert b"gp_debug_set" in lib.gp_last_error()
+    for key, value in ((4, 9), (4, 0), (3, 2), (3, 0), (11, 4), (11, 0), (15, 2), (15, 0), (7, 2), (7, 0)):
+        assert lib.gp_debug_set(key, value) == 0, (key, value)
+    # a stamp buffer comes with its size
+    assert lib.gp_debug_ptr(0, None, 64) == EINVAL and lib.gp_debug_ptr(4, None, 0) == EINVAL
+    assert lib.gp_debug_ptr(0, None, 0) == 0

@@ -89,6 +89,7 @@ def test_pooling_properties_full_size(big):
     Nv, D = nbr.shape[0], 512
     tiles = ops.pool_tiles_build(nbr, w, 8)
     mfma = {br: ops.pool_mfma_build(nbr, w, br, min_steps=9 if br == 64 else 0) for br in (64, 128)}   # (64: the persistent kernel's operator)
+    cs_op = ops.pool_cs_build(nbr, w)                       # the DEFAULT kernel's operator (cs_pool_kernel / cs_engine_kernel)
     X = torch.randn(Nv, 544, device="cuda")
     Y = torch.randn(Nv, 544, device="cuda")
 
@@ -98,6 +99,8 @@ def test_pooling_properties_full_size(big):
             ops.pool_ell(z, nbr, w, D, out)
         elif mode == "tiles":
             ops.pool_tiles_apply(z, tiles, D, out)
+        elif mode in ("cs", "engine"):                      # the benchmarked default and its producer / consumer form
+            ops.pool_cs_apply(ops.split_f16(z, D), cs_op, D, out_f32=out, engine=mode == "engine")
         elif isinstance(mode, str):                         # "p64": the persistent kernel (outputs padded to row blocks)
             op = mfma[int(mode[1:])]
             assert op.min_steps >= 9                        # the builder pads every row block to >= 9 steps
@@ -109,15 +112,35 @@ def test_pooling_properties_full_size(big):
             ops.pool_mfma_apply(ops.split_f16(z, D), mfma[mode], D, out_f32=out)
         return out
     ones = torch.ones(Nv, 544, device="cuda")
-    for mode in ("ell", "tiles", 64, 128, "p64"):
+    for mode in ("ell", "tiles", 64, 128, "p64", "cs", "engine"):
         assert (P(ones, mode) - 1).abs().max() < 1e-5                                # A 1 = 1
         lin = P((2.0 * X - 0.5 * Y).contiguous(), mode) - (2.0 * P(X, mode) - 0.5 * P(Y, mode))
         assert lin.abs().max() < 1e-4                                                 # linearity
         px = P(X, mode)
         assert (px.amax(0) <= X[:, :D].amax(0) + 1e-5).all() and (px.amin(0) >= X[:, :D].amin(0) - 1e-5).all()   # convexity
     ref = P(X, "ell")
-    for mode in ("tiles", 64, 128, "p64"):
+    for mode in ("tiles", 64, 128, "p64", "cs", "engine"):
         assert (P(X, mode) - ref).abs().max() < 1e-5                                  # independent kernels agree
+    # the default kernel at full size: chained split hand-off == ELL twice, the engine gives the
+    # default kernel's bits, and five launches over NaN-filled outputs reproduce them bit for bit
+    xs = ops.split_f16(X, D)
+    ref2 = torch.empty(Nv, D, device="cuda")
+    ops.pool_ell(ref, nbr, w, D, ref2)
+    first = {}
+    for engine in (False, True):
+        mid = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+        out2 = torch.empty(Nv, D, device="cuda")
+        ops.pool_cs_apply(xs, cs_op, D, out_split=mid, engine=engine)
+        ops.pool_cs_apply(mid, cs_op, D, out_f32=out2, engine=engine)
+        assert (out2 - ref2).abs().max() < 2e-5
+        first[engine] = (mid, out2)
+        for _ in range(5):
+            m2 = tuple(torch.full((Nv, D), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+            o2 = torch.full((Nv, D), float("nan"), device="cuda")
+            ops.pool_cs_apply(xs, cs_op, D, out_split=m2, engine=engine)
+            ops.pool_cs_apply(m2, cs_op, D, out_f32=o2, engine=engine)
+            assert torch.equal(m2[0], mid[0]) and torch.equal(m2[1], mid[1]) and torch.equal(o2, out2)
+    assert torch.equal(first[False][1], first[True][1]) and torch.equal(first[False][0][0], first[True][0][0])
     # the persistent kernel's split (hi, lo) output feeds its next application: two chained == ELL twice
     for br in (64,):
         op = mfma[br]
@@ -263,3 +286,81 @@ def test_all_views_lift_equals_view_by_view_full_size(big):
     assert torch.equal(F_all, F_one)
     nrm = F_all.norm(dim=1)
     assert bool((nrm > 0).all()) and bool((nrm < 1 + 1e-4).all()) and ((nrm - 1).abs() < 1e-4).float().mean() > 0.5
+
+
+def _scene_run(cfg_name, seed, pool_iters, **over):
+    """One whole scene of a BASELINE configuration at FULL size through the device path; returns what the property checks need."""
+    import dataclasses
+    from geopurify_amd import pipeline as pl, synthetic as syn
+    cfg = dataclasses.replace(syn.CONFIGS[cfg_name], **over) if over else syn.CONFIGS[cfg_name]
+    scene = syn.make_scene(cfg, seed)
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, seed)
+    if cfg.dense_features:
+        feat = syn.make_dense_feature_maps(cfg, cfg.num_views, seed)
+        text = np.random.default_rng(seed).normal(size=(cfg.num_classes, cfg.feat_dim)).astype(np.float32)
+        vlm = pl.DenseFeatureVLM(feat, text, 1 / 0.07, "cuda")
+    else:
+        vlm = pl.SyntheticVLM(syn.make_vlm_outputs(cfg, cfg.num_views, seed), "cuda")
+    sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
+    hp = pl.HotPath(pl.StudentWeights(sd, "cuda"), cfg.mask_shape, K=96, sharpen=20.0, num_iters=pool_iters, device="cuda")
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+    F, text, scale = hp.lift_dense(batch, vlm) if cfg.dense_features else hp.lift_masks(batch, vlm)
+    feats = hp.refine(batch, F)
+    counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device="cuda")
+    pred, _ = hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale}, batch.scene_label,
+                                    cfg.num_classes, cfg.ignore_ids, counts)
+    torch.cuda.synchronize()
+    return dict(cfg=cfg, scene=scene, rigid=rigid, vlm=vlm, hp=hp, batch=batch, F=F, feats=feats, counts=counts, pred=pred, pl=pl, syn=syn)
+
+
+def _check_scene_properties(r):
+    cfg, scene, batch, F, feats, counts, pred, hp = (r[k] for k in ("cfg", "scene", "batch", "F", "feats", "counts", "pred", "hp"))
+    assert feats.shape == (scene.coords.shape[0], cfg.feat_dim) and bool(torch.isfinite(feats).all())
+    # exact IoU bookkeeping (util/util.py:160-177): target histogram, prediction total, intersection <= both
+    lab = torch.from_numpy(scene.labels)
+    valid = lab < cfg.num_classes
+    assert torch.equal(counts[2].cpu(), torch.bincount(lab[valid], minlength=cfg.num_classes))
+    assert int(counts[1].sum()) == int(valid.sum()) and bool((counts[0] <= counts[2]).all()) and bool((counts[0] <= counts[1]).all())
+    assert torch.equal(counts[0].cpu(), torch.bincount(lab[valid & (pred.cpu() == lab)], minlength=cfg.num_classes))
+    # points of one voxel receive the same pooled row (the final gather, affinity_module.py:1589)
+    inv = batch.scene_inds_reconstruct.long()
+    nv = int(inv.max()) + 1
+    rep = torch.full((nv,), feats.shape[0], dtype=torch.int64, device="cuda").scatter_reduce(0, inv, torch.arange(feats.shape[0], device="cuda"), "amin")
+    assert torch.equal(feats, feats[rep[inv]])
+    # pooling is a convex combination of the voxel means of the lifted features: column ranges can only shrink
+    assert bool((feats.amax(0) <= F.amax(0) + 1e-4).all()) and bool((feats.amin(0) >= F.amin(0) - 1e-4).all())
+    return nv
+
+
+def test_config_m_full_size_properties():
+    """BASELINE configs[3] at its FULL size: Matterport3D-shaped region, 500k points, 80 views, 160 classes
+    (config/geopurify_matterport160.yaml: 160 classes, ignore 255), depth scale 4000, visibility threshold 0.02, T = 19 --
+    through the default kernels, checked by size-independent properties; the all-views lift equals the view-by-view lift."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _scene_run("M", 31, 19)
+    cfg, hp, batch, pl = r["cfg"], r["hp"], r["batch"], r["pl"]
+    assert cfg.num_points == 500_000 and cfg.num_views == 80 and cfg.num_classes == 160 and cfg.depth_scale == 4000.0
+    nv = _check_scene_properties(r)
+    assert 0.7 * cfg.num_points < nv < cfg.num_points and hp.stats["pool_kernel"] == "cs_pool_kernel"
+    assert 60 <= len(batch.views) <= 80 and batch.ent is not None and batch.ent["max_nv"] < 131072     # the all-views path ran
+    # all-views lift == view-by-view lift, bit for bit, at 80 views
+    b_one = pl.build_scene_batch(pl.upload_scene(r["scene"], "cuda"), r["rigid"], "cuda", batch_views=False)
+    hp1 = pl.HotPath(hp.student, cfg.mask_shape, K=96, num_iters=1, device="cuda", batch_views=False)
+    F_one, _, _ = hp1.lift_masks(b_one, r["vlm"])
+    assert torch.equal(F_one, r["F"])
+
+
+def test_config_p_full_size_properties():
+    """BASELINE configs[0] at its full size: 50k points, ONE view, 64-d dense features (lift a5), T = 19; the generic ELL
+    pooling kernel (D = 64) and the f16x3 student with a 70-channel input layer."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _scene_run("P", 7, 19)
+    cfg = r["cfg"]
+    assert cfg.num_points == 50_000 and cfg.num_views == 1 and cfg.feat_dim == 64 and cfg.dense_features
+    nv = _check_scene_properties(r)
+    assert 0.7 * cfg.num_points < nv < cfg.num_points
+    assert r["hp"].stats["pool_kernel"] == "pool_ell_kernel"
+    # dense lift: a seen point's feature is the mean of its pixels' columns; every point has one (nearest-seen fill): no zero rows
+    assert bool((r["F"].abs().sum(1) > 0).all())

@@ -555,6 +555,65 @@ def test_error_paths(ops):
     assert ops.pool_mfma_build(nb2, w2, 64).min_steps < 9 <= ops.pool_mfma_build(nb2, w2, 64, min_steps=9).min_steps
     with pytest.raises(GeoPurifyHipError, match="min_steps"):
         ops.pool_mfma_build(nb2, w2, 64, min_steps=65)
+    # tuning knobs: an undefined mask is rejected, a stamp buffer that is too small is rejected at the launch
+    from geopurify_amd import _lib
+    lib = _lib.load()
+    assert lib.gp_debug_set(4, 128) == -22 and lib.gp_debug_set(11, 8) == -22 and lib.gp_debug_set(8, 0) == -22
+    opm = ops.pool_mfma_build(nb2, w2, 64)
+    xs2 = ops.split_f16(torch.randn(200, 512, device="cuda"), 512)
+    ys2 = tuple(torch.empty((200, 512), dtype=torch.float16, device="cuda") for _ in range(2))
+    small = torch.zeros(8, dtype=torch.int64, device="cuda")
+    assert lib.gp_debug_ptr(0, small.data_ptr(), small.numel() * 8) == 0
+    try:
+        with pytest.raises(GeoPurifyHipError, match="stamp buffer"):
+            ops.pool_mfma_apply(xs2, opm, 512, out_split=ys2)
+    finally:
+        assert lib.gp_debug_ptr(0, None, 0) == 0
+
+
+def test_pooling_tuning_masks_keep_the_ring_discipline(ops):
+    """The round-3 faults (scripts/bench_pool.py, pooling knob 4 = 8 / 9: memory access fault in pool_mfma_kernel): tuning bit 3
+    dropped two of a stage's seven LDS-DMA instructions while the hand-over kept waiting vmcnt(7), so the older stage's row-id
+    load could still be in flight when the ids were read back -- garbage row numbers went into the gather.  Now (a) the product
+    kernels compile the bits out and (b) the *_tuning_kernel twins replace a switched-off fetch by one hot piece, keeping the
+    instruction count.  Every mask that faulted (8, 9) and every other combination of the fetch bits must run to completion on
+    every matrix-core kernel, and with the bits cleared the results must be the product kernels' bits."""
+    from geopurify_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    c = surface_voxels(rng, 3000)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    nbr = ops.knn_lattice(grid, cs, perm, 96)
+    Nv = cs.shape[0]
+    w = ops.affinity_softmax(torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1), nbr, 20.0)
+    X = torch.randn(Nv, 512, device="cuda")
+    xs = ops.split_f16(X, 512)
+    op_cs = ops.pool_cs_build(nbr, w)
+    op64, op128 = ops.pool_mfma_build(nbr, w, 64), ops.pool_mfma_build(nbr, w, 128)
+    new = lambda: tuple(torch.empty((Nv, 512), dtype=torch.float16, device="cuda") for _ in range(2))
+    runs = {"cs": lambda y: ops.pool_cs_apply(xs, op_cs, 512, out_split=y),
+            "engine": lambda y: ops.pool_cs_apply(xs, op_cs, 512, out_split=y, engine=True),
+            "mfma64": lambda y: ops.pool_mfma_apply(xs, op64, 512, out_split=y),
+            "mfma128": lambda y: ops.pool_mfma_apply(xs, op128, 512, out_split=y)}
+    ref = {}
+    for name, f in runs.items():
+        ref[name] = new()
+        f(ref[name])
+    torch.cuda.synchronize()
+    try:
+        for mask in (8, 9, 2, 10, 11, 1, 3, 16, 24, 27):
+            assert lib.gp_debug_set(4, mask) == 0
+            for name, f in runs.items():
+                f(new())                                                  # results are meaningless; the launch must complete
+            torch.cuda.synchronize()
+    finally:
+        assert lib.gp_debug_set(4, 0) == 0
+    for name, f in runs.items():
+        y = new()
+        f(y)
+        torch.cuda.synchronize()
+        assert torch.equal(y[0], ref[name][0]) and torch.equal(y[1], ref[name][1]), name
+    assert torch.equal(ref["cs"][0], ref["engine"][0]) and torch.equal(ref["cs"][1], ref["engine"][1])
 
 
 # ------------------------------------------------------------------------------------------ row 9 fast path
