@@ -256,16 +256,32 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-template <bool TUNE>
+__device__ __forceinline__ uint64_t cv_now() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ uint64_t cv_real() {
+    uint64_t t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// STAMP (tuning twin only): wave 0 of every workgroup writes 8 x uint64 into `stamp`: {real-time start, real-time length, prologue
+// (descriptor + row ids + first stage landed), K loop, partial-store ISSUE, store drain (vmcnt(0)), whole tile -- shader cycles --,
+// XCC id | pairs << 8}
+template <bool TUNE, bool STAMP>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
                      const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
                      const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
                      const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
                      float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base,
-                     const float *__restrict__ x_inv_scale) {
+                     const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
+    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0;
+    if constexpr (STAMP) { st_t0 = cv_now(); st_r0 = cv_real(); }
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-contiguous tile order: blocks b, b+8, ... share an XCD; each XCD walks a contiguous range of
@@ -333,13 +349,29 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     const int steps = cin / TK;
     issue(0, 0);
     __syncthreads();
+    if constexpr (STAMP) st_pro = cv_now();
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
         if (!(ablate & 2)) mma_step_f16x3<4>(sm, buf, wm, wn, fl, fsw, acc);   // padded rows are computed and discarded
         __syncthreads();
     }
-    if (ablate & 8) return;
+    if constexpr (STAMP) st_loop = cv_now();
+    auto stamp_out = [&]() {
+        if constexpr (STAMP) {
+            st_iss = cv_now();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint64_t t3 = cv_now(), r3 = cv_real();
+            if (tid == 0 && stamp) {
+                uint64_t *o = stamp + (int64_t)blockIdx.x * 8;
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_loop - st_pro; o[4] = st_iss - st_loop;
+                o[5] = t3 - st_iss; o[6] = t3 - st_t0; o[7] = (uint64_t)(xcc & 0xff) | ((uint64_t)cnt << 8);
+            }
+        }
+    };
+    if (ablate & 8) { stamp_out(); return; }
     // ---- epilogue: accumulators straight to the partial buffer (per instruction 4 rows x 64-byte runs, merged in L2).
     //      Staging the tile through LDS for 512-byte runs made every slice's LDS reads wait for the previous slice's
     //      stores (one vector-memory counter): 4 store round trips per tile, a third of the kernel's time.
@@ -358,6 +390,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                 }
             }
         }
+        stamp_out();
         return;
     }
     // (ablate bit 5: the former LDS-staged epilogue, kept for A/B timing)
@@ -389,12 +422,14 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 #define P1_PARAMS const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh, const int32_t *__restrict__ pair_in, \
                   const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg,  \
                   int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, \
-                  int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base, const float *__restrict__ x_inv_scale
-#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale
+                  int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base, const float *__restrict__ x_inv_scale,           \
+                  uint64_t *__restrict__ stamp
+#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp
 // the product kernel (tuning bits compiled out) and its twin with the bits of knob 3 live, under its own name in a trace
 // (bench.py's data-movement ceiling of the convolution and scripts/bench_conv.py's ablations launch the twin)
-__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true>(P1_FWD); }
 #undef P1_PARAMS
 #undef P1_FWD
 
@@ -632,6 +667,8 @@ size_t scan_tmp32(int64_t n) {
 }  // namespace
 
 extern int g_gp_knobs[16];
+extern void *g_gp_debug_ptr[4];
+extern size_t g_gp_debug_bytes[4];
 #define g_conv_ablate g_gp_knobs[3]
 
 
@@ -730,6 +767,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_SMEM_ATTR(conv_phase1_kernel<true>, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_dma_kernel, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_tuning_kernel, sizeof(V2Smem));
+    GP_SMEM_ATTR(conv_phase1_stamp_kernel, sizeof(V2Smem));
+    // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
+    // blockIdx * 8 (a chunk overwrites the previous one's: the last chunk of the last call stays)
+    uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[1]);
     GP_CHECK_ARG(cout % TN == 0, "gp_sparse_conv_f16x3: cout=%d must be a multiple of %d on this path", cout, TN);
     hipStream_t s = gp_stream(stream_);
     int n_tiles = cout / TN;
@@ -769,9 +810,13 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
             const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
-                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale
+                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp
             if (x_hi && !(g_conv_ablate & 16)) {
-                if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 8 * sizeof(uint64_t),
+                             "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
+                             g_gp_debug_bytes[1], (size_t)nblocks * 8 * sizeof(uint64_t));
+                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
             } else {
                 GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
