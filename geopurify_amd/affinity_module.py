@@ -208,7 +208,8 @@ class SonataXAffinityTrainer(nn.Module):
         if V and o > 0:
             ent = {"pt": pts.contiguous(), "x": x_labels.long().contiguous(), "y": y_labels.long().contiguous(),
                    "view": view_of.to(torch.int32).contiguous(), "view_off": torch.cat([counts.new_zeros(1), counts.cumsum(0)]),
-                   "keep": torch.ones(V, dtype=torch.uint8, device=dev), "total": o, "max_nv": max(host[:V]), "num_views": V}
+                   "keep": torch.ones(V, dtype=torch.uint8, device=dev), "total": o, "max_nv": max(host[:V]),
+                   "sum_nv2": float(sum(h * h for h in host[:V])), "num_views": V}
         return SceneBatch(scene_coords.to(dev, non_blocking=nb).float().contiguous(), scene_coords_3d.to(dev, non_blocking=nb).float().contiguous(),
                           scene_inds_reconstruct.to(dev, non_blocking=nb).long().contiguous(), scene_label.to(dev, non_blocking=nb).long(),
                           scene_gauss_features[:, :6].to(dev, non_blocking=nb).float().contiguous(), views, imgs=imgs, ent=ent)

@@ -90,7 +90,14 @@ __global__ void fd_widen_kernel(const uint8_t *__restrict__ m, int64_t n, int32_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= n) o[i] = (i < n && m[i]) ? 1 : 0;
 }
-__global__ void fd_count_kernel(const int32_t *__restrict__ pos, int64_t nv, int64_t *__restrict__ n_sel) { n_sel[0] = pos[nv]; }
+// n_sel[0] = kept voxels; n_sel[1] = points in the chunk = the number of rows a well-formed file holds (the caller compares it
+// with feat_rows: the host formulation of the reference raises on a file whose mask and row count disagree, fd_flags_kernel
+// only masks the rows beyond the file's end)
+__global__ void fd_count_kernel(const int32_t *__restrict__ pos, int64_t nv, const int32_t *__restrict__ rank, int64_t n,
+                                int64_t *__restrict__ n_sel) {
+    n_sel[0] = pos[nv];
+    n_sel[1] = rank[n];
+}
 
 }  // namespace
 
@@ -117,7 +124,7 @@ extern "C" int gp_fused_decode(const uint8_t *mask_chunk, int64_t n, const uint8
     fd_flags_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, s>>>(mask_chunk, n, k.rank, row_keep, feat_rows, vox_ind, nv, k.keep, k.row, mask_out);
     GP_CHECK_HIP(hipMemsetAsync(k.keep + nv, 0, sizeof(int32_t), s));
     GP_CHECK_HIP(rocprim::exclusive_scan(k.tmp, k.tmp_bytes, k.keep, k.pos, (int32_t)0, (size_t)(nv + 1), rocprim::plus<int32_t>(), s));
-    fd_count_kernel<<<1, 1, 0, s>>>(k.pos, nv, n_sel);
+    fd_count_kernel<<<1, 1, 0, s>>>(k.pos, nv, k.rank, n, n_sel);
     const bool v16 = row_bytes % 16 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0;
     const unsigned grid = (unsigned)((nv + 3) / 4);
     if (v16)

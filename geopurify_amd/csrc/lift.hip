@@ -249,16 +249,24 @@ __device__ __forceinline__ bool fill_locate(const int4 *__restrict__ tab, int nv
     r1 = b.y;
     return true;
 }
+// The partial results of the FV_CHUNKS reference parts live in part_d / part_i [FV_CHUNKS][stride], indexed by the QUERY's compact
+// index -- so `stride` only has to cover the fill queries (uncovered entries), not every entry (192 B per entry,
+// 0.7 GB at config M).  The number of queries is known on the device only; the caller passes a capacity (fill_cap) and a block of
+// queries that does not fit below it takes the overflow path: ONE block (blockIdx.y == 0) sweeps the view's whole reference
+// range and writes the result itself -- same (d2, index) rule, same result, no partials, just less parallel.
 __global__ void __launch_bounds__(256)
 fill_part_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ ent_pt, const int4 *__restrict__ tab, int nviews,
                  const float *__restrict__ rxyz, const int32_t *__restrict__ qent,
-                 double *__restrict__ part_d, int32_t *__restrict__ part_i, int64_t stride) {
+                 double *__restrict__ part_d, int32_t *__restrict__ part_i, int64_t stride,
+                 const int32_t *__restrict__ rent, int32_t *__restrict__ seg) {
     __shared__ double sx[FV_TILE], sy[FV_TILE], sz[FV_TILE];
     int q0, q1, vr0, vr1;
     if (!fill_locate(tab, nviews, blockIdx.x, q0, q1, vr0, vr1)) return;                  // block-uniform
     const int n_ref = vr1 - vr0;
     if (n_ref == 0) return;
-    const int per = (n_ref + FV_CHUNKS - 1) / FV_CHUNKS;
+    const bool overflow = (int64_t)q0 + 256 > stride;                                     // block-uniform
+    if (overflow && blockIdx.y != 0) return;
+    const int per = overflow ? n_ref : (n_ref + FV_CHUNKS - 1) / FV_CHUNKS;
     const int r0 = vr0 + blockIdx.y * per, r1 = r0 + per < vr1 ? r0 + per : vr1;
     const int qi = q0 + threadIdx.x;
     const bool live = qi < q1;
@@ -282,7 +290,13 @@ fill_part_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ ent_
             if (d2 < best) { best = d2; bi = t0 + j; }
         }
     }
-    if (live) { part_d[(int64_t)blockIdx.y * stride + qi] = best; part_i[(int64_t)blockIdx.y * stride + qi] = bi; }
+    if (!live) return;
+    if (overflow) {
+        if (bi >= 0) seg[qent[qi]] = seg[rent[bi]];              // references keep their segment: no read/write overlap
+        return;
+    }
+    part_d[(int64_t)blockIdx.y * stride + qi] = best;
+    part_i[(int64_t)blockIdx.y * stride + qi] = bi;
 }
 __global__ void fill_reduce_kernel(const int4 *__restrict__ tab, int nviews,
                                    const double *__restrict__ part_d, const int32_t *__restrict__ part_i, int64_t stride,
@@ -290,6 +304,7 @@ __global__ void fill_reduce_kernel(const int4 *__restrict__ tab, int nviews,
     int q0, q1, vr0, vr1;
     if (!fill_locate(tab, nviews, blockIdx.x, q0, q1, vr0, vr1)) return;
     if (vr1 == vr0) return;
+    if ((int64_t)q0 + 256 > stride) return;                      // an overflow block wrote its results itself
     const int qi = q0 + threadIdx.x;
     if (qi >= q1) return;
     const int per = (vr1 - vr0 + FV_CHUNKS - 1) / FV_CHUNKS;
@@ -550,7 +565,8 @@ struct LvWork {
     float *mt; int32_t *cov, *rs, *rent, *qent; float *rxyz; double *part_d; int32_t *part_i; unsigned long long *vmask; int4 *tab;
     int64_t *cnt; char *tmp; size_t tmp_bytes;
 };
-static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n, LvWork &k) {
+static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n, int64_t fill_cap,
+                       LvWork &k) {
     GpCarver cv(ws, bytes);
     k.mt = cv.take<float>((size_t)nsrc * q * h * w);
     k.cov = cv.take<int32_t>(total + 1);
@@ -558,8 +574,8 @@ static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t 
     k.rent = cv.take<int32_t>(total);
     k.qent = cv.take<int32_t>(total);
     k.rxyz = cv.take<float>(total * 3);
-    k.part_d = cv.take<double>((size_t)FV_CHUNKS * total);
-    k.part_i = cv.take<int32_t>((size_t)FV_CHUNKS * total);
+    k.part_d = cv.take<double>((size_t)FV_CHUNKS * fill_cap);
+    k.part_i = cv.take<int32_t>((size_t)FV_CHUNKS * fill_cap);
     k.vmask = cv.take<unsigned long long>(n * 2);
     k.cnt = cv.take<int64_t>(n + 1);
     k.tab = cv.take<int4>(130);
@@ -568,10 +584,14 @@ static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t 
     k.tmp = cv.take<char>(k.tmp_bytes);
     return cv.off;
 }
-extern "C" size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n) {
-    if (nsrc <= 0 || q <= 0 || h <= 0 || w <= 0 || total <= 0 || n <= 0) return 0;
+// fill_cap: capacity (in fill queries = uncovered entries) of the partial-result arrays of the in-view fill, 1 .. total; 0 = total
+// (every entry could be a query).  Queries beyond the capacity are still answered (one block per 256 of them sweeps the whole
+// reference range), so any value is CORRECT; a capacity of the expected query count keeps the fill fully parallel.
+extern "C" size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n,
+                                                      int64_t fill_cap) {
+    if (nsrc <= 0 || q <= 0 || h <= 0 || w <= 0 || total <= 0 || n <= 0 || fill_cap < 0 || fill_cap > total) return 0;
     LvWork k;
-    return lv_carve(nullptr, 0, nsrc, q, h, w, total, n, k);
+    return lv_carve(nullptr, 0, nsrc, q, h, w, total, n, fill_cap ? fill_cap : total, k);
 }
 // seg i32 [total] (out: segment of every entry after the in-view fill, -1 = none); pv_start i64 [n+1], pv_view / pv_seg i32 [total]
 // (out: the point -> (view, segment) CSR that gp_fuse_views_top3 reads).  Replaces, for all views together, the per-view
@@ -580,16 +600,19 @@ extern "C" int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_
                                    const int32_t *tap_x0, const float *tap_wx, const int32_t *tap_y0, const float *tap_wy,
                                    int32_t out_h, int32_t out_w, const float *xyz, int64_t n, const int64_t *ent_pt,
                                    const int64_t *ent_x, const int64_t *ent_y, const int32_t *ent_view, const int64_t *view_off,
-                                   const uint8_t *keep, int32_t nviews, int64_t total, int32_t *seg, int64_t *pv_start,
-                                   int32_t *pv_view, int32_t *pv_seg, void *workspace, size_t workspace_bytes, void *stream_) {
+                                   const uint8_t *keep, int32_t nviews, int64_t total, int64_t fill_cap, int32_t *seg,
+                                   int64_t *pv_start, int32_t *pv_view, int32_t *pv_seg, void *workspace, size_t workspace_bytes,
+                                   void *stream_) {
     GP_CHECK_ARG(pred_masks && scores && tap_x0 && tap_wx && tap_y0 && tap_wy && xyz && ent_pt && ent_x && ent_y && ent_view && view_off &&
                      keep && seg && pv_start && pv_view && pv_seg && workspace,
                  "gp_lift_masks_views: null argument");
     GP_CHECK_ARG(q > 0 && h > 0 && w > 0 && n > 0 && total > 0, "gp_lift_masks_views: empty shape");
     GP_CHECK_ARG(nviews > 0 && nviews <= 128 && nviews <= nsrc, "gp_lift_masks_views: %d views (1..128, <= %d mask sets)", nviews, nsrc);
     GP_CHECK_ARG(total < (int64_t)INT32_MAX, "gp_lift_masks_views: too many entries");
+    GP_CHECK_ARG(fill_cap >= 0 && fill_cap <= total, "gp_lift_masks_views: fill_cap=%lld outside 0..total", (long long)fill_cap);
+    if (fill_cap == 0) fill_cap = total;
     LvWork k;
-    if (lv_carve(workspace, workspace_bytes, nsrc, q, h, w, total, n, k) > workspace_bytes) {
+    if (lv_carve(workspace, workspace_bytes, nsrc, q, h, w, total, n, fill_cap, k) > workspace_bytes) {
         gp_set_error("gp_lift_masks_views: workspace too small");
         return GP_ENOMEM;
     }
@@ -606,8 +629,9 @@ extern "C" int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_
     fill_compact_kernel<<<eb, 256, 0, s>>>(xyz, ent_pt, seg, k.rs, total, k.rxyz, k.rent, k.qent);
     const unsigned qb = (unsigned)(total / 256 + nviews + 1);                           // >= sum over views of ceil(queries / 256)
     fill_table_kernel<<<1, 64, 0, s>>>(view_off, k.rs, nviews, k.tab);
-    fill_part_kernel<<<dim3(qb, FV_CHUNKS), 256, 0, s>>>(xyz, ent_pt, k.tab, nviews, k.rxyz, k.qent, k.part_d, k.part_i, total);
-    fill_reduce_kernel<<<qb, 256, 0, s>>>(k.tab, nviews, k.part_d, k.part_i, total, k.rent, k.qent, seg);
+    fill_part_kernel<<<dim3(qb, FV_CHUNKS), 256, 0, s>>>(xyz, ent_pt, k.tab, nviews, k.rxyz, k.qent, k.part_d, k.part_i, fill_cap,
+                                                         k.rent, seg);
+    fill_reduce_kernel<<<qb, 256, 0, s>>>(k.tab, nviews, k.part_d, k.part_i, fill_cap, k.rent, k.qent, seg);
     // point -> (view, segment) lists
     GP_CHECK_HIP(hipMemsetAsync(k.vmask, 0, (size_t)n * 2 * sizeof(unsigned long long), s));
     pv_mask_kernel<<<eb, 256, 0, s>>>(ent_pt, ent_view, keep, total, k.vmask);

@@ -131,24 +131,24 @@ def _item(self, locs_in, feats_in, labels_in, processed):
     else:
         feat, mask_chunk = feat.to(dev), mask_chunk.to(dev)
         row_keep = row_keep.to(dev) if row_keep is not None else None
-        M_v, M_r = self.voxelizer.get_transformation_matrix()
         pts = torch.as_tensor(np.ascontiguousarray(locs_in, dtype=np.float64)).to(dev)
         cols = torch.as_tensor(np.ascontiguousarray(feats_in)).to(dev)
         labs = torch.as_tensor(np.ascontiguousarray(labels_in)).to(dev)
         labs_v = labs
         if chunk_only:
             pts, cols, labs_v = pts[mask_chunk], cols[mask_chunk], labs[mask_chunk]
-        r = ops.voxelize(pts.contiguous(), M_r @ M_v)
+        # the voxelizer's own device form: clip box, augmentation switch and normal rotation are those of the host call
+        r = self.voxelizer.voxelize_device(pts.contiguous(), cols, labs_v)
         vox_ind = r["inds"]
         decode = ops.fused_decode
         coords = r["coords_aug"].to(torch.int32)
         if self.input_color:
             # tensor / tensor: an IEEE division, as on the host (torch's tensor / Python-scalar on the GPU multiplies by the reciprocal)
-            c = cols[vox_ind].float()
+            c = r["feats"].float()
             feats = c / torch.full_like(c, 127.5) - 1.0
         else:
             feats = torch.ones((coords.shape[0], 3), device=dev)
-        labels = (labs if self.eval_all else labs_v[vox_ind]).long()
+        labels = (labs if self.eval_all else r["labels"]).long()
         inds_reconstruct = r["inds_reconstruct"].long()
         ones = torch.ones((coords.shape[0], 1), dtype=torch.int32, device=dev)
     if train:

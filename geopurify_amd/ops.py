@@ -629,9 +629,12 @@ def views_visible_lists(coords, params, depth_all, width, height, cut_bound, vis
     return ent
 
 
-def lift_masks_views(pred_masks, scores, taps, out_hw, xyz, ent, total, nviews):
+def lift_masks_views(pred_masks, scores, taps, out_hw, xyz, ent, total, nviews, fill_cap=None):
     """Rows 6-7 up to the point -> (view, segment) lists for all views at once.  pred_masks f32 [Vsrc,Q,h,w], scores f32
-    [Vsrc,Q], xyz f32 [N,3], ent = views_visible_lists(...), total = entries used.  Returns (seg, pv_start, pv_view, pv_seg)."""
+    [Vsrc,Q], xyz f32 [N,3], ent = views_visible_lists(...), total = entries used.  Returns (seg, pv_start, pv_view, pv_seg).
+    fill_cap: capacity of the in-view fill's partial arrays in fill queries (None: a quarter of the entries, at least 65 536 --
+    the uncovered share of the visible pixels is a few per cent on every scene measured; more queries than that are still
+    answered, by the kernel's overflow path)."""
     lib = _lib.load()
     _chk(pred_masks, torch.float32, "pred_masks")
     _chk(scores, torch.float32, "scores")
@@ -643,11 +646,13 @@ def lift_masks_views(pred_masks, scores, taps, out_hw, xyz, ent, total, nviews):
     start = torch.empty(n + 1, dtype=torch.int64, device=dev)
     pvv = torch.empty(total, dtype=torch.int32, device=dev)
     pvs = torch.empty(total, dtype=torch.int32, device=dev)
-    ws = _ws(lib.gp_lift_masks_views_workspace_bytes(nsrc, Q, h, w, total, n), dev)
+    if fill_cap is None:
+        fill_cap = min(int(total), max(int(total) // 4, 65536))
+    ws = _ws(lib.gp_lift_masks_views_workspace_bytes(nsrc, Q, h, w, total, n, int(fill_cap)), dev)
     tx0, twx, ty0, twy = taps
     check(lib.gp_lift_masks_views(_ptr(pred_masks), nsrc, Q, h, w, _ptr(scores), _ptr(tx0), _ptr(twx), _ptr(ty0), _ptr(twy),
                                   int(out_hw[0]), int(out_hw[1]), _ptr(xyz), n, _ptr(ent["pt"]), _ptr(ent["x"]), _ptr(ent["y"]),
-                                  _ptr(ent["view"]), _ptr(ent["view_off"]), _ptr(ent["keep"]), int(nviews), int(total), _ptr(seg),
+                                  _ptr(ent["view"]), _ptr(ent["view_off"]), _ptr(ent["keep"]), int(nviews), int(total), int(fill_cap), _ptr(seg),
                                   _ptr(start), _ptr(pvv), _ptr(pvs), _ptr(ws), ws.numel(), _stream()), "gp_lift_masks_views")
     return seg, start, pvv, pvs
 
@@ -875,11 +880,15 @@ def fused_decode(mask_chunk, feat, vox_ind, mode, row_keep=None):
     n, nv = mc.shape[0], vox_ind.shape[0]
     out = torch.empty((nv,) + tuple(feat.shape[1:]), dtype=feat.dtype, device=dev)
     mask_out = torch.empty(nv, dtype=torch.uint8, device=dev)
-    n_sel = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_sel = torch.zeros(2, dtype=torch.int64, device=dev)
     ws = _ws(lib.gp_fused_decode_workspace_bytes(n, nv), dev)
     row_bytes = feat[0].numel() * feat.element_size()
     check(lib.gp_fused_decode(_ptr(mc), n, _ptr(rk), _ptr(feat), feat.shape[0], row_bytes, _ptr(vox_ind), nv, int(mode), _ptr(out),
                               _ptr(mask_out), _ptr(n_sel), _ptr(ws), ws.numel(), _stream()), "gp_fused_decode")
+    kept, in_chunk = (int(v) for v in n_sel.tolist())                # the one host sync (a loader item, off the scene's hot path)
+    if in_chunk != feat.shape[0]:
+        # the host formulation (reference: dataset/feature_loader.py:141-190) fails on such a file; so does the device path
+        raise ValueError(f"fused-feature file: mask_full selects {in_chunk} points but feat holds {feat.shape[0]} rows")
     if mode == 0:
-        out = out[: int(n_sel.item())]
+        out = out[:kept]
     return out, mask_out.bool()

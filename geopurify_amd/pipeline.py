@@ -216,6 +216,7 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_vi
             views.append(ViewLists(ent["pt"][o:o + n_v], ent["x"][o:o + n_v], ent["y"][o:o + n_v], i))
         ent["total"] = host[V]
         ent["max_nv"] = max([host[i + 1] - host[i] for i in range(V)] + [0])
+        ent["sum_nv2"] = float(sum((host[i + 1] - host[i]) ** 2 for i in range(V)))
         ent["num_views"] = V
         return SceneBatch(coords64.float(), vox["coords_aug"].float(), vox["inds_reconstruct"], labels, gauss, views,
                           vox["order"], vox["seg_start"], host[V + 1:V + 4], ent=ent)
@@ -313,9 +314,11 @@ class HotPath:
                  pool_mode="auto", pool_tile_rows=8, pool_block_rows=64, batch_views=True):
         self.student = student
         self.batch_views = batch_views                 # lift all views of a scene in one set of launches when the inputs allow it
-        # the all-views in-view fill is a brute-force search per view (queries x references of that view); views with more
-        # visible points than this go through the view-by-view path, whose fill uses the grid search
-        self.all_views_max_nv = int(os.environ.get("GP_ALL_VIEWS_MAX_NV", "131072"))
+        # the all-views in-view fill is a brute-force search per view: sum over views of (queries x references) <= sum n_v^2 / 4
+        # pair tests in fp64.  The limit is that COST (round 3 had a fixed 131 072 visible points per view): config M
+        # (80 views of 30-60k visible points) is 4e10 pair tests and takes the lift from 23.6 to 14.4 ms against the view-by-view
+        # grid search; beyond 2e11 (a scene with views of several hundred thousand visible points) the view-by-view path is taken.
+        self.all_views_max_pairs = float(os.environ.get("GP_ALL_VIEWS_MAX_PAIRS", "2e11"))
         self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
@@ -374,7 +377,7 @@ class HotPath:
         ent = batch.ent
         pm_all = getattr(vlm, "pred_masks", None)
         all_views = (self.batch_views and batched and scores_all is not None and ent is not None and ent["total"] > 0
-                     and ent["num_views"] <= 128 and ent["max_nv"] < self.all_views_max_nv
+                     and ent["num_views"] <= 128 and ent.get("sum_nv2", float(ent["max_nv"]) ** 2 * ent["num_views"]) / 4 <= self.all_views_max_pairs
                      and torch.is_tensor(pm_all) and pm_all.dim() == 4 and pm_all.is_contiguous()
                      and pm_all.shape[0] >= ent["num_views"])
         if all_views:

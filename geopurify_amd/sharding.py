@@ -77,22 +77,41 @@ def _world(group=None):
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def sync_batch_stats(col_sums_fn, n_local, channels, device, group=None):
+def sync_row_count(n_local, device, group=None):
+    """Rows of all ranks, once per training step: submanifold convolutions keep the row set, so every BatchNorm layer of a step
+    normalises over the same count (it used to ride in every layer's first all-reduce and cost a host sync each)."""
+    import torch.distributed as dist
+    if _world(group) == 1:
+        return int(n_local)
+    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(round(float(t.item())))
+
+
+def sync_batch_stats(col_sums_fn, n_local, channels, device, group=None, n_total=None):
     """SyncBatchNorm statistics (run/train.py:212-213: the reference converts the student to MinkowskiSyncBatchNorm, so a
     BatchNorm layer normalises with the mean / biased variance of the rows of ALL ranks).  Two passes like the single-process
     kernel (gp_col_stats), each followed by ONE small all-reduce of fp64 [C (+1)]:
         col_sums_fn(None)  -> fp64 [C] sum of this rank's rows;   all-reduce with the row count  -> global mean
         col_sums_fn(mean)  -> fp64 [C] sum of squared deviations from the GLOBAL mean; all-reduce -> global biased variance
-    Returns (mean fp32 [C], var fp32 [C], n_total).  Without a process group (or world size 1) the all-reduces are skipped."""
+    Returns (mean fp32 [C], var fp32 [C], n_total).  Without a process group (or world size 1) the all-reduces are skipped.
+    n_total: the all-rank row count when the caller already has it (sync_row_count, once per step): the count then neither rides
+    in the first all-reduce nor costs a host synchronisation here."""
     import torch.distributed as dist
     multi = _world(group) > 1
-    t = torch.empty(channels + 1, dtype=torch.float64, device=device)
-    t[:channels] = col_sums_fn(None)
-    t[channels] = float(n_local)
-    if multi:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    n_total = int(round(float(t[channels].item())))
-    mean = (t[:channels] / n_total).float()
+    if n_total is not None:
+        s = col_sums_fn(None).clone()
+        if multi:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        mean = (s / n_total).float()
+    else:
+        t = torch.empty(channels + 1, dtype=torch.float64, device=device)
+        t[:channels] = col_sums_fn(None)
+        t[channels] = float(n_local)
+        if multi:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        n_total = int(round(float(t[channels].item())))
+        mean = (t[:channels] / n_total).float()
     sq = col_sums_fn(mean).clone()
     if multi:
         dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)

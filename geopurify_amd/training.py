@@ -117,6 +117,7 @@ class StudentTrainer:
         # SyncBatchNorm (run/train.py:212-213): statistics and backward reductions over the rows of ALL ranks -- four small
         # all-reduces per BatchNorm layer and step (sharding.sync_*); without a process group identical to the local path
         self.sync_bn, self.group = sync_bn, group
+        self._ident_plans = {}
 
     # ---- state_dict in the reference layout (input kernel un-padded) -----------------------------------
     def state_dict(self):
@@ -185,12 +186,14 @@ class StudentTrainer:
             ctx["offset_pairs"].append((out_rows, m[out_rows].long()))
         ctx["wgrad_plan"] = ops.wgrad_plan_build(ctx["offset_pairs"], Nv) if self.fast else None
         mom = self.bn_momentum
+        n_all = sharding.sync_row_count(Nv, dev, self.group) if self.sync_bn else Nv       # one count per step, not one per layer
 
         def bn_fwd(y, prefix, residual=None, want_split=True):
             rm, rv = (B[prefix + ".bn.running_mean"], B[prefix + ".bn.running_var"]) if update_running else (None, None)
             if self.sync_bn:
                 c = y.shape[1]
-                mean, var, n_tot = sharding.sync_batch_stats(lambda m: ops.col_sums_f64(y, c, m), y.shape[0], c, dev, self.group)
+                mean, var, n_tot = sharding.sync_batch_stats(lambda m: ops.col_sums_f64(y, c, m), y.shape[0], c, dev, self.group,
+                                                             n_total=n_all)
                 out, sp = ops.bn_train_apply(y, mean, var, P[prefix + ".bn.weight"], P[prefix + ".bn.bias"], self.bn_eps, residual=residual,
                                              relu=True, want_split=want_split and self.fast, momentum=mom)
                 if rm is not None:
@@ -234,8 +237,12 @@ class StudentTrainer:
         if dense_hip:
             # dW = h^T dE on the weight-gradient kernel: one "offset" whose pairs are the identity; the gradient rides in a
             # 256-column operand (columns >= embed are zero) because the kernel's tiles are 256 x 256
-            ident = torch.arange(Nv, device=dev)
-            plan = ops.wgrad_plan_build([(ident, ident)], Nv)
+            plan = self._ident_plans.get((Nv, str(dev)))              # the identity plan depends on the row count only
+            if plan is None:
+                ident = torch.arange(Nv, device=dev)
+                plan = self._ident_plans[(Nv, str(dev))] = ops.wgrad_plan_build([(ident, ident)], Nv)
+                if len(self._ident_plans) > 8:
+                    self._ident_plans.pop(next(iter(self._ident_plans)))
             dEp = torch.zeros((Nv, 256), dtype=torch.float32, device=dev)
             dEp[:, :Wo.shape[1]] = dE
             _, ysplit, inv_s = self._grad_split(dEp)

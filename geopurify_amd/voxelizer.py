@@ -64,21 +64,65 @@ class Voxelizer:
         lim = np.asarray(self.clip_bound, dtype=float)
         return np.all((coords >= lim[:, 0] + c) & (coords < lim[:, 1] + c), axis=1)
 
+    # -- np.random draws of one call, in the reference's order (voxelizer.py:86-104) -------------
+    def _clip_box_and_matrices(self, lo, hi, center):
+        """(clip box [2,3] or None, rigid 4x4, M_r): the translation ratios of the clip are drawn BEFORE the matrices, as in the
+        reference; `rigid` is M_r @ M_v with augmentation and M_v alone without.  The host and the device form of voxelize share
+        this, so a loader whose voxelizer is configured differently (no augmentation, a clip box) stays one code path."""
+        box = None
+        if self.clip_bound is not None:
+            ratio = np.zeros(3)
+            if self.use_augmentation and self.translation_augmentation_ratio_bound is not None:
+                ratio = np.array([np.random.uniform(*b) for b in self.translation_augmentation_ratio_bound])
+            size = hi - lo
+            c = lo + 0.5 * size if center is None else center
+            c = c + np.multiply(ratio, size)
+            lim = np.asarray(self.clip_bound, dtype=float)
+            box = np.stack([lim[:, 0] + c, lim[:, 1] + c])
+        M_v, M_r = self.get_transformation_matrix()
+        return box, (M_r @ M_v if self.use_augmentation else M_v), M_r
+
+    def voxelize_device(self, coords, feats=None, labels=None, center=None):
+        """The same call with device tensors in and out (coords f64 [N,3] on the GPU): dict(coords_aug f64 [Nv,3], inds i64 [Nv]
+        -- indices into the CLIPPED cloud, as in the reference --, inds_reconstruct i64, feats[inds] with the normals of
+        columns 3:6 rotated when there are more than six, labels[inds], M_r)."""
+        if not (coords.dim() == 2 and coords.shape[1] == 3 and coords.shape[0]):
+            raise AssertionError("voxelize: need N>0 points with 3 coordinates and one feature row each")
+        lo, hi = (coords.amin(0).cpu().numpy().astype(float), coords.amax(0).cpu().numpy().astype(float)) \
+            if self.clip_bound is not None else (None, None)
+        box, rigid, M_r = self._clip_box_and_matrices(lo, hi, center)
+        if box is not None:
+            b = torch.from_numpy(box).to(coords.device)
+            keep = ((coords >= b[0]) & (coords < b[1])).all(1)
+            if bool(keep.any()):
+                coords = coords[keep]
+                feats = feats[keep] if feats is not None else None
+                labels = labels[keep] if labels is not None else None
+        r = ops.voxelize(coords.contiguous(), rigid)
+        out = {"coords_aug": r["coords_aug"], "inds": r["inds"], "inds_reconstruct": r["inds_reconstruct"], "M_r": M_r,
+               "feats": None, "labels": None}
+        if feats is not None:
+            f = feats[r["inds"]]
+            if f.shape[1] > 6:                           # normals ride in columns 3:6 and rotate with the cloud
+                rot = torch.from_numpy(M_r[:3, :3].T.copy()).to(f.device)
+                f[:, 3:6] = (f[:, 3:6].double() @ rot).to(f.dtype)
+            out["feats"] = f
+        if labels is not None:
+            out["labels"] = labels[r["inds"]]
+        return out
+
     # -- the hot call ----------------------------------------------------------------------------
     def voxelize(self, coords, feats, labels, center=None, link=None, return_ind=False):
         """(coords_aug f64 [Nv,3], feats[inds], labels[inds], inds_reconstruct[, inds | link[inds]])."""
         if not (coords.shape[1] == 3 and coords.shape[0] == feats.shape[0] and coords.shape[0]):
             raise AssertionError("voxelize: need N>0 points with 3 coordinates and one feature row each")
-        if self.clip_bound is not None:
-            ratio = np.zeros(3)
-            if self.use_augmentation and self.translation_augmentation_ratio_bound is not None:
-                ratio = np.array([np.random.uniform(*b) for b in self.translation_augmentation_ratio_bound])
-            keep = self.clip(coords, center, ratio)
+        lo, hi = (coords.min(0).astype(float), coords.max(0).astype(float)) if self.clip_bound is not None else (None, None)
+        box, rigid, M_r = self._clip_box_and_matrices(lo, hi, center)
+        if box is not None:
+            keep = np.all((coords >= box[0]) & (coords < box[1]), axis=1)
             if keep.sum():
                 coords, feats = coords[keep], feats[keep]
                 labels = labels[keep] if labels is not None else None
-        M_v, M_r = self.get_transformation_matrix()
-        rigid = M_r @ M_v if self.use_augmentation else M_v
         dev_coords = torch.as_tensor(np.ascontiguousarray(coords, dtype=np.float64)).cuda()
         r = ops.voxelize(dev_coords, rigid)
         inds = r["inds"].cpu().numpy()

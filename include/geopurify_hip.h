@@ -288,13 +288,17 @@ int gp_lift_masks_view(const float *pred_masks, int32_t q, int32_t h, int32_t w,
 /* same view, (fp64 squared distance of the fp32 xyz [n,3], entry order) minimum = gp_nn1_masked_f64's rule); then the     */
 /* CSR pv_start i64 [n+1], pv_view / pv_seg i32 [total] that gp_fuse_views_top3 reads, a point's entries in ascending      */
 /* view order (= gp_pv_count + scan + gp_pv_fill called view by view).  seg i32 [total] out.  Entries of views with       */
-/* keep == 0 take no part.                                                                                              */
-size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n);
+/* keep == 0 take no part.  fill_cap: capacity, in fill queries (entries without a segment), of the in-view fill's       */
+/* partial-result arrays: 1..total, or 0 = total.  ANY value gives the same results -- queries beyond the capacity are     */
+/* answered by one block per 256 of them sweeping the view's whole reference range -- a capacity near the expected query   */
+/* count keeps the fill fully parallel and the workspace small (192 B per unit of capacity).                               */
+size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n,
+                                           int64_t fill_cap);
 int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_t q, int32_t h, int32_t w, const float *scores,
                         const int32_t *tap_x0, const float *tap_wx, const int32_t *tap_y0, const float *tap_wy,
                         int32_t out_h, int32_t out_w, const float *xyz, int64_t n, const int64_t *ent_pt,
                         const int64_t *ent_x, const int64_t *ent_y, const int32_t *ent_view, const int64_t *view_off,
-                        const uint8_t *keep, int32_t nviews, int64_t total, int32_t *seg, int64_t *pv_start,
+                        const uint8_t *keep, int32_t nviews, int64_t total, int64_t fill_cap, int32_t *seg, int64_t *pv_start,
                         int32_t *pv_view, int32_t *pv_seg, void *workspace, size_t workspace_bytes, void *stream);
 /* gp_segment_tables: per view, f_seg[q,:] = normalize(mask_embed[q,:]) and                         */
 /* logit_seg[q,c] = logit_scale * <f_seg[q], normalize(text[c])>  (affinity_module.py:627-630;       */
@@ -431,9 +435,12 @@ int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *queries, int64
 /* "mask"); vox_ind i64 [nv] = representative point of each voxel.  With p = vox_ind[v],             */
 /* in = mask_chunk[p], r = #True in mask_chunk[0..p), keep = in && (row_keep ? row_keep[r] : 1):      */
 /*   mode 0 (training forms):   mask_out[v] = keep; out[j] = feat[r] for the j-th kept voxel (compact, */
-/*                              voxel order); n_sel[0] (device i64) = number of kept voxels.          */
+/*                              voxel order).                                                         */
 /*   mode 1 (evaluation forms): mask_out[v] = keep; out[v] = in ? feat[r] : 0 for every voxel.        */
-/* out holds nv rows in both modes.                                                                  */
+/* out holds nv rows in both modes.  n_sel (device i64 [2]): [0] = number of kept voxels, [1] = number */
+/* of True in mask_chunk = the rows a well-formed file holds: the caller MUST compare it with         */
+/* feat_rows (the reference's host code raises on a file whose mask and row count disagree; the       */
+/* kernel alone would only mask the rows beyond the file's end).                                      */
 size_t gp_fused_decode_workspace_bytes(int64_t n, int64_t nv);
 int gp_fused_decode(const uint8_t *mask_chunk, int64_t n, const uint8_t *row_keep, const void *feat,
                     int64_t feat_rows, int64_t row_bytes, const int64_t *vox_ind, int64_t nv, int32_t mode,

@@ -54,3 +54,18 @@ def test_debug_knobs_reject_what_is_not_in_the_table():
     # a stamp buffer comes with its size
     assert lib.gp_debug_ptr(0, None, 64) == EINVAL and lib.gp_debug_ptr(4, None, 0) == EINVAL
     assert lib.gp_debug_ptr(0, None, 0) == 0
+
+
+def test_lift_views_workspace_is_sized_by_fill_capacity():
+    """ADVICE r2 / VERDICT r3 next 8: the in-view fill's partial arrays (192 B per unit) are sized by a capacity in fill queries,
+    not by the entry count.  At config-M entry counts (80 views x 45k visible points) the default capacity of ops.lift_masks_views
+    (a quarter of the entries) takes 0.5 GB off the query; capacity 0 means `total` (the round-3 size)."""
+    lib = _lib.load()
+    total, n = 80 * 45_000, 500_000
+    args = (80, 200, 128, 160)
+    full = lib.gp_lift_masks_views_workspace_bytes(*args, total, n, 0)
+    assert full == lib.gp_lift_masks_views_workspace_bytes(*args, total, n, total)
+    quarter = lib.gp_lift_masks_views_workspace_bytes(*args, total, n, total // 4)
+    assert full - quarter == 16 * (8 + 4) * (total - total // 4)
+    assert full - quarter > 500e6
+    assert lib.gp_lift_masks_views_workspace_bytes(*args, total, n, total + 1) == 0       # a capacity beyond the entries is an error

@@ -982,3 +982,32 @@ def test_fused_decode_vs_index_arithmetic(ops, dtype, d):
     from geopurify_amd._lib import GeoPurifyHipError
     with pytest.raises(GeoPurifyHipError, match="mode"):
         ops.fused_decode(mask_chunk.cuda(), feat.cuda(), vox_ind.cuda(), 2)
+
+
+def test_voxelizer_device_form_equals_host_form(ops):
+    """FusedFeatureLoader(device=) used to re-implement the voxelizer call inline (always M_r @ M_v, no clip box, no
+    normal rotation).  Voxelizer.voxelize_device shares the clip / matrix logic with the host call: the same np.random stream
+    gives the same voxels, representatives, features (normals rotated) and labels -- without augmentation, with a clip box and
+    with nine feature columns."""
+    from geopurify_amd.voxelizer import Voxelizer
+    rng = np.random.default_rng(5)
+    N = 6000
+    pts = rng.uniform(-2.0, 2.0, size=(N, 3))
+    feats = rng.normal(size=(N, 9))
+    labels = rng.integers(0, 20, size=N)
+    for kw in (dict(use_augmentation=False),
+               dict(use_augmentation=True, scale_augmentation_bound=(0.9, 1.1),
+                    rotation_augmentation_bound=((-0.05, 0.05), (-0.05, 0.05), (-3.14, 3.14))),
+               dict(use_augmentation=True, clip_bound=((-1.0, 1.0), (-1.5, 1.5), (-0.5, 2.5)),
+                    scale_augmentation_bound=(0.9, 1.1), rotation_augmentation_bound=((-0.05, 0.05), (-0.05, 0.05), (-3.14, 3.14)),
+                    translation_augmentation_ratio_bound=((-0.2, 0.2), (-0.2, 0.2), (0, 0)))):
+        vz = Voxelizer(voxel_size=0.05, **kw)
+        np.random.seed(11)
+        c_h, f_h, l_h, inv_h, ind_h = vz.voxelize(pts, feats.copy(), labels, return_ind=True)
+        np.random.seed(11)
+        r = vz.voxelize_device(torch.from_numpy(pts).cuda(), torch.from_numpy(feats).cuda(), torch.from_numpy(labels).cuda())
+        assert np.array_equal(r["coords_aug"].cpu().numpy(), c_h) and np.array_equal(r["inds"].cpu().numpy(), ind_h)
+        assert np.array_equal(r["inds_reconstruct"].cpu().numpy(), inv_h) and np.array_equal(r["labels"].cpu().numpy(), l_h)
+        assert np.abs(r["feats"].cpu().numpy() - f_h).max() < 1e-12
+        if "clip_bound" in kw:
+            assert len(inv_h) < N                                       # the clip box removed points on both paths

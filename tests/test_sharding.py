@@ -125,6 +125,10 @@ def _syncbn_worker(rank, world, port, q):
     def col_sums(mean):
         return y.double().sum(0) if mean is None else ((y - mean).double() ** 2).sum(0)
     mean, var, n_tot = sharding.sync_batch_stats(col_sums, n, C, "cpu")
+    # the per-step form: the row count is all-reduced ONCE and handed to every layer -- same statistics
+    n_all = sharding.sync_row_count(n, "cpu")
+    mean2, var2, n_tot2 = sharding.sync_batch_stats(col_sums, n, C, "cpu", n_total=n_all)
+    assert n_all == n_tot == n_tot2 and torch.equal(mean, mean2) and torch.equal(var, var2)
     rm, rv = torch.zeros(C), torch.ones(C)
     sharding.sync_running_stats(rm, rv, mean, var, n_tot, 0.1)
     xhat = (y - mean) / torch.sqrt(var + eps)
