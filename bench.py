@@ -97,6 +97,43 @@ def conv_roofline(timer):
             "avg_layer_ms": round(ms, 4)}
 
 
+def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
+    """north_star: "scenes/sec ... as fraction of the HBM roofline".  One line per stage of the scene: the ALGORITHMIC bytes of
+    SURVEY.md section 8(d) (what the stage has to move at least, N points, Nv voxels, V views, n_v visible points per view,
+    K = 96) over the HIP-event time of the stage in the one-stream side pass, against 8 TB/s.  The student's stage is priced in
+    issued f16 flops by `roofline_conv`; the pooling stage is `roofline`'s kernel x T plus its operator build."""
+    H, W = cfg.mask_shape
+    K = 96
+    alg = {
+        "voxelize": ("rows 1-2: N x 48 B (24 in, 8 key, 8 + 8 index out)", n * 48.0),
+        "project+lists": ("row 3 + loader glue: V x N x (24 in + 24 out) + V x H x W x 8 (depth maps)", views * n * 48.0 + views * H * W * 8.0),
+        "lift+fuse+fill": ("rows 5-7: N x D x 4 written + sum n_v x 8 (entry ids)", n * d * 4.0 + n_vis * 8.0),
+        "scatter_mean": ("row 8: N x (D+6) x 4 read + Nv x (D+6) x 4 written + N x 8", n * (d + 6) * 4.0 + nv * (d + 6) * 4.0 + n * 8.0),
+        "kNN": ("row 10: Nv x (12 + K x 4)", nv * (12.0 + K * 4)),
+        "affinity": ("row 11: Nv x (128 x 4 + K x 4 + K x 4)", nv * (128 * 4.0 + K * 8)),
+        "pooling": (f"row 12: {pool_iters} x Nv x (2 x D x 4 + K x 8)", pool_iters * nv * (2.0 * d * 4 + K * 8)),
+        "gather": ("row 12 tail: Nv x D x 4 read + N x D x 4 written", (nv + n) * d * 4.0),
+        "classify+iou": ("row 13: N x D x 4 read + N x 16 (prediction, label)", n * d * 4.0 + n * 16.0),
+    }
+    out = {}
+    for name, (what, b) in alg.items():
+        t = ms.get(name)
+        if t is None or t <= 0:
+            continue
+        gbs = b / (t * 1e-3) / 1e9
+        out[name] = {"ms": round(t, 4), "algorithmic_bytes": int(b), "achieved": round(gbs, 1), "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": what}
+    for name in ("morton order", "grid+kernel_map", "student", "pool operator+split"):
+        if name in ms:
+            out[name] = {"ms": round(ms[name], 4), "note": {"morton order": "internal row order of the voxels (sort of Nv keys): index work, no SURVEY 8(d) figure",
+                                                           "grid+kernel_map": "lattice grid + 27-offset kernel map: index work, no SURVEY 8(d) figure",
+                                                           "student": "matrix-core bound: see roofline_conv",
+                                                           "pool operator+split": "built once per scene: the pooling operator in fragment order + the f16 hi/lo split of X"}[name]}
+    out["note"] = ("one-stream side pass after the timed region, HIP events at stage boundaries, mean over the side scenes; "
+                   "achieved = SURVEY 8(d) algorithmic bytes / stage time; peak 8000 GB/s")
+    return out
+
+
 def training_step_rate(batch, dev, sd, steps=6):
     """SURVEY 8f-1 (BASELINE config 5 shape): optimisation steps per second of the student on the bench scene --
     4096 anchors x (1 + 63) samples, teacher features [N, 1088] synthetic, lifted features random unit rows
@@ -294,10 +331,12 @@ class ConvTimer:
 
 
 class StageTimer:
-    """Coarse per-stage HIP-event timing (reported in `stages_ms`, not part of the contract)."""
+    """Per-stage HIP-event timing of the one-stream side pass (`stages_ms_per_scene`, `roofline_stages`).  `fine` is handed to
+    build_scene_batch / HotPath.refine, which call it after each sub-stage's kernels are enqueued."""
 
-    def __init__(self):
+    def __init__(self, fine=False):
         self.marks = []
+        self.fine = self.mark if fine else None
 
     def mark(self, name):
         e = torch.cuda.Event(enable_timing=True)
@@ -547,7 +586,9 @@ def main():
         j = i % max(args.scenes, 1)
         if stage:
             stage.mark("start")
-        batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
+        fine = getattr(stage, "fine", None) if stage else None         # the per-stage roofline pass: marks inside loader and refine
+        hp.stage_mark = fine
+        batch = pl.build_scene_batch(scenes[j], rigids[j], dev, mark=fine)
         if stage:
             stage.mark("loader: voxelize+project+lists")
         if cfg.dense_features:
@@ -563,6 +604,7 @@ def main():
                               batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
         if stage:
             stage.mark("classify+iou")
+        hp.stage_mark = None
         return batch
 
     def join_streams():
@@ -685,6 +727,15 @@ def main():
             step(i, stage, stream=streams[0])
         torch.cuda.synchronize()
         stages = stage.table()
+        # per-stage roofline: the same pass once more with marks inside the loader and refine
+        fine = StageTimer(fine=True)
+        fb = [step(i, fine, stream=streams[0]) for i in range(side)]
+        torch.cuda.synchronize()
+        fine_ms = {k: v / side for k, v in fine.table().items()}
+        n_pts = float(np.mean([int(b.scene_coords.shape[0]) for b in fb]))
+        n_vis = float(np.mean([sum(int(v.pt.shape[0]) for v in b.views) for b in fb]))
+        n_views = float(np.mean([len(b.views) for b in fb]))
+        stage_roof = stage_rooflines(fine_ms, n_pts, hp.stats["Nv"], n_views, n_vis, cfg, args.pool_iters, D)
         pairs = int((hp.stats["nbr_map"] >= 0).sum().item())
         flops = student.flops(pairs, Nv)
         if val_mode:
@@ -719,6 +770,7 @@ def main():
                                  "region (HIP events around every launch); _isolated: the last scene's launches (Nv in config.workload) "
                                  "repeated with nothing else on the GPU (one warm pass, then the median of three passes)"},
             "roofline_conv": conv_roofline(conv_timer),
+            "roofline_stages": stage_roof,
             "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},

@@ -267,9 +267,9 @@ __device__ __forceinline__ uint64_t cv_real() {
     return t;
 }
 
-// STAMP (tuning twin only): wave 0 of every workgroup writes 8 x uint64 into `stamp`: {real-time start, real-time length, prologue
+// STAMP (tuning twin only): wave 0 of every workgroup writes 10 x uint64 into `stamp`: {real-time start, real-time length, prologue
 // (descriptor + row ids + first stage landed), K loop, partial-store ISSUE, store drain (vmcnt(0)), whole tile -- shader cycles --,
-// XCC id | pairs << 8}
+// XCC id | pairs << 8, cycles of the loop spent issuing LDS-DMA, cycles of the loop spent in the end-of-step wait + barrier}
 template <bool TUNE, bool STAMP>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
@@ -280,7 +280,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                      const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
-    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0;
+    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0, st_dma = 0, st_wait = 0;
     if constexpr (STAMP) { st_t0 = cv_now(); st_r0 = cv_real(); }
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -296,19 +296,6 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     const int4 td = tile_desc[mt];
     const int k = td.x, base = td.y, cnt = td.z;
     const int n0 = nt * TN;
-    // per-row power-of-two scales of the pre-split operand (x_hi + x_lo = x * 2^e(row), gp_split_f16_scaled): the partial
-    // row of a pair is multiplied back by 2^-e(input row).  Loaded before the K loop (16 rows per lane), used in the epilogue.
-    float rinv[4][4];
-    {
-        const int wm_ = wv >> 1, fq_ = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = wm_ * 64 + i * 16 + fq_ * 4 + r;
-                rinv[i][r] = x_inv_scale ? x_inv_scale[pair_in[base + (grow < cnt ? grow : cnt - 1)]] : 1.f;
-            }
-    }
     // DMA roles: wave wv stages rows [wv*32, wv*32+32) of each array, two instructions of 16 rows
     const int lrow = lane >> 2, lp = lane & 3;
     const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;         // logical 8-half slot this lane fetches
@@ -348,13 +335,33 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 
     const int steps = cin / TK;
     issue(0, 0);
+    // per-row power-of-two scales of the pre-split operand (x_hi + x_lo = x * 2^e(row), gp_split_f16_scaled): the partial
+    // row of a pair is multiplied back by 2^-e(input row).  Used in the epilogue only: the two dependent gathers (row id, then
+    // its scale; 16 rows per lane) are issued AFTER the first stage's DMA so that they ride behind it instead of holding the
+    // first DMA back (vector memory operations complete in order: round 4 stamps, prologue 12.0k cycles of a 92k-cycle tile).
+    float rinv[4][4];
+    {
+        const int wm_ = wv >> 1, fq_ = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = wm_ * 64 + i * 16 + fq_ * 4 + r;
+                rinv[i][r] = x_inv_scale ? x_inv_scale[pair_in[base + (grow < cnt ? grow : cnt - 1)]] : 1.f;
+            }
+    }
     __syncthreads();
     if constexpr (STAMP) st_pro = cv_now();
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
+        uint64_t st_a = 0;
+        if constexpr (STAMP) st_a = cv_now();
         if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
+        if constexpr (STAMP) st_dma += cv_now() - st_a;
         if (!(ablate & 2)) mma_step_f16x3<4>(sm, buf, wm, wn, fl, fsw, acc);   // padded rows are computed and discarded
+        if constexpr (STAMP) st_a = cv_now();
         __syncthreads();
+        if constexpr (STAMP) st_wait += cv_now() - st_a;
     }
     if constexpr (STAMP) st_loop = cv_now();
     auto stamp_out = [&]() {
@@ -363,11 +370,12 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint64_t t3 = cv_now(), r3 = cv_real();
             if (tid == 0 && stamp) {
-                uint64_t *o = stamp + (int64_t)blockIdx.x * 8;
+                uint64_t *o = stamp + (int64_t)blockIdx.x * 10;
                 unsigned xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_loop - st_pro; o[4] = st_iss - st_loop;
                 o[5] = t3 - st_iss; o[6] = t3 - st_t0; o[7] = (uint64_t)(xcc & 0xff) | ((uint64_t)cnt << 8);
+                o[8] = st_dma; o[9] = st_wait;
             }
         }
     };
@@ -812,9 +820,9 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp
             if (x_hi && !(g_conv_ablate & 16)) {
-                GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 8 * sizeof(uint64_t),
+                GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
-                             g_gp_debug_bytes[1], (size_t)nblocks * 8 * sizeof(uint64_t));
+                             g_gp_debug_bytes[1], (size_t)nblocks * 10 * sizeof(uint64_t));
                 if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);

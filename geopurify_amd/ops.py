@@ -200,6 +200,23 @@ class ConvPairs:
         self.partial = None
         self.chunk_rows, self.num_chunks, self.chunk_tile_off, self.chunk_pair_off = 0, 0, None, None   # 0 = not chunked
 
+    def regroup(self, g):
+        """The same pair ORDER (chunk-major: a chunk's 27 offset segments gather from the same few thousand input rows, which
+        keeps the gathered operand in the XCDs' L2) executed `g` chunks per LAUNCH: phase 1 of g consecutive chunks is one grid
+        (fewer partly filled last rounds and kernel boundaries per layer), phase 2 follows for their rows; the partial buffer
+        then holds g chunks.  Returns a ConvPairs sharing the device arrays."""
+        g = max(1, min(int(g), max(self.num_chunks, 1)))
+        cp = ConvPairs(self.pair_in, self.pair_pos, self.pair_off, self.tile_start, self.nseg, self.num_pairs, self.nv)
+        cp.tile_desc = self.tile_desc
+        n = self.num_chunks
+        idx = list(range(0, n, g)) + [n]
+        po, to = list(self.chunk_pair_off), list(self.chunk_tile_off)
+        cp.chunk_rows, cp.num_chunks = self.chunk_rows * g, len(idx) - 1
+        cp.chunk_pair_off = (ctypes.c_int32 * len(idx))(*[po[i] for i in idx])
+        cp.chunk_tile_off = (ctypes.c_int32 * len(idx))(*[to[i] for i in idx])
+        cp.max_chunk_pairs = max(po[idx[i + 1]] - po[idx[i]] for i in range(len(idx) - 1))
+        return cp
+
 
 def conv_pairs_build(nbr_map, chunk_rows=16384):
     """nbr_map i32 [27,nv] -> ConvPairs.  One host sync (number of pairs, to size the partial buffer).

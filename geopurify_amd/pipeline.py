@@ -185,17 +185,20 @@ def _voxel_extent(vox):
     return ops.minmax_i32(ci.contiguous())[3:6].to(torch.int64) + 1
 
 
-def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_views=True):
+def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_views=True, mark=None):
     """Loader math on the device for one synthetic scene (geopurify_amd.synthetic.Scene):
     scene voxelization (rows 1-2), per-view mapping (row 3), visible lists and the view-drop rule
     (data_loader_ablation.py:254-255,280-288).  batch_views: all views in one set of launches (needs the depth maps
-    stacked on the device, upload_scene) -- the same lists as the view-by-view path, bit for bit."""
+    stacked on the device, upload_scene) -- the same lists as the view-by-view path, bit for bit.
+    mark: optional callable(name) called on the host after each sub-stage's kernels are enqueued (bench.py's per-stage events)."""
     from .synthetic import mapper_intrinsics
     cfg = scene.cfg
     dev = torch.device(device)
     coords64 = scene.coords_dev if hasattr(scene, "coords_dev") else torch.from_numpy(scene.coords).to(dev)
     N = coords64.shape[0]
     vox = ops.voxelize(coords64, rigid)                                   # sync #1 (nv)
+    if mark is not None:
+        mark("voxelize")
     W, H = cfg.image_dim
     V = len(scene.views)
     gauss = scene.gauss_dev if hasattr(scene, "gauss_dev") else torch.from_numpy(
@@ -218,6 +221,8 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_vi
         ent["max_nv"] = max([host[i + 1] - host[i] for i in range(V)] + [0])
         ent["sum_nv2"] = float(sum((host[i + 1] - host[i]) ** 2 for i in range(V)))
         ent["num_views"] = V
+        if mark is not None:
+            mark("project+lists")
         return SceneBatch(coords64.float(), vox["coords_aug"].float(), vox["inds_reconstruct"], labels, gauss, views,
                           vox["order"], vox["seg_start"], host[V + 1:V + 4], ent=ent)
     depth_dev = scene.depth_dev if hasattr(scene, "depth_dev") else [torch.from_numpy(v.depth).to(dev) for v in scene.views]
@@ -325,6 +330,7 @@ class HotPath:
         self.device = torch.device(device)
         self._taps = {}
         self.stats = {}
+        self.stage_mark = None                          # optional callable(name): bench.py's per-stage HIP events (side pass only)
 
     def _tap_tables(self, h, w):
         key = (h, w)
@@ -474,6 +480,8 @@ class HotPath:
         Nv = coords.shape[0]
         perm, rank = ops.morton_order(coords)
         cs = coords[perm.long()].contiguous()
+        mark = self.stage_mark if self.stage_mark is not None else (lambda name: None)
+        mark("morton order")
         if batch.order is None:                                               # generic tuple input: CSR from the index
             order = torch.sort(batch.scene_inds_reconstruct, stable=True).indices
             segc = torch.zeros(Nv + 1, dtype=torch.int64, device=dev)
@@ -483,19 +491,26 @@ class HotPath:
         ops.scatter_mean_csr(F, D, batch.order, batch.seg_start, Nv, X, col0=0, row_map=rank)
         ops.scatter_mean_csr(batch.scene_gauss_features, GEO_DIM, batch.order, batch.seg_start, Nv, X, col0=D,
                              row_map=rank)
+        mark("scatter_mean")
         if batch.extent is not None:
             grid = ops.grid_build(cs, [0, 0, 0], batch.extent)
         else:
             grid = ops.grid_build(cs)
         nbr_map = ops.kernel_map_build(grid, cs)
+        mark("grid+kernel_map")
         E = st.forward(X, nbr_map)
+        mark("student")
         if after_student is not None:
             after_student()
         nbr = ops.knn_lattice(grid, cs, perm, self.K)
+        mark("kNN")
         w = ops.affinity_softmax(E, nbr, self.sharpen)
+        mark("affinity")
         self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12
         out = self._pool(X, nbr, w, Nv, D)
+        mark("pooling")
         out = ops.gather_rows(out, D, batch.scene_inds_reconstruct, row_map=rank)
+        mark("gather")
         self.stats = {"Nv": Nv, "nbr_map": nbr_map, "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8),
                       "pool_kernel": self._pool_kernel}
         return out
@@ -529,6 +544,8 @@ class HotPath:
             out = torch.empty((Nv, D), dtype=torch.float32, device=dev)
             sc = ops.pow2_scale(X, D)
             sp = [ops.split_f16(X, D, scale=sc[0:1]), tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))]
+            if self.stage_mark is not None:
+                self.stage_mark("pool operator+split")
             src = sp[0]
             for t in range(self.num_iters):
                 last = t == self.num_iters - 1
