@@ -270,7 +270,12 @@ __device__ __forceinline__ uint64_t cv_real() {
 // STAMP (tuning twin only): wave 0 of every workgroup writes 10 x uint64 into `stamp`: {real-time start, real-time length, prologue
 // (descriptor + row ids + first stage landed), K loop, partial-store ISSUE, store drain (vmcnt(0)), whole tile -- shader cycles --,
 // XCC id | pairs << 8, cycles of the loop spent issuing LDS-DMA, cycles of the loop spent in the end-of-step wait + barrier}
-template <bool TUNE, bool STAMP>
+// SPLIT: waves 0-3 issue ALL of a stage's LDS-DMA (64 rows of each operand per wave), waves 4-7 none.  Round-4 stamps of the
+// symmetric form (every wave issues 8 instructions at the top of a step, then multiplies): per step 817 cycles of DMA issue during
+// which NEITHER wave of a SIMD feeds the matrix pipe, 2 153 of reads + MFMA, 1 827 waiting at the barrier for the SIMD partner's
+// MFMAs -- 4 797 cycles for 3 072 cycles of matrix work.  With the roles split, the partner (wave 4-7) multiplies while wave 0-3
+// absorbs the memory pipeline's back-pressure, and finishes its own MFMAs behind it.
+template <bool TUNE, bool STAMP, bool SPLIT>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
                      const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
@@ -283,7 +288,8 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0, st_dma = 0, st_wait = 0;
     if constexpr (STAMP) { st_t0 = cv_now(); st_r0 = cv_real(); }
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-contiguous tile order: blocks b, b+8, ... share an XCD; each XCD walks a contiguous range of
     // (m-tile, n-tile) pairs, both channel tiles of an m-tile back to back (shared A rows hit its L2)
     const int64_t nb = gridDim.x, per_xcd = nb >> 3;
@@ -296,28 +302,30 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     const int4 td = tile_desc[mt];
     const int k = td.x, base = td.y, cnt = td.z;
     const int n0 = nt * TN;
-    // DMA roles: wave wv stages rows [wv*32, wv*32+32) of each array, two instructions of 16 rows
+    // DMA roles: an issuing wave stages RPW rows of each array, NI instructions of 16 rows per plane.  Symmetric form: every
+    // wave 32 rows; SPLIT: waves 0-3 64 rows each, waves 4-7 nothing.  The lo planes sit at a uniform distance from the hi planes.
+    constexpr int NI = SPLIT ? 4 : 2, RPW = 16 * NI;
+    const bool issuer = !SPLIT || wv < 4;                                     // wave-uniform
     const int lrow = lane >> 2, lp = lane & 3;
     const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;         // logical 8-half slot this lane fetches
-    const _Float16 *ga_hi[2], *ga_lo[2], *gb_hi[2], *gb_lo[2];
+    const int64_t da = x_lo - x_hi, db = w_lo - w_hi;                         // (in halfs)
+    const _Float16 *ga_hi[NI], *gb_hi[NI];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int row = wv * 32 + t * 16 + lrow;
+    for (int t = 0; t < NI; ++t) {
+        int row = (issuer ? wv : 0) * RPW + t * 16 + lrow;
         int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];              // clamped, unconditional: both loads overlap
         ga_hi[t] = x_hi + (int64_t)in_row * ld_xh + q;
-        ga_lo[t] = x_lo + (int64_t)in_row * ld_xh + q;
-        int64_t wrow = ((int64_t)k * cout + n0 + row) * cin + q;
-        gb_hi[t] = w_hi + wrow;
-        gb_lo[t] = w_lo + wrow;
+        gb_hi[t] = w_hi + ((int64_t)k * cout + n0 + row) * cin + q;
     }
     auto issue = [&](int c0, int buf) {
+        if (!issuer) return;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int r0 = wv * 32 + t * 16;
+        for (int t = 0; t < NI; ++t) {
+            const int r0 = wv * RPW + t * 16;
             glds16(ga_hi[t] + c0, &sm.a_hi[buf][r0][0]);
-            glds16(ga_lo[t] + c0, &sm.a_lo[buf][r0][0]);
+            glds16(ga_hi[t] + da + c0, &sm.a_lo[buf][r0][0]);
             glds16(gb_hi[t] + c0, &sm.b_hi[buf][r0][0]);
-            glds16(gb_lo[t] + c0, &sm.b_lo[buf][r0][0]);
+            glds16(gb_hi[t] + db + c0, &sm.b_lo[buf][r0][0]);
         }
     };
 
@@ -435,9 +443,12 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 #define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp
 // the product kernel (tuning bits compiled out) and its twin with the bits of knob 3 live, under its own name in a trace
 // (bench.py's data-movement ceiling of the convolution and scripts/bench_conv.py's ablations launch the twin)
-__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, false>(P1_FWD); }
+// experiment (knob 3 bit 6): the split-role form, plain and stamped
+__global__ void __launch_bounds__(NT2) conv_phase1_split_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false, true>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_split_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, true>(P1_FWD); }
 #undef P1_PARAMS
 #undef P1_FWD
 
@@ -776,6 +787,8 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_SMEM_ATTR(conv_phase1_dma_kernel, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_tuning_kernel, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_stamp_kernel, sizeof(V2Smem));
+    GP_SMEM_ATTR(conv_phase1_split_kernel, sizeof(V2Smem));
+    GP_SMEM_ATTR(conv_phase1_split_stamp_kernel, sizeof(V2Smem));
     // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
     // blockIdx * 8 (a chunk overwrites the previous one's: the last chunk of the last call stays)
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[1]);
@@ -815,7 +828,8 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         int64_t row_count = chunked ? ((row_begin + chunk_rows < nv) ? chunk_rows : nv - row_begin) : nv;
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            const bool split = (g_conv_ablate & 64) != 0;   // experiment: split DMA / MFMA roles
+            const int tune = g_conv_ablate & ~(16 | 64);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp
@@ -823,7 +837,9 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
                              g_gp_debug_bytes[1], (size_t)nblocks * 10 * sizeof(uint64_t));
-                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                if (stamp && split) conv_phase1_split_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                else if (split) conv_phase1_split_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                else if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
             } else {

@@ -218,11 +218,13 @@ class ConvPairs:
         return cp
 
 
-def conv_pairs_build(nbr_map, chunk_rows=16384):
+def conv_pairs_build(nbr_map, chunk_rows=8192):
     """nbr_map i32 [27,nv] -> ConvPairs.  One host sync (number of pairs, to size the partial buffer).
     chunk_rows: pairs are ordered chunk-major and phase 1 / phase 2 run chunk by chunk, so the partial
-    buffer only holds one chunk (62k..245k pairs instead of ~1M per 134k voxels).  Speed is flat from 8192
-    rows up (2.06 ms per 512->512 layer); 2048-row chunks cost 15 % (more partial tiles).  None = one chunk."""
+    buffer only holds one chunk.  Round 4 on the S scene (profiles/r04_conv_launch_groups.log), per 512->512 layer:
+    8192-row chunks (17 launches, 128 MB of partial rows -- inside the Infinity Cache) 1.87 ms, 16384 rows (the earlier
+    default, 250 MB) 1.96 ms, 4096 rows 2.65 ms (33 launches: too many partly filled last rounds); several chunks per
+    launch (ConvPairs.regroup) never wins.  None = one chunk."""
     lib = _lib.load()
     kv, nv = nbr_map.shape
     dev = nbr_map.device
