@@ -162,11 +162,11 @@ __device__ int cs_union(const int32_t *__restrict__ nbr, int n, int *keys, int *
 
 // pass 1: padded union size of every block (a multiple of 32 union rows, at least one step)
 __global__ void __launch_bounds__(1024)
-cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int64_t *__restrict__ padded_cnt, int32_t *__restrict__ bu_n) {
+cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int rpb, int64_t *__restrict__ padded_cnt, int32_t *__restrict__ bu_n) {
     extern __shared__ int s_mem[];
     int *keys = s_mem, *dense = s_mem + CS_HS;
-    const int64_t b = blockIdx.x, r0 = b * CS_BR;
-    const int rows = (int)((nv - r0) < CS_BR ? (nv - r0) : CS_BR);
+    const int64_t b = blockIdx.x, r0 = b * rpb;
+    const int rows = (int)((nv - r0) < rpb ? (nv - r0) : rpb);
     const int U = cs_union(nbr + r0 * k, rows * k, keys, dense);
     if (threadIdx.x == 0) { padded_cnt[b] = (int64_t)((U + CS_KS - 1) / CS_KS) * CS_KS; bu_n[b] = U; }
 }
@@ -175,14 +175,14 @@ cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int64_t *__r
 // whether the 16 x 32 weight fragment holds a non-zero, and the ELL weights scattered into MFMA fragment order:
 // wa[(step * 8 + group) * 64 + lane][8], lane = (k >> 3) * 16 + m  (k = union row within the step, m = row within the group).
 __global__ void __launch_bounds__(1024)
-cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, const int64_t *__restrict__ bu_off,
+cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int rpb, const int64_t *__restrict__ bu_off,
                int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
     extern __shared__ int s_mem[];                           // A[16384] | B[16384] | npos u16 [br*k]
     int *A = s_mem, *B = s_mem + CS_HS;
     unsigned short *npos = reinterpret_cast<unsigned short *>(s_mem + CS_HS + CS_MAXID);
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x, r0 = b * CS_BR;
-    const int rows = (int)((nv - r0) < CS_BR ? (nv - r0) : CS_BR);
+    const int64_t b = blockIdx.x, r0 = b * rpb;
+    const int rows = (int)((nv - r0) < rpb ? (nv - r0) : rpb);
     const int n = rows * k;
     const int32_t *nb = nbr + r0 * k;
     const int U = cs_union(nb, n, A, B);
@@ -274,17 +274,31 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
                const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
                _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
-               int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
+               int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb,
+               const int32_t *__restrict__ order) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
     if constexpr (STAMP) { st_t0 = cs_now(); st_r0 = cs_real(); }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);    // XCD-contiguous order
-    const int64_t b = lb >> 1;
-    const int col0 = (int)(lb & 1) * CS_NC;
-    if (b >= nblocks) return;
+    int64_t b;
+    int col0;
+    if (order) {
+        // longest-first order (`order` = row blocks by descending step count): the blocks are dealt round-robin over the XCDs
+        // (block index & 7 = XCD under the observed round-robin placement), the two column halves of a row block back to back on
+        // one XCD (they share the weight fragments in its L2).  A launch of equal tiles on one workgroup per CU costs whole
+        // rounds; with the long tiles first the short ones fill the last round.
+        const int64_t j = blockIdx.x >> 3, slot = (j >> 1) * 8 + (blockIdx.x & 7);
+        if (slot >= nblocks) return;
+        b = order[slot];
+        col0 = (int)(j & 1) * CS_NC;
+    } else {
+        const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);    // XCD-contiguous order
+        b = lb >> 1;
+        col0 = (int)(lb & 1) * CS_NC;
+        if (b >= nblocks) return;
+    }
     const int64_t ub0 = bu_off[b];
     const int n = (int)((bu_off[b + 1] - ub0) / CS_KS);                            // steps (>= 1)
     const int64_t ks0 = ub0 / CS_KS;
@@ -468,7 +482,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
 #pragma unroll
             for (int r = 0; r < 4; ++r) stg[(mt * 16 + fq * 4 + r) * CS_EP + cb * 16 + fl] = acc[mt * 2 + cb][r] * inv;
     gp_wave_sync();
-    const int64_t row0 = b * CS_BR;
+    const int64_t row0 = b * rpb;
     const int colw = col0 + wv * CS_WC;
     // lane -> 8 consecutive columns of row it * 16 + (lane >> 2): every store instruction writes 16 rows x 64 bytes
     const int er = lane >> 2, ec = (lane & 3) * 8;
@@ -485,8 +499,9 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int64_t grow = row0 + h8 * 64 + it * 16 + er;
-            if (grow < nv && !(ablate & 16)) {             // tuning aid: bit 4 skips the output stores
+            const int lrow = h8 * 64 + it * 16 + er;       // (rows rpb .. 127 of a block do not exist: their weights are zero)
+            const int64_t grow = row0 + lrow;
+            if (lrow < rpb && grow < nv && !(ablate & 16)) {             // tuning aid: bit 4 skips the output stores
                 const float xv[8] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w, v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
                 if (y_hi) {
                     f16x8 h, l;
@@ -520,8 +535,8 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                        const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask, const _Float16 *__restrict__ wa_hi,                    \
                        const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks, _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo,       \
                        int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale,       \
-                       uint64_t *__restrict__ stamp
-#define CS_POOL_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp
+                       uint64_t *__restrict__ stamp, int rpb, const int32_t *__restrict__ order
+#define CS_POOL_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp, rpb, order
 // the product kernel (STAMP = false: no tuning bits, no stamps) and its stamped instantiation
 template <bool STAMP>
 __global__ void __launch_bounds__(512, 2) cs_pool_kernel(CS_POOL_PARAMS) { cs_pool_body<STAMP, STAMP>(CS_POOL_FWD); }
@@ -580,7 +595,7 @@ cs_engine_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
                const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
                const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
                _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
-               int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp) {
+               int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -761,7 +776,7 @@ cs_engine_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
         // ---- epilogue: 32 rows at a time through the wave's private staging area; every store instruction writes 16 rows x 64 bytes
         uint64_t st_e = 0;
         if constexpr (STAMP) st_e = cs_now();
-        const int64_t row0 = b * CS_BR;
+        const int64_t row0 = b * rpb;
         const int colw = col0 + cw * CS_WC;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
@@ -782,8 +797,9 @@ cs_engine_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
             gp_wave_sync();
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const int64_t grow = row0 + ch * 32 + it * 16 + er;
-                if (grow < nv && !(ablate & 16)) {
+                const int lrow = ch * 32 + it * 16 + er;
+                const int64_t grow = row0 + lrow;
+                if (lrow < rpb && grow < nv && !(ablate & 16)) {
                     const float xv[8] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w, v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
                     if (y_hi) {
                         f16x8 h, lo8;
@@ -814,8 +830,9 @@ cs_engine_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x
 #define EG_PARAMS const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x, const int64_t *__restrict__ bu_off,            \
                   const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask, const _Float16 *__restrict__ wa_hi,                      \
                   const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks, _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo,         \
-                  int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp
-#define EG_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, ablate, out_scale, stamp
+                  int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf, int ablate, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, \
+                  int rpb
+#define EG_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, ablate, out_scale, stamp, rpb
 // the product engine (no tuning bits, no stamps) and the same body with both live, under its own name in a kernel trace
 __global__ void __launch_bounds__(512, 2) cs_engine_kernel(EG_PARAMS) { cs_engine_body<false, false>(EG_FWD); }
 template <bool STAMP>
@@ -832,21 +849,44 @@ int cs_np2(int64_t n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
-extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv) {
-    if (nv <= 0) return 0;
-    int64_t nb = (nv + CS_BR - 1) / CS_BR;
+// rows per block: 64 .. 128 (the kernels' blocks hold eight 16-row groups; a block of fewer rows leaves the last groups empty,
+// their weight fragments are never fetched).  gp_pool_cs_rows_per_block(nv) picks the height that spreads the rows evenly over
+// whole rounds of one workgroup per CU: a launch of near-equal tiles costs ceil(tiles / CUs) rounds, and e.g. 133 933 rows in
+// 128-row blocks are 2 094 tiles = 8.18 rounds = 9 rounds of full-height tiles; 117-row blocks are 2 290 tiles <= 9 x 256 of 9 %
+// less work each.
+static bool cs_rpb_ok(int32_t rpb) { return rpb >= 16 && rpb <= CS_BR; }
+
+extern "C" int32_t gp_pool_cs_rows_per_block(int64_t nv) {
+    if (nv <= 0) return CS_BR;
+    const int n_cu = gp_cu_count();
+    if (n_cu <= 0) return CS_BR;
+    const int64_t half = n_cu;                            // tiles per round = CUs (one workgroup per CU); a row block is 2 tiles
+    const int64_t tiles128 = 2 * ((nv + CS_BR - 1) / CS_BR);
+    const int64_t rounds = (tiles128 + half - 1) / half;
+    const int64_t blocks = rounds * half / 2;             // row blocks that fit the rounds
+    int64_t rpb = (nv + blocks - 1) / blocks;
+    if (rpb < 64) rpb = rpb < 16 ? CS_BR : 64;            // small scenes: a round is not even full, keep the tiles tall
+    if (rpb > CS_BR) rpb = CS_BR;
+    return (int32_t)rpb;
+}
+
+extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block) {
+    if (nv <= 0 || !cs_rpb_ok(rows_per_block)) return 0;
+    int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     GpCarver cv(nullptr, 0);
     cv.take<int64_t>(nb + 1);
     cv.take<char>(cs_scan_tmp(nb + 1));
     return cv.off;
 }
 
-// pass 1: bu_off i64 [nblocks+1] (padded union rows before each 128-row block; multiples of 32), bu_n i32 [nblocks]
-extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int64_t *bu_off, int32_t *bu_n, void *workspace,
-                                size_t workspace_bytes, void *stream_) {
+// pass 1: bu_off i64 [nblocks+1] (padded union rows before each block; multiples of 32), bu_n i32 [nblocks];
+// nblocks = ceil(nv / rows_per_block)
+extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, int64_t *bu_off, int32_t *bu_n,
+                                void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(nbr && bu_off && bu_n && workspace && nv > 0 && k > 0, "gp_pool_cs_count: null/empty argument");
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_count: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
     GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_count: k=%d too large (128*k <= %d)", k, CS_MAXNK);
-    int64_t nb = (nv + CS_BR - 1) / CS_BR;
+    int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     GpCarver cv(workspace, workspace_bytes);
     int64_t *cnt = cv.take<int64_t>(nb + 1);
     size_t tb = cs_scan_tmp(nb + 1);
@@ -855,9 +895,8 @@ extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int64
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(cnt + nb, 0, sizeof(int64_t), s));
     size_t sm = (size_t)(CS_HS + cs_np2((int64_t)CS_BR * k)) * sizeof(int);
-    GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (CS_HS + CS_MAXID) * (int)sizeof(int)));
-    cs_count_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, cnt, bu_n);
+    GP_SMEM_ATTR(cs_count_kernel, (CS_HS + CS_MAXID) * sizeof(int));
+    cs_count_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, rows_per_block, cnt, bu_n);
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, cnt, bu_off, (int64_t)0, (size_t)(nb + 1), rocprim::plus<int64_t>(), s));
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -865,17 +904,18 @@ extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int64
 
 // pass 2: bu_row i32 [total], bu_mask u32 [total/32], wa_hi / wa_lo f16 [total/32 * 8 * 512] (only the fragments whose
 // mask bit is set are defined -- and read)
-extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, const int64_t *bu_off, int64_t total_rows,
-                               int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream_) {
+extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
+                               int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream_) {
     GP_CHECK_ARG(nbr && w && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
                  "gp_pool_cs_fill: bad argument");
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_fill: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
     GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_fill: k=%d too large (128*k <= %d)", k, CS_MAXNK);
-    int64_t nb = (nv + CS_BR - 1) / CS_BR;
+    int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
     size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
-    GP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cs_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_max));
-    cs_fill_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
+    GP_SMEM_ATTR(cs_fill_kernel, sm_max);
+    cs_fill_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
                                                   static_cast<_Float16 *>(wa_lo));
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -885,19 +925,24 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
 // engine = false: cs_pool_kernel (one tile per workgroup, the default); engine = true: cs_engine_kernel (persistent producer /
 // consumer form, one workgroup per CU).  The choice is an ARGUMENT of the call (round 3 selected the engine through the
 // process-global debug knob 11: a raised error left every later launch on the engine, and two host threads raced on it).
+// rows_per_block: the builder's (gp_pool_cs_count / _fill).  block_order (nullable, i32 [nblocks], a permutation of the row
+// blocks, device memory): the order in which the one-tile-per-workgroup kernel starts the row blocks -- by descending step
+// count (bu_off differences) the long tiles run first; NULL = memory order, XCD-contiguous.  The engine ignores it.
 static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
-                    const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
-                    void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, bool engine, void *stream_) {
+                    const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, int32_t rpb,
+                    const int32_t *block_order, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
+                    const float *out_scale, bool engine, void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0, "gp_pool_cs_apply: null/empty argument");
     GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply: d=%d (kernel specialised for %d columns)", d, CS_D);
+    GP_CHECK_ARG(cs_rpb_ok(rpb), "gp_pool_cs_apply: rows_per_block=%d (16..%d)", rpb, CS_BR);
     GP_CHECK_ARG((y_hi && y_lo) || y_f32, "gp_pool_cs_apply: no output requested");
     GP_CHECK_ARG(ld_x % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0, "gp_pool_cs_apply: x rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (ld_y % 8 == 0 && (uintptr_t)y_hi % 16 == 0 && (uintptr_t)y_lo % 16 == 0 && y_hi != x_hi && y_lo != x_lo),
                  "gp_pool_cs_apply: y rows must be 16-byte aligned and must not alias x");
     GP_CHECK_ARG(!y_f32 || (ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0), "gp_pool_cs_apply: fp32 output rows must be 16-byte aligned");
     hipStream_t s = gp_stream(stream_);
-    const int64_t nb = (nv + CS_BR - 1) / CS_BR;
-    const int64_t per_xcd = (nb * (CS_D / CS_NC) + 7) / 8;
+    const int64_t nb = (nv + rpb - 1) / rpb;
+    const int64_t per_xcd = block_order && !engine ? 2 * ((nb + 7) / 8) : (nb * (CS_D / CS_NC) + 7) / 8;
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
     const int tune = g_gp_knobs[4];                       // tuning bits: only ever handed to the *_tuning_kernel twins
     if (engine) {
@@ -909,7 +954,7 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
                      g_gp_debug_bytes[0], (size_t)grid * 4 * 10 * sizeof(uint64_t));
 #define EG_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
-                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, tune, out_scale, stamp
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, tune, out_scale, stamp, rpb
         if (stamp) {
             GP_SMEM_ATTR(cs_engine_tuning_kernel<true>, EG_SMEM);
             cs_engine_tuning_kernel<true><<<grid, 512, EG_SMEM, s>>>(EG_ARGS);
@@ -929,7 +974,7 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
                  g_gp_debug_bytes[0], (size_t)(per_xcd * 8) * CS_NW * 10 * sizeof(uint64_t));
 #define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
-                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp, rpb, block_order
     if (stamp) {
         GP_SMEM_ATTR(cs_pool_kernel<true>, CS_SMEM);
         cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
@@ -946,15 +991,18 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
 }
 
 extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
-                                const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, void *y_hi,
-                                void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale, void *stream_) {
-    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, false, stream_);
+                                const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
+                                int32_t rows_per_block, const int32_t *block_order, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
+                                int64_t ld_yf, const float *out_scale, void *stream_) {
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, block_order, y_hi, y_lo, ld_y, y_f32,
+                    ld_yf, out_scale, false, stream_);
 }
 
 // The same application through the persistent producer / consumer engine (cs_engine_kernel); bit-identical results.
 extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                                        const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
-                                       void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf, const float *out_scale,
-                                       void *stream_) {
-    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, y_hi, y_lo, ld_y, y_f32, ld_yf, out_scale, true, stream_);
+                                       int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
+                                       const float *out_scale, void *stream_) {
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, nullptr, y_hi, y_lo, ld_y, y_f32, ld_yf,
+                    out_scale, true, stream_);
 }

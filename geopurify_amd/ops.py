@@ -445,33 +445,41 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None
 
 
 class PoolCs:
-    """Column-sliced matrix-core pooling operator (gp_pool_cs_*): 128-row blocks, fragment masks."""
+    """Column-sliced matrix-core pooling operator (gp_pool_cs_*): blocks of up to 128 rows, fragment masks."""
 
-    def __init__(self, bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total):
+    def __init__(self, bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=128, order=None):
         self.bu_off, self.bu_n, self.bu_row, self.bu_mask = bu_off, bu_n, bu_row, bu_mask
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
-        self.block_rows = 128
+        self.block_rows = block_rows
+        self.order = order                              # i32 [nblocks]: row blocks by descending step count, or None
 
 
-def pool_cs_build(nbr, w):
-    """One host sync (total padded union rows, to size the arrays)."""
+def pool_cs_build(nbr, w, rows_per_block=None, longest_first=True):
+    """One host sync (total padded union rows, to size the arrays).
+    rows_per_block: None = gp_pool_cs_rows_per_block(nv) (the height that fills whole rounds of one workgroup per CU);
+    longest_first: also build the launch order of the row blocks by descending step count."""
     lib = _lib.load()
     nv, k = nbr.shape
     dev = nbr.device
-    nb = (nv + 127) // 128
-    ws = _ws(lib.gp_pool_cs_workspace_bytes(nv), dev)
+    rpb = int(lib.gp_pool_cs_rows_per_block(nv)) if rows_per_block is None else int(rows_per_block)
+    nb = (nv + rpb - 1) // rpb
+    ws = _ws(lib.gp_pool_cs_workspace_bytes(nv, rpb), dev)
     bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
     bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
-    check(lib.gp_pool_cs_count(_ptr(nbr), nv, int(k), _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(), _stream()),
+    check(lib.gp_pool_cs_count(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(), _stream()),
           "gp_pool_cs_count")
     total = int(bu_off[nb].item())                                                            # the one host sync
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
-    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
+    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), rpb, _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
                               _ptr(wa_lo), _stream()), "gp_pool_cs_fill")
-    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total)
+    order = None
+    if longest_first:
+        # tiles by descending step count (stable: equal counts keep their memory order); a tiny sort once per scene
+        order = torch.sort(bu_off[1:] - bu_off[:-1], descending=True, stable=True).indices.to(torch.int32).contiguous()
+    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb, order=order)
 
 
 def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, engine=False):
@@ -482,10 +490,14 @@ def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, 
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
     yh, yl = out_split if out_split is not None else (None, None)
-    fn, name = (lib.gp_pool_cs_apply_engine, "gp_pool_cs_apply_engine") if engine else (lib.gp_pool_cs_apply, "gp_pool_cs_apply")
-    check(fn(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
-             _ptr(op.wa_lo), op.nv, int(d), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
-             _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()), name)
+    head = (_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo),
+            op.nv, int(d), int(op.block_rows))
+    tail = (_ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0, _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+            _ptr(out_scale), _stream())
+    if engine:
+        check(lib.gp_pool_cs_apply_engine(*head, *tail), "gp_pool_cs_apply_engine")
+    else:
+        check(lib.gp_pool_cs_apply(*head, _ptr(op.order), *tail), "gp_pool_cs_apply")
     return out_f32 if out_f32 is not None else out_split
 
 

@@ -40,7 +40,7 @@ ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in ran
 NW = 4 if BR == 64 else 8
 nq = 4 if BR == 64 else 2
 nb = (Nv + BR - 1) // BR
-nwg = ((nb * nq + 7) // 8) * 8
+nwg = ((nb * nq + 7) // 8) * 8 + 64          # (+ slack: the cs operator may use a smaller block height / the longest-first grid)
 buf = torch.zeros(nwg * NW * 10, dtype=torch.int64, device="cuda")
 for _ in range(3):
     apply(xs, op, D, out_split=ys)
