@@ -17,6 +17,7 @@
 // Weight re-use is per offset (all pairs of k stream through W[k]) instead of per output tile, which
 // cuts the weight traffic from L2 by ~8x against the output-stationary v1 kernel.
 #include <cstring>
+#include <type_traits>
 #include <rocprim/device/device_scan.hpp>
 
 #include <hip/hip_fp16.h>
@@ -270,11 +271,13 @@ __device__ __forceinline__ uint64_t cv_real() {
 // STAMP (tuning twin only): wave 0 of every workgroup writes 10 x uint64 into `stamp`: {real-time start, real-time length, prologue
 // (descriptor + row ids + first stage landed), K loop, partial-store ISSUE, store drain (vmcnt(0)), whole tile -- shader cycles --,
 // XCC id | pairs << 8, cycles of the loop spent issuing LDS-DMA, cycles of the loop spent in the end-of-step wait + barrier}
-// SPLIT: waves 0-3 issue ALL of a stage's LDS-DMA (64 rows of each operand per wave), waves 4-7 none.  Round-4 stamps of the
-// symmetric form (every wave issues 8 instructions at the top of a step, then multiplies): per step 817 cycles of DMA issue during
-// which NEITHER wave of a SIMD feeds the matrix pipe, 2 153 of reads + MFMA, 1 827 waiting at the barrier for the SIMD partner's
-// MFMAs -- 4 797 cycles for 3 072 cycles of matrix work.  With the roles split, the partner (wave 4-7) multiplies while wave 0-3
-// absorbs the memory pipeline's back-pressure, and finishes its own MFMAs behind it.
+// Round-4 stamps of this loop (scripts/stamp_conv.py, profiles/r04_conv_stamps.log): per step 550-820 cycles of DMA issue during
+// which neither wave of a SIMD feeds the matrix pipe, 2 150 of reads + MFMA, 1 850 waiting at the barrier for the SIMD partner's
+// MFMAs -- 4 550-4 800 cycles for 3 072 cycles of matrix work.  Measured and left out (SPLIT = true, kept here as the switch of the
+// experiment): waves 0-3 issue ALL of a stage's LDS-DMA (64 rows of each operand), waves 4-7 none, so that a SIMD's second wave
+// multiplies while the first absorbs the memory pipeline's back-pressure: the step falls to 4 150 cycles (-8.6 %), the in-kernel
+// clock from 2.04 to 1.99 GHz, and the layer takes the same 1.929 ms -- on all-zero operands the same cycle count runs at
+// 2.37 GHz and 1.664 ms: the layer is bound by the clock the chip holds under this load, not by the schedule.
 template <bool TUNE, bool STAMP, bool SPLIT>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
@@ -360,17 +363,29 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     }
     __syncthreads();
     if constexpr (STAMP) st_pro = cv_now();
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        uint64_t st_a = 0;
-        if constexpr (STAMP) st_a = cv_now();
-        if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
-        if constexpr (STAMP) st_dma += cv_now() - st_a;
-        if (!(ablate & 2)) mma_step_f16x3<4>(sm, buf, wm, wn, fl, fsw, acc);   // padded rows are computed and discarded
-        if constexpr (STAMP) st_a = cv_now();
-        __syncthreads();
-        if constexpr (STAMP) st_wait += cv_now() - st_a;
-    }
+    // the last tile of a (chunk, offset) segment is partly filled (8192-row chunks: 1 tile in 9, a third full on average): a
+    // wave multiplies only the 16-row tiles that hold pairs -- matrix work the chip's power budget does not have to pay for.
+    // nrt is wave-uniform and fixed for the tile: one copy of the loop per value (a switch INSIDE the loop costs 98 spills).
+    auto k_loop = [&](auto nrt_c) {
+        constexpr int NRT = decltype(nrt_c)::value;
+        for (int s = 0; s < steps; ++s) {
+            const int buf = s & 1;
+            uint64_t st_a = 0;
+            if constexpr (STAMP) st_a = cv_now();
+            if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
+            if constexpr (STAMP) st_dma += cv_now() - st_a;
+            if constexpr (NRT > 0)
+                if (!(ablate & 2)) mma_step_f16x3<NRT>(sm, buf, wm, wn, fl, fsw, acc);
+            if constexpr (STAMP) st_a = cv_now();
+            __syncthreads();
+            if constexpr (STAMP) st_wait += cv_now() - st_a;
+        }
+    };
+    if (nrt == 4) k_loop(std::integral_constant<int, 4>{});
+    else if (nrt == 3) k_loop(std::integral_constant<int, 3>{});
+    else if (nrt == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (nrt == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
     if constexpr (STAMP) st_loop = cv_now();
     auto stamp_out = [&]() {
         if constexpr (STAMP) {
@@ -446,9 +461,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 __global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, false>(P1_FWD); }
 __global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false, false>(P1_FWD); }
 __global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, false>(P1_FWD); }
-// experiment (knob 3 bit 6): the split-role form, plain and stamped
-__global__ void __launch_bounds__(NT2) conv_phase1_split_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false, true>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_split_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, true>(P1_FWD); }
+
 #undef P1_PARAMS
 #undef P1_FWD
 
@@ -787,8 +800,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_SMEM_ATTR(conv_phase1_dma_kernel, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_tuning_kernel, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_stamp_kernel, sizeof(V2Smem));
-    GP_SMEM_ATTR(conv_phase1_split_kernel, sizeof(V2Smem));
-    GP_SMEM_ATTR(conv_phase1_split_stamp_kernel, sizeof(V2Smem));
+
     // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
     // blockIdx * 8 (a chunk overwrites the previous one's: the last chunk of the last call stays)
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[1]);
@@ -828,8 +840,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         int64_t row_count = chunked ? ((row_begin + chunk_rows < nv) ? chunk_rows : nv - row_begin) : nv;
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            const bool split = (g_conv_ablate & 64) != 0;   // experiment: split DMA / MFMA roles
-            const int tune = g_conv_ablate & ~(16 | 64);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp
@@ -837,9 +848,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
                              g_gp_debug_bytes[1], (size_t)nblocks * 10 * sizeof(uint64_t));
-                if (stamp && split) conv_phase1_split_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
-                else if (split) conv_phase1_split_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
-                else if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
                 else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
             } else {
