@@ -123,12 +123,13 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
         gbs = b / (t * 1e-3) / 1e9
         out[name] = {"ms": round(t, 4), "algorithmic_bytes": int(b), "achieved": round(gbs, 1), "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": what}
-    for name in ("morton order", "grid+kernel_map", "student", "pool operator+split"):
+    for name in ("morton order", "grid+kernel_map", "student", "pool plan+split", "pool operator fill"):
         if name in ms:
             out[name] = {"ms": round(ms[name], 4), "note": {"morton order": "internal row order of the voxels (sort of Nv keys): index work, no SURVEY 8(d) figure",
                                                            "grid+kernel_map": "lattice grid + 27-offset kernel map: index work, no SURVEY 8(d) figure",
                                                            "student": "matrix-core bound: see roofline_conv",
-                                                           "pool operator+split": "built once per scene: the pooling operator in fragment order + the f16 hi/lo split of X"}[name]}
+                                                           "pool plan+split": "once per scene, needs the kNN lists only: union sizes of the pooling operator + the f16 hi/lo split of X",
+                                                           "pool operator fill": "once per scene: union rows, fragment masks and the weights in fragment order"}[name]}
     out["note"] = ("one-stream side pass after the timed region, HIP events at stage boundaries, mean over the side scenes; "
                    "achieved = SURVEY 8(d) algorithmic bytes / stage time; peak 8000 GB/s")
     return out
@@ -539,6 +540,8 @@ def main():
         elif hasattr(obj, "__dataclass_fields__"):
             for f in obj.__dataclass_fields__:
                 yield from _tensors(getattr(obj, f))
+        elif type(obj).__module__.startswith("geopurify_amd") and hasattr(obj, "__dict__"):
+            yield from _tensors(vars(obj))              # ConvPairs, PoolCs, Grid: plain holders of device arrays
 
     def step(i, stage=None, stream=None, prefetch=True):
         if split and stream is None:
@@ -547,18 +550,20 @@ def main():
             return _step(i, stage)
 
     def _lift_ahead(i, after=None):
-        """Loader + lift of scene i on streams[0], after the event `after` (recorded on streams[1])."""
+        """Loader + lift + HotPath.prepare (voxel means, kernel map and pairs, kNN lists, pooling plan: everything of refine that
+        does not need the student) of scene i on streams[0], after the event `after` (recorded on streams[1])."""
         j = i % max(args.scenes, 1)
         with torch.cuda.stream(streams[0]):
             if after is not None:
                 streams[0].wait_event(after)
             batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
             F, text, scale = hp.lift_dense(batch, vlms[j]) if cfg.dense_features else hp.lift_masks(batch, vlms[j])
+            prep = hp.prepare(batch, F)
             done = torch.cuda.Event()
             done.record(streams[0])
-        for t in _tensors([batch, F, text]):            # the consumer stream: the allocator keeps the blocks until its kernels ran
+        for t in _tensors([batch, F, text, prep]):      # the consumer stream: the allocator keeps the blocks until its kernels ran
             t.record_stream(streams[1])
-        pending[i] = (batch, F, text, scale, done)
+        pending[i] = (batch, F, text, scale, done, prep)
 
     def _step_split(i, prefetch):
         """Scene i's refine + classify on streams[1]; the NEXT scene's loader + lift is enqueued on streams[0] from inside
@@ -567,7 +572,7 @@ def main():
         kernel has the chip to itself.  One scene = one lift + one refine, as in the other schedules."""
         if i not in pending:
             _lift_ahead(i)
-        batch, F, text, scale, done = pending.pop(i)
+        batch, F, text, scale, done, prep = pending.pop(i)
         with torch.cuda.stream(streams[1]):
             streams[1].wait_event(done)
             started = torch.cuda.Event()
@@ -577,7 +582,7 @@ def main():
                 if prefetch:
                     _lift_ahead(i + 1, after=started)
                     streams[1].wait_event(pending[i + 1][4])
-            feats = hp.refine(batch, F, after_student=hook)
+            feats = hp.refine(batch, F, after_student=hook, prepared=prep)
             hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale},
                                   batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
         return batch

@@ -454,14 +454,16 @@ class PoolCs:
         self.order = order                              # i32 [nblocks]: row blocks by descending step count, or None
 
 
-def pool_cs_build(nbr, w, rows_per_block=None, longest_first=True):
-    """One host sync (total padded union rows, to size the arrays).
-    rows_per_block: None = gp_pool_cs_rows_per_block(nv) (the height that fills whole rounds of one workgroup per CU);
-    longest_first: also build the launch order of the row blocks by descending step count."""
+def pool_cs_plan(nbr, rows_per_block=None):
+    """First half of the operator build: needs the neighbour lists only (not the weights), so a scheduler can run it -- and its
+    one host sync (total padded union rows, to size the arrays) -- before the affinity weights exist.  Returns a PoolCs without
+    weights; pool_cs_fill completes it.
+    rows_per_block: None = 128 (gp_pool_cs_rows_per_block(nv) spreads the rows over whole rounds of one workgroup per CU; on the S
+    scene every height from 112 to 128 measures the same 0.223 ms per application, profiles/r04_pool_block_height.log)."""
     lib = _lib.load()
     nv, k = nbr.shape
     dev = nbr.device
-    rpb = int(lib.gp_pool_cs_rows_per_block(nv)) if rows_per_block is None else int(rows_per_block)
+    rpb = 128 if rows_per_block is None else int(rows_per_block)
     nb = (nv + rpb - 1) // rpb
     ws = _ws(lib.gp_pool_cs_workspace_bytes(nv, rpb), dev)
     bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
@@ -473,13 +475,27 @@ def pool_cs_build(nbr, w, rows_per_block=None, longest_first=True):
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
-    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), rpb, _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
-                              _ptr(wa_lo), _stream()), "gp_pool_cs_fill")
-    order = None
+    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb, order=None)
+
+
+def pool_cs_fill(op, nbr, w, longest_first=False):
+    """Second half: union rows, fragment masks and the weights in fragment order (no host sync).
+    longest_first: also build a launch order of the row blocks by descending step count (measured SLOWER, 0.279 against 0.223 ms
+    per application: dealing the sorted blocks over the XCDs takes the halo rows of neighbouring blocks out of each other's L2;
+    kept as an option of the ABI, off by default)."""
+    lib = _lib.load()
+    nv, k = nbr.shape
+    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), int(op.block_rows), _ptr(op.bu_off), op.total, _ptr(op.bu_row),
+                              _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo), _stream()), "gp_pool_cs_fill")
+    op.order = None
     if longest_first:
-        # tiles by descending step count (stable: equal counts keep their memory order); a tiny sort once per scene
-        order = torch.sort(bu_off[1:] - bu_off[:-1], descending=True, stable=True).indices.to(torch.int32).contiguous()
-    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb, order=order)
+        op.order = torch.sort(op.bu_off[1:] - op.bu_off[:-1], descending=True, stable=True).indices.to(torch.int32).contiguous()
+    return op
+
+
+def pool_cs_build(nbr, w, rows_per_block=None, longest_first=False):
+    """pool_cs_plan + pool_cs_fill."""
+    return pool_cs_fill(pool_cs_plan(nbr, rows_per_block), nbr, w, longest_first)
 
 
 def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, engine=False):
