@@ -97,6 +97,65 @@ def conv_roofline(timer):
             "avg_layer_ms": round(ms, 4)}
 
 
+def conv_ceilings(hp, dev):
+    """What bounds a 512->512 layer (VERDICT r3 next 4 ii): ONE layer of the last scene, alone on the GPU, on random pre-split rows:
+      layer_ms             the product kernels (conv_phase1_dma_kernel per chunk + conv_phase2_kernel per chunk)
+      no_mfma_ms           the same launches with the MFMAs compiled out of the loop's body (conv_phase1_tuning_kernel, knob 3 = 2):
+                           operand gathers into LDS, the partial-row round trip and phase 2 -- the layer's DATA-MOVEMENT ceiling
+      zero_operand_ms      the product kernels on all-zero rows and weights: the same instruction stream, the same cycles, at the
+                           clock the chip holds when the matrix pipes toggle nothing (MI355X_MICROARCH.md "DVFS give-back")
+      mfma_floor_ms        3 x the layer's flops at the dense f16 peak (2.5 PFLOP/s).
+    Algorithmic bytes per layer: gathered operand rows P x 2 KiB x 2 column tiles, weight tiles (P / 256) x 2 x 512 KiB, partial
+    rows P x 2 KiB written and read, output rows (fp32 where kept + hi/lo planes); the memory-side bytes per LAYER are in
+    profiles/r04_conv_pmc_summary.json."""
+    from geopurify_amd import _lib, ops
+    st = hp.student
+    pairs = getattr(st, "last_pairs", None)
+    lay = [l for l in st.layers if l[0] == "f16x3" and l[1][0].shape[1] == l[1][0].shape[2]]
+    if pairs is None or not lay:
+        return None
+    _, (hi, lo), scale, shift = lay[0]
+    nv, c = pairs.nv, hi.shape[1]
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def run_on(x, w_hi, w_lo, knob):
+        xs = ops.split_f16(x, c, per_row=True)
+        ys = (torch.empty((nv, c), dtype=torch.float16, device=dev), torch.empty((nv, c), dtype=torch.float16, device=dev),
+              torch.empty(nv, dtype=torch.float32, device=dev))
+        f = lambda: ops.sparse_conv_f16x3(None, pairs, w_hi, w_lo, scale, shift, relu=True, x_split=xs[:2], x_row_inv=xs[2],
+                                          out_split=ys[:2], out_row_inv=ys[2], want_f32=False)
+        lib.gp_debug_set(3, knob)
+        try:
+            for _ in range(20):
+                f()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(8):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 8)
+        finally:
+            lib.gp_debug_set(3, 0)
+        return float(np.median(ts))
+    x = torch.randn(nv, c, device=dev, generator=g)
+    full = run_on(x, hi, lo, 0)
+    nomfma = run_on(x, hi, lo, 2)
+    zero = run_on(torch.zeros(nv, c, device=dev), torch.zeros_like(hi), torch.zeros_like(lo), 0)
+    P = float(pairs.num_pairs)
+    flop = 2.0 * P * c * c
+    alg = {"gathered_rows": P * c * 4 * (c // 256), "weight_tiles": np.ceil(P / 256) * (c // 256) * 256 * c * 4,
+           "partial_rows_written_and_read": 2 * P * c * 4, "output_planes": nv * c * 4}
+    return {"layer_ms": round(full, 4), "no_mfma_ms": round(nomfma, 4), "zero_operand_ms": round(zero, 4),
+            "mfma_floor_ms": round(3 * flop / (MFMA_F16_PEAK_TFLOPS * 1e12) * 1e3, 4), "pairs": int(P), "chunks": int(pairs.num_chunks),
+            "algorithmic_bytes_per_layer": {k: int(v) for k, v in alg.items()},
+            "note": "one 512->512 layer of the last scene alone on the GPU, random pre-split rows, median of 3 x 8 launches after 20 warm ones"}
+
+
 def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
     """north_star: "scenes/sec ... as fraction of the HBM roofline".  One line per stage of the scene: the ALGORITHMIC bytes of
     SURVEY.md section 8(d) (what the stage has to move at least, N points, Nv voxels, V views, n_v visible points per view,
@@ -724,6 +783,10 @@ def main():
                        "frac_isolated_over_ceiling": round(c_ms / pool_ms_alone, 4),
                        "what": "the isolated launches repeated with the fragment reads, the MFMAs and the weight-fragment DMA switched "
                                "off: union rows gathered into the LDS ring and output rows stored, nothing else (same grid, ring, occupancy)"}
+        try:
+            conv_ceil = conv_ceilings(hp, dev) if cfg.feat_dim == 512 else None
+        except Exception as e:                            # an extra: never lose the headline line over it
+            conv_ceil = {"error": repr(e)}
         achieved = tot_rows * per_row / (tot_ms * 1e-3) / 1e9      # all timed launches, each priced by its own voxel count
         # per-stage breakdown from a ONE-stream side pass (stage marks are meaningless while two scenes interleave)
         stage = StageTimer()
@@ -774,7 +837,7 @@ def main():
                          "note": "achieved = algorithmic_bytes_per_launch / avg_launch_ms, both means over the launches of the timed "
                                  "region (HIP events around every launch); _isolated: the last scene's launches (Nv in config.workload) "
                                  "repeated with nothing else on the GPU (one warm pass, then the median of three passes)"},
-            "roofline_conv": conv_roofline(conv_timer),
+            "roofline_conv": dict(conv_roofline(conv_timer) or {}, ceilings=conv_ceil) or None,
             "roofline_stages": stage_roof,
             "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV output: per kernel name, mean counter value per dispatch (+ launches).
-usage: scripts/pmc_summarize.py <dir> [kernel-substring]"""
+usage: scripts/pmc_summarize.py <dir> [kernel-substring ...]"""
 import csv
 import glob
 import json
@@ -9,12 +9,12 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-want = sys.argv[2] if len(sys.argv) > 2 else "pool"
+wants = sys.argv[2:] if len(sys.argv) > 2 else ["pool"]
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if want in k:
+        if any(w in k for w in wants):
             acc[k.split("(")[0][:90]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
