@@ -20,9 +20,6 @@
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 
-#include <initializer_list>
-#include <utility>
-
 #include "gp_common.h"
 
 extern int g_gp_knobs[16];
@@ -44,8 +41,7 @@ constexpr int CS_NC = 256;             // columns per workgroup
 constexpr int CS_NW = 8;               // waves per workgroup
 constexpr int CS_WC = CS_NC / CS_NW;   // columns per wave
 constexpr int CS_MAXID = 16384;        // sort buffers of the builder (a power of two)
-constexpr int CS_BR_MAX = 152;         // tallest block (10 groups): 152 x 96 neighbour ids + the sort buffers fill the builder's LDS
-constexpr int CS_MAXNK = CS_BR_MAX * 96;   // block_rows x K ids per block (K <= 96)
+constexpr int CS_MAXNK = 12288;        // block_rows x K ids per block (K <= 96): with the position table the builder's LDS is full
 constexpr int CS_HS = 16384;           // hash slots of the builder
 constexpr float CS_WSCALE = 1024.f;    // weights (<= 1) are stored x 2^10 so that their f16 lo parts stay normal
 
@@ -177,10 +173,9 @@ cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int rpb, int
 
 // pass 2: the block's union rows in (first group, last group, group set, id) order, one bit per (step, group) that says
 // whether the 16 x 32 weight fragment holds a non-zero, and the ELL weights scattered into MFMA fragment order:
-// wa[(step * ng + group) * 64 + lane][8], lane = (k >> 3) * 16 + m  (k = union row within the step, m = row within the group;
-// ng = 8 groups for blocks of up to 128 rows, 10 beyond).
+// wa[(step * 8 + group) * 64 + lane][8], lane = (k >> 3) * 16 + m  (k = union row within the step, m = row within the group).
 __global__ void __launch_bounds__(1024)
-cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int rpb, int ng, const int64_t *__restrict__ bu_off,
+cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int rpb, const int64_t *__restrict__ bu_off,
                int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
     extern __shared__ int s_mem[];                           // A[16384] | B[16384] | npos u16 [br*k]
     int *A = s_mem, *B = s_mem + CS_HS;
@@ -206,14 +201,13 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
         atomicOr(&A[lo], 1 << ((t / k) >> 4));
     }
     __syncthreads();
-    // order key: first group | group set | index among the sorted ids (deterministic).  Among sets with the same first group the
-    // numeric order of the set is led by its HIGHEST bit, i.e. this is the order (first group, last group, set, id).
+    // order key: first group | last group | group set | index among the sorted ids (deterministic)
     for (int i = tid; i < np2; i += 1024) {
         int key = INT32_MAX;
         if (i < U) {
             const int m = A[i];
-            const int first = __ffs(m) - 1;
-            key = (first << 24) | (m << 14) | i;                       // 4 + 10 + 14 bits
+            const int first = __ffs(m) - 1, last = 31 - __clz(m);
+            key = (first << 28) | (last << 25) | (m << 14) | i;      // 3 + 3 + 8 + 14 bits (bit 31 stays clear)
         }
         A[i] = key;
     }
@@ -230,19 +224,19 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
     __shared__ unsigned s_mask[CS_MAXNK / CS_KS];
     for (int t = tid; t < Up / CS_KS; t += 1024) {
         unsigned m = 0;
-        for (int p = t * CS_KS; p < (t + 1) * CS_KS && p < U; ++p) m |= (unsigned)(A[p] >> 14) & 0x3FFu;
+        for (int p = t * CS_KS; p < (t + 1) * CS_KS && p < U; ++p) m |= (unsigned)(A[p] >> 14) & 0xFFu;
         bu_mask[ks0 + t] = m;
         s_mask[t] = m;
     }
     __syncthreads();
     // zero the block's non-empty fragments (the only ones the apply kernel fetches), then scatter into them: the
     // barrier orders this workgroup's zero stores before its element stores (both through the same L2)
-    for (int i = tid; i < (Up / CS_KS) * ng * 64; i += 1024) {
+    for (int i = tid; i < (Up / CS_KS) * CS_NG * 64; i += 1024) {
         const int f = i >> 6;
-        if ((s_mask[f / ng] >> (f % ng)) & 1u) {
+        if ((s_mask[f >> 3] >> (f & 7)) & 1u) {
             const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<f16x8 *>(wa_hi + (ks0 * ng * 64 + i) * 8) = z;
-            *reinterpret_cast<f16x8 *>(wa_lo + (ks0 * ng * 64 + i) * 8) = z;
+            *reinterpret_cast<f16x8 *>(wa_hi + (ks0 * CS_NG * 64 + i) * 8) = z;
+            *reinterpret_cast<f16x8 *>(wa_lo + (ks0 * CS_NG * 64 + i) * 8) = z;
         }
     }
     __syncthreads();
@@ -254,7 +248,7 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
         const int p = npos[lo];
         const int64_t ks = ks0 + p / CS_KS;
         const int kk = p % CS_KS;
-        const int64_t idx = ((ks * ng + (rl >> 4)) * 64 + (kk >> 3) * 16 + (rl & 15)) * 8 + (kk & 7);
+        const int64_t idx = ((ks * CS_NG + (rl >> 4)) * 64 + (kk >> 3) * 16 + (rl & 15)) * 8 + (kk & 7);
         const float v = w[r0 * k + t] * CS_WSCALE;
         const _Float16 h = (_Float16)v;
         wa_hi[idx] = h;
@@ -274,35 +268,7 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
 // `s_waitcnt vmcnt(6); s_barrier` (6 = the DMA instructions of the younger stage; vector memory operations complete in
 // issue order and the loop issues no other).  Row ids and fragment masks are scalar loads issued one step ahead.
 // (TUNE: the ablation bits of `ablate_` are honoured; the production instantiation compiles them out)
-// NG = 16-row groups a block can hold: 8 (blocks of up to 128 rows: the default) or 10 (up to 152 rows: fewer, fuller rounds of
-// one workgroup per CU and smaller unions per row, for scenes whose row count leaves the last round of 128-row tiles nearly
-// empty -- gp_pool_cs_rows_per_block).  Per NG: weight plane NG KiB, stage 32 + 2 NG KiB (NG = 10: 3 x 52 = 156 KiB of LDS),
-// 2 NG accumulator tiles per wave; waves 0 .. NG - 9 stage a second weight fragment (8 instead of 6 LDS-DMA per stage).
-template <int NG>
-struct CsGeo {
-    static constexpr int H = NG / 2;                       // groups per MFMA batch
-    static constexpr int WPL = NG * 1024;                  // one weight plane
-    static constexpr int STAGE = CS_OFF_W + 2 * WPL;
-    static constexpr size_t SMEM = (size_t)CS_NST * STAGE;
-    static_assert(NG == 8 || NG == 10, "two batches of 4 or 5 groups");
-    static_assert((size_t)CS_NW * H * 16 * CS_EP * sizeof(float) <= SMEM, "epilogue staging (half a block) must fit in the ring");
-    static_assert(CS_OFF_W + 2 * WPL < 65536, "intra-stage LDS offsets are 16-bit immediates");
-};
-// weight fragments of groups G0 .. G0 + H - 1 of a stage (the non-empty ones): compile-time LDS offsets
-template <int G0, int WPL, int H, int... I>
-__device__ __forceinline__ void cs_rd_frags_(unsigned m, uint32_t aw, f16x8 (&ah)[H], f16x8 (&al)[H], std::integer_sequence<int, I...>) {
-    (void)std::initializer_list<int>{(((m >> (G0 + I)) & 1u) ? (cs_rd128<(G0 + I) * 1024>(ah[I], aw), cs_rd128<WPL + (G0 + I) * 1024>(al[I], aw), 0) : 0)...};
-}
-template <int G0, int WPL, int H>
-__device__ __forceinline__ void cs_rd_frags(unsigned m, uint32_t aw, f16x8 (&ah)[H], f16x8 (&al)[H]) {
-    cs_rd_frags_<G0, WPL, H>(m, aw, ah, al, std::make_integer_sequence<int, H>{});
-}
-__device__ __forceinline__ void cs_wait_a(f16x8 (&h)[5], f16x8 (&l)[5]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]));
-}
-
-template <bool STAMP, bool TUNE, int NG>
+template <bool STAMP, bool TUNE>
 __device__ __forceinline__ void
 cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
                const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
@@ -311,8 +277,6 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb,
                const int32_t *__restrict__ order) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    using G = CsGeo<NG>;
-    constexpr int H = G::H, WPL = G::WPL, STAGE = G::STAGE;
     const int ablate = TUNE ? ablate_ : 0;
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
     if constexpr (STAMP) { st_t0 = cs_now(); st_r0 = cs_real(); }
@@ -347,14 +311,13 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
     const int64_t dsrc1 = col0 + ((dc ^ (2 * t1)) * 8);
     const int32_t *idg = bu_row + ub0 + 4 * wv;                                    // this wave's row ids, step 0
     const uint32_t *mkg = bu_mask + ks0;
-    const _Float16 *wah = wa_hi + (ks0 * NG + wv) * 512;
-    const _Float16 *wal = wa_lo + (ks0 * NG + wv) * 512;
-    const bool two_frags = NG > 8 && wv < NG - 8;          // wave-uniform: this wave also stages fragment 8 + wv
+    const _Float16 *wah = wa_hi + (ks0 * CS_NG + wv) * 512;
+    const _Float16 *wal = wa_lo + (ks0 * CS_NG + wv) * 512;
     auto issue = [&](i32x4 id, unsigned mk, int k, int slot) {
-        unsigned char *dst = smem_raw + slot * STAGE;
+        unsigned char *dst = smem_raw + slot * CS_STAGE;
         const int ida = du ? id.y : id.x, idb = du ? id.w : id.z;
-        // Every stage is EXACTLY CS_DMA = 6 LDS-DMA instructions per wave (8 for a wave that stages two weight fragments), in every
-        // tuning mask: the hand-over's hand-counted `vmcnt` means "the older stage has landed" only then.  Tuning bit 1 (no row gather) and bit 3 (no weight
+        // Every stage is EXACTLY CS_DMA = 6 LDS-DMA instructions per wave, in every tuning mask: the hand-over's hand-counted
+        // `vmcnt(CS_DMA)` means "the older stage has landed" only then.  Tuning bit 1 (no row gather) and bit 3 (no weight
         // fragments) therefore do not drop instructions, they make all lanes fetch ONE hot 16-byte piece instead (round 3
         // dropped them: the ceiling launches of bench.py handed a slot over with half of the older stage in flight, and the
         // 64-row kernel of pool_mfma.hip, whose row ids ride in the ring, read stale ids and faulted).
@@ -366,22 +329,8 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
         cs_glds16(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
         // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line)
         const int lo = (((mk >> wv) & 1u) && !hot_w) ? lane * 8 : 0;
-        cs_glds16(wah + (int64_t)k * (NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
-        cs_glds16(wal + (int64_t)k * (NG * 512) + lo, dst + CS_OFF_W + WPL + wv * 1024);
-        if constexpr (NG > 8) {
-            if (two_frags) {
-                const int lo2 = (((mk >> (8 + wv)) & 1u) && !hot_w) ? lane * 8 : 0;
-                cs_glds16(wah + (int64_t)k * (NG * 512) + 8 * 512 + lo2, dst + CS_OFF_W + (8 + wv) * 1024);
-                cs_glds16(wal + (int64_t)k * (NG * 512) + 8 * 512 + lo2, dst + CS_OFF_W + WPL + (8 + wv) * 1024);
-            }
-        }
-    };
-    // hand-over: wait until only this wave's DMA of the YOUNGER stage is outstanding (per wave: 6, or 8 with two fragments)
-    auto handover = [&]() {
-        if constexpr (NG > 8) {
-            if (two_frags) { cs_handover<CS_DMA + 2>(); return; }
-        }
-        cs_handover<CS_DMA>();
+        cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
+        cs_glds16(wal + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + CS_WPL + wv * 1024);
     };
     auto load_ids = [&](int k) { return *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS); };
 
@@ -397,9 +346,9 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
     }
     const uint32_t addr_w = lds0 + CS_OFF_W + lane * 16;
 
-    f32x4 acc[NG * 2];
+    f32x4 acc[CS_NG * 2];
 #pragma unroll
-    for (int i = 0; i < NG * 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < CS_NG * 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: stages 0 and 1 in flight (a one-step block stages its only step twice)
     unsigned mA, mB, mC;
@@ -414,7 +363,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
         idv = load_ids(k2);
         mC = mkg[k2];
         asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mC));   // (waited for here, not inside the loop)
-        handover();
+        cs_handover<CS_DMA>();
     }
     if constexpr (STAMP) st_pro = cs_now();
     // Software pipeline (the fragment reads of all eight waves leave the barrier together and take ~500 cycles to come back;
@@ -430,22 +379,22 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
     // (a second barrier per step, the stage THREE steps ahead issued into it: 0.259 instead of 0.232 ms -- the launch is bound by
     // the bytes that reach HBM, 1.28 GB at 5.5 TB/s, not by the bytes in flight).
     s16x4 fb[2][2][2];
-    f16x8 ah0[H], al0[H], ah1[H], al1[H], bhp[2], blp[2];
+    f16x8 ah0[4], al0[4], ah1[4], al1[4], bhp[2], blp[2];
 #pragma unroll
-    for (int i = 0; i < H; ++i) { ah0[i] = al0[i] = ah1[i] = al1[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    for (int i = 0; i < 4; ++i) { ah0[i] = al0[i] = ah1[i] = al1[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { bhp[u] = blp[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
     unsigned mP = 0;                                         // fragment mask of the previous step (its groups 4-7 are pending)
     auto mfma_hi = [&](unsigned m) {
 #pragma unroll
-        for (int mt = 0; mt < H; ++mt)
-            if (__builtin_expect((m >> (H + mt)) & 1u, 1)) {
+        for (int mt = 0; mt < 4; ++mt)
+            if (__builtin_expect((m >> (4 + mt)) & 1u, 1)) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(H + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bhp[u], acc[(H + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], bhp[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(H + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], blp[u], acc[(H + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[mt], blp[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[(H + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1[mt], bhp[u], acc[(H + mt) * 2 + u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[(4 + mt) * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1[mt], bhp[u], acc[(4 + mt) * 2 + u], 0, 0, 0);
             }
     };
     const bool late = !(ablate & 32) && wv >= 4;            // tuning aid: bit 5 makes every wave issue first
@@ -457,7 +406,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
             if (s < n) {
                 uint64_t st_a = 0, st_b = 0;
                 if constexpr (STAMP) st_a = cs_now();
-                const uint32_t a0 = addr[0] + J * STAGE, a1 = addr[1] + J * STAGE, aw = addr_w + J * STAGE;
+                const uint32_t a0 = addr[0] + J * CS_STAGE, a1 = addr[1] + J * CS_STAGE, aw = addr_w + J * CS_STAGE;
                 const unsigned m = mA;
                 if (do_reads) {
                     // staged rows: fb[col block][plane][rows 8g+q | 8g+q+4]; weight fragments of groups 0-3
@@ -469,7 +418,10 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                     cs_tr<4 * CS_RB>(fb[1][0][1], a1);
                     cs_tr<CS_PLANE>(fb[1][1][0], a1);
                     cs_tr<CS_PLANE + 4 * CS_RB>(fb[1][1][1], a1);
-                    cs_rd_frags<0, WPL, H>(m, aw, ah0, al0);
+                    if (m & 1u) { cs_rd128<0 * 1024>(ah0[0], aw); cs_rd128<CS_WPL + 0 * 1024>(al0[0], aw); }
+                    if (m & 2u) { cs_rd128<1 * 1024>(ah0[1], aw); cs_rd128<CS_WPL + 1 * 1024>(al0[1], aw); }
+                    if (m & 4u) { cs_rd128<2 * 1024>(ah0[2], aw); cs_rd128<CS_WPL + 2 * 1024>(al0[2], aw); }
+                    if (m & 8u) { cs_rd128<3 * 1024>(ah0[3], aw); cs_rd128<CS_WPL + 3 * 1024>(al0[3], aw); }
                 }
                 if (!late && s + 2 < n) issue(idv, mC, s + 2, (J + 2) % CS_NST);
                 if constexpr (STAMP) if (ablate & 64) st_issue += cs_now() - st_a;
@@ -484,11 +436,14 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                 const i32x4 idn = load_ids(kn);
                 const unsigned mN = mkg[kn];
                 if (do_reads) {
-                    cs_rd_frags<H, WPL, H>(m, aw, ah1, al1);
+                    if (m & 16u) { cs_rd128<4 * 1024>(ah1[0], aw); cs_rd128<CS_WPL + 4 * 1024>(al1[0], aw); }
+                    if (m & 32u) { cs_rd128<5 * 1024>(ah1[1], aw); cs_rd128<CS_WPL + 5 * 1024>(al1[1], aw); }
+                    if (m & 64u) { cs_rd128<6 * 1024>(ah1[2], aw); cs_rd128<CS_WPL + 6 * 1024>(al1[2], aw); }
+                    if (m & 128u) { cs_rd128<7 * 1024>(ah1[3], aw); cs_rd128<CS_WPL + 7 * 1024>(al1[3], aw); }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) { bhp[u] = cs_cat(fb[u][0][0], fb[u][0][1]); blp[u] = cs_cat(fb[u][1][0], fb[u][1][1]); }
 #pragma unroll
-                    for (int mt = 0; mt < H; ++mt)
+                    for (int mt = 0; mt < 4; ++mt)
                         if (__builtin_expect((m >> mt) & 1u, 1)) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u) acc[mt * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[mt], bhp[u], acc[mt * 2 + u], 0, 0, 0);
@@ -504,7 +459,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                 cs_wait_a(ah1, al1);
                 asm volatile("" ::"s"(idn.x), "s"(idn.y), "s"(idn.z), "s"(idn.w), "s"(mN));
                 if constexpr (STAMP) { st_b = cs_now(); st_work += st_b - st_a; }
-                if (s + 2 < n) handover(); else cs_handover<0>();
+                if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
                 if constexpr (STAMP) st_wait += cs_now() - st_b;
                 mP = m; mA = mB; mB = mC; mC = mN; idv = idn;
             }
@@ -518,34 +473,33 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
     // x * s (s = the power of two of gp_pow2_scale); pooling is linear, so the planes written for the next application stay
     // in that domain and only the fp32 output is multiplied by out_scale = 1/s.
     const float inv = 1.f / CS_WSCALE;
-    float *stg = reinterpret_cast<float *>(smem_raw) + wv * (H * 16 * CS_EP);
+    float *stg = reinterpret_cast<float *>(smem_raw) + wv * (CS_BR * CS_EP);
     const int fl = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < CS_NG; ++mt)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(mt * 16 + fq * 4 + r) * CS_EP + cb * 16 + fl] = acc[mt * 2 + cb][r] * inv;
+    gp_wave_sync();
     const int64_t row0 = b * rpb;
     const int colw = col0 + wv * CS_WC;
     // lane -> 8 consecutive columns of row it * 16 + (lane >> 2): every store instruction writes 16 rows x 64 bytes
     const int er = lane >> 2, ec = (lane & 3) * 8;
     const float so = (y_f32 && out_scale) ? out_scale[0] : 1.f;
 #pragma unroll
-    for (int h8 = 0; h8 < 2; ++h8) {                        // two halves of H groups: bounds the staging area and the live registers
+    for (int h8 = 0; h8 < 2; ++h8) {                        // two halves of 64 rows: bounds the live registers
+        float4 v[4][2];
 #pragma unroll
-        for (int mt = 0; mt < H; ++mt)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stg[(mt * 16 + fq * 4 + r) * CS_EP + cb * 16 + fl] = acc[(h8 * H + mt) * 2 + cb][r] * inv;
-        gp_wave_sync();
-        float4 v[H][2];
-#pragma unroll
-        for (int it = 0; it < H; ++it) {
-            const float *sp = stg + (it * 16 + er) * CS_EP + ec;
+        for (int it = 0; it < 4; ++it) {
+            const float *sp = stg + (h8 * 64 + it * 16 + er) * CS_EP + ec;
             v[it][0] = *reinterpret_cast<const float4 *>(sp);
             v[it][1] = *reinterpret_cast<const float4 *>(sp + 4);
         }
         asm volatile("" ::: "memory");
-        gp_wave_sync();                                     // the next half overwrites the staging area
 #pragma unroll
-        for (int it = 0; it < H; ++it) {
-            const int lrow = (h8 * H + it) * 16 + er;       // (rows rpb .. of a block do not exist: their weights are zero)
+        for (int it = 0; it < 4; ++it) {
+            const int lrow = h8 * 64 + it * 16 + er;       // (rows rpb .. 127 of a block do not exist: their weights are zero)
             const int64_t grow = row0 + lrow;
             if (lrow < rpb && grow < nv && !(ablate & 16)) {             // tuning aid: bit 4 skips the output stores
                 const float xv[8] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w, v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
@@ -584,12 +538,11 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                        uint64_t *__restrict__ stamp, int rpb, const int32_t *__restrict__ order
 #define CS_POOL_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp, rpb, order
 // the product kernel (STAMP = false: no tuning bits, no stamps) and its stamped instantiation
-template <bool STAMP, int NG>
-__global__ void __launch_bounds__(512, 2) cs_pool_kernel(CS_POOL_PARAMS) { cs_pool_body<STAMP, STAMP, NG>(CS_POOL_FWD); }
+template <bool STAMP>
+__global__ void __launch_bounds__(512, 2) cs_pool_kernel(CS_POOL_PARAMS) { cs_pool_body<STAMP, STAMP>(CS_POOL_FWD); }
 // the same body with the tuning bits live, under its own name: launches with parts of the kernel switched off (bench.py's
 // gather + store ceiling, scripts/bench_pool.py ablations) do not mix into the product kernel's rows of a kernel trace
-template <int NG>
-__global__ void __launch_bounds__(512, 2) cs_pool_tuning_kernel(CS_POOL_PARAMS) { cs_pool_body<false, true, NG>(CS_POOL_FWD); }
+__global__ void __launch_bounds__(512, 2) cs_pool_tuning_kernel(CS_POOL_PARAMS) { cs_pool_body<false, true>(CS_POOL_FWD); }
 #undef CS_POOL_PARAMS
 #undef CS_POOL_FWD
 
@@ -896,26 +849,25 @@ int cs_np2(int64_t n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
-// rows per block: 16 .. 152.  Up to 128 rows a block holds eight 16-row groups (cs_pool_kernel<.., 8>), beyond that ten (<.., 10>:
-// 156 KiB of LDS); a block of fewer rows than its groups hold leaves the last groups (partly) empty -- their weight fragments are
-// never fetched.  A launch of near-equal tiles on one workgroup per CU costs about ceil(tiles / CUs) rounds plus a drain of one
-// tile (round 4: 1.48 ns per row + 25 us per launch, profiles/r04_pool_size_sweep.log), and taller blocks have smaller unions per
-// row; gp_pool_cs_rows_per_block(nv) returns the height with the FEWEST rounds on the current device, rows spread evenly over
-// them: 133 933 rows on 256 CUs are 8.18 rounds of 128-row blocks, or 6.98 rounds of 150-row blocks.
-static bool cs_rpb_ok(int32_t rpb) { return rpb >= 16 && rpb <= CS_BR_MAX; }
-static int cs_groups(int32_t rpb) { return rpb > CS_BR ? 10 : 8; }
+// rows per block: 64 .. 128 (the kernels' blocks hold eight 16-row groups; a block of fewer rows leaves the last groups empty,
+// their weight fragments are never fetched).  gp_pool_cs_rows_per_block(nv) picks the height that spreads the rows evenly over
+// whole rounds of one workgroup per CU: a launch of near-equal tiles costs ceil(tiles / CUs) rounds, and e.g. 133 933 rows in
+// 128-row blocks are 2 094 tiles = 8.18 rounds = 9 rounds of full-height tiles; 117-row blocks are 2 290 tiles <= 9 x 256 of 9 %
+// less work each.
+static bool cs_rpb_ok(int32_t rpb) { return rpb >= 16 && rpb <= CS_BR; }
 
 extern "C" int32_t gp_pool_cs_rows_per_block(int64_t nv) {
     if (nv <= 0) return CS_BR;
     const int n_cu = gp_cu_count();
     if (n_cu <= 0) return CS_BR;
-    const int64_t per_round = n_cu / 2 > 0 ? n_cu / 2 : 1;                 // row blocks per round (a row block is two tiles)
-    const int64_t r128 = (nv + per_round * CS_BR - 1) / (per_round * CS_BR);
-    const int64_t rmax = (nv + per_round * CS_BR_MAX - 1) / (per_round * CS_BR_MAX);
-    if (rmax >= r128 || r128 <= 2) return CS_BR;                           // taller blocks save no round (or the scene is one or two rounds)
-    int64_t rpb = (nv + per_round * rmax - 1) / (per_round * rmax);       // rows spread evenly over rmax rounds
-    if (rpb <= CS_BR) return CS_BR;
-    return (int32_t)(rpb > CS_BR_MAX ? CS_BR_MAX : rpb);
+    const int64_t half = n_cu;                            // tiles per round = CUs (one workgroup per CU); a row block is 2 tiles
+    const int64_t tiles128 = 2 * ((nv + CS_BR - 1) / CS_BR);
+    const int64_t rounds = (tiles128 + half - 1) / half;
+    const int64_t blocks = rounds * half / 2;             // row blocks that fit the rounds
+    int64_t rpb = (nv + blocks - 1) / blocks;
+    if (rpb < 64) rpb = rpb < 16 ? CS_BR : 64;            // small scenes: a round is not even full, keep the tiles tall
+    if (rpb > CS_BR) rpb = CS_BR;
+    return (int32_t)rpb;
 }
 
 extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block) {
@@ -932,8 +884,8 @@ extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block)
 extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, int64_t *bu_off, int32_t *bu_n,
                                 void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(nbr && bu_off && bu_n && workspace && nv > 0 && k > 0, "gp_pool_cs_count: null/empty argument");
-    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_count: rows_per_block=%d (16..%d)", rows_per_block, CS_BR_MAX);
-    GP_CHECK_ARG((int64_t)rows_per_block * k <= CS_MAXNK && k <= 96, "gp_pool_cs_count: k=%d too large (rows_per_block*k <= %d, k <= 96)", k, CS_MAXNK);
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_count: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_count: k=%d too large (128*k <= %d)", k, CS_MAXNK);
     int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     GpCarver cv(workspace, workspace_bytes);
     int64_t *cnt = cv.take<int64_t>(nb + 1);
@@ -942,7 +894,7 @@ extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32
     if (!cv.ok()) { gp_set_error("gp_pool_cs_count: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(cnt + nb, 0, sizeof(int64_t), s));
-    size_t sm = (size_t)(CS_HS + cs_np2((int64_t)rows_per_block * k)) * sizeof(int);
+    size_t sm = (size_t)(CS_HS + cs_np2((int64_t)CS_BR * k)) * sizeof(int);
     GP_SMEM_ATTR(cs_count_kernel, (CS_HS + CS_MAXID) * sizeof(int));
     cs_count_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, rows_per_block, cnt, bu_n);
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, cnt, bu_off, (int64_t)0, (size_t)(nb + 1), rocprim::plus<int64_t>(), s));
@@ -950,20 +902,20 @@ extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32
     return GP_OK;
 }
 
-// pass 2: bu_row i32 [total], bu_mask u32 [total/32], wa_hi / wa_lo f16 [total/32 * ng * 512], ng = 8 groups per block for
-// rows_per_block <= 128, 10 beyond (only the fragments whose mask bit is set are defined -- and read)
+// pass 2: bu_row i32 [total], bu_mask u32 [total/32], wa_hi / wa_lo f16 [total/32 * 8 * 512] (only the fragments whose
+// mask bit is set are defined -- and read)
 extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
                                int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream_) {
     GP_CHECK_ARG(nbr && w && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
                  "gp_pool_cs_fill: bad argument");
-    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_fill: rows_per_block=%d (16..%d)", rows_per_block, CS_BR_MAX);
-    GP_CHECK_ARG((int64_t)rows_per_block * k <= CS_MAXNK && k <= 96, "gp_pool_cs_fill: k=%d too large (rows_per_block*k <= %d, k <= 96)", k, CS_MAXNK);
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_fill: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_fill: k=%d too large (128*k <= %d)", k, CS_MAXNK);
     int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
-    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)rows_per_block * k * sizeof(unsigned short);
+    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
     GP_SMEM_ATTR(cs_fill_kernel, sm_max);
-    cs_fill_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, cs_groups(rows_per_block), bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
+    cs_fill_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
                                                   static_cast<_Float16 *>(wa_lo));
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -982,8 +934,7 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
                     const float *out_scale, bool engine, void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0, "gp_pool_cs_apply: null/empty argument");
     GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply: d=%d (kernel specialised for %d columns)", d, CS_D);
-    GP_CHECK_ARG(cs_rpb_ok(rpb), "gp_pool_cs_apply: rows_per_block=%d (16..%d)", rpb, CS_BR_MAX);
-    GP_CHECK_ARG(!engine || rpb <= CS_BR, "gp_pool_cs_apply_engine: rows_per_block=%d (the engine holds eight groups: <= %d)", rpb, CS_BR);
+    GP_CHECK_ARG(cs_rpb_ok(rpb), "gp_pool_cs_apply: rows_per_block=%d (16..%d)", rpb, CS_BR);
     GP_CHECK_ARG((y_hi && y_lo) || y_f32, "gp_pool_cs_apply: no output requested");
     GP_CHECK_ARG(ld_x % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0, "gp_pool_cs_apply: x rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (ld_y % 8 == 0 && (uintptr_t)y_hi % 16 == 0 && (uintptr_t)y_lo % 16 == 0 && y_hi != x_hi && y_lo != x_lo),
@@ -1024,21 +975,16 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
 #define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
                 static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp, rpb, block_order
-#define CS_LAUNCH(NGV)                                                                                                                 \
-    do {                                                                                                                               \
-        if (stamp) {                                                                                                                   \
-            GP_SMEM_ATTR((cs_pool_kernel<true, NGV>), CsGeo<NGV>::SMEM);                                                               \
-            cs_pool_kernel<true, NGV><<<(unsigned)(per_xcd * 8), 512, CsGeo<NGV>::SMEM, s>>>(CS_ARGS);                                 \
-        } else if (tune != 0) {                                                                                                        \
-            GP_SMEM_ATTR(cs_pool_tuning_kernel<NGV>, CsGeo<NGV>::SMEM);                                                                \
-            cs_pool_tuning_kernel<NGV><<<(unsigned)(per_xcd * 8), 512, CsGeo<NGV>::SMEM, s>>>(CS_ARGS);                                \
-        } else {                                                                                                                       \
-            GP_SMEM_ATTR((cs_pool_kernel<false, NGV>), CsGeo<NGV>::SMEM);                                                              \
-            cs_pool_kernel<false, NGV><<<(unsigned)(per_xcd * 8), 512, CsGeo<NGV>::SMEM, s>>>(CS_ARGS);                                \
-        }                                                                                                                              \
-    } while (0)
-    if (cs_groups(rpb) == 10) CS_LAUNCH(10); else CS_LAUNCH(8);
-#undef CS_LAUNCH
+    if (stamp) {
+        GP_SMEM_ATTR(cs_pool_kernel<true>, CS_SMEM);
+        cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    } else if (tune != 0) {
+        GP_SMEM_ATTR(cs_pool_tuning_kernel, CS_SMEM);
+        cs_pool_tuning_kernel<<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    } else {
+        GP_SMEM_ATTR(cs_pool_kernel<false>, CS_SMEM);
+        cs_pool_kernel<false><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
+    }
 #undef CS_ARGS
     GP_CHECK_LAUNCH();
     return GP_OK;

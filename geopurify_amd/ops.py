@@ -458,12 +458,12 @@ def pool_cs_plan(nbr, rows_per_block=None):
     """First half of the operator build: needs the neighbour lists only (not the weights), so a scheduler can run it -- and its
     one host sync (total padded union rows, to size the arrays) -- before the affinity weights exist.  Returns a PoolCs without
     weights; pool_cs_fill completes it.
-    rows_per_block: 16..152; None = gp_pool_cs_rows_per_block(nv): 128, or a taller block (129..152: ten 16-row groups per block)
-    where that saves a whole round of tiles on the current device."""
+    rows_per_block: None = 128 (gp_pool_cs_rows_per_block(nv) spreads the rows over whole rounds of one workgroup per CU; on the S
+    scene every height from 112 to 128 measures the same 0.223 ms per application, profiles/r04_pool_block_height.log)."""
     lib = _lib.load()
     nv, k = nbr.shape
     dev = nbr.device
-    rpb = int(lib.gp_pool_cs_rows_per_block(nv)) if rows_per_block is None else int(rows_per_block)
+    rpb = 128 if rows_per_block is None else int(rows_per_block)
     nb = (nv + rpb - 1) // rpb
     ws = _ws(lib.gp_pool_cs_workspace_bytes(nv, rpb), dev)
     bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
@@ -473,8 +473,7 @@ def pool_cs_plan(nbr, rows_per_block=None):
     total = int(bu_off[nb].item())                                                            # the one host sync
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
-    ng = 10 if rpb > 128 else 8                                                               # 16-row groups a block holds
-    wa_hi = torch.empty(total // 32 * ng * 512, dtype=torch.float16, device=dev)
+    wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
     return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb, order=None)
 

@@ -506,9 +506,7 @@ class HotPath:
         mode = self._pool_mode(D)
         if mode in ("mfma_cs", "mfma_engine"):
             sc = ops.pow2_scale(X, D)
-            # (the engine holds eight groups per block: 128 rows; the default kernel takes the device's best block height)
-            state["pool"] = {"op": ops.pool_cs_plan(nbr, 128 if mode == "mfma_engine" else None), "sc": sc,
-                             "x_split": ops.split_f16(X, D, scale=sc[0:1]),
+            state["pool"] = {"op": ops.pool_cs_plan(nbr), "sc": sc, "x_split": ops.split_f16(X, D, scale=sc[0:1]),
                              "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
             mark("pool plan+split")
         return state
@@ -569,8 +567,7 @@ class HotPath:
             # form of the same operator (persistent, 128-column tiles) -- same bits, same speed on MI355X.
             if plan is None:                            # (isolated calls: bench.py's pooling-only passes, tests)
                 sc = ops.pow2_scale(X, D)
-                plan = {"op": ops.pool_cs_plan(nbr, 128 if mode == "mfma_engine" else None), "sc": sc,
-                        "x_split": ops.split_f16(X, D, scale=sc[0:1]),
+                plan = {"op": ops.pool_cs_plan(nbr), "sc": sc, "x_split": ops.split_f16(X, D, scale=sc[0:1]),
                         "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
             op = ops.pool_cs_fill(plan["op"], nbr, w)
             out = torch.empty((Nv, D), dtype=torch.float32, device=dev)

@@ -234,17 +234,15 @@ int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo, int64_t ld
                                   int64_t ld_y, float *y_f32, int64_t ld_yf, int64_t y_rows,
                                   const float *out_scale, uint32_t *queue, void *stream);
 
-/* Column-sliced matrix-core variant (d = 512; the default from round 3 on): blocks of rows x 256-column halves, every     */
-/* wave owns all rows x 32 columns; the builder orders a block's union rows by the 16-row groups that use them and         */
+/* Column-sliced matrix-core variant (d = 512; the default from round 3 on): blocks of up to 128 rows x 256-column halves,  */
+/* every wave owns all rows x 32 columns; the builder orders a block's union rows by the 16-row groups that use them and   */
 /* stores one bit per (32-row step, group): all-zero 16 x 32 weight fragments are neither fetched nor multiplied.        */
-/* rows_per_block (16..152; the same value for count, fill and apply): the block height.  ng = groups a block holds: 8 up   */
-/* to 128 rows, 10 beyond (a second instantiation of the kernel, 156 KiB of LDS).  A launch of one workgroup per CU costs    */
-/* about ceil(tiles / CUs) rounds, and taller blocks have smaller unions per row: gp_pool_cs_rows_per_block(nv) returns 128,  */
-/* or the height in 129..152 that saves a whole round on the current device with the rows spread evenly over the rounds      */
-/* (133 933 rows on 256 CUs: 150 -- 6.98 rounds instead of 8.18).  The engine (gp_pool_cs_apply_engine) takes <= 128.        */
+/* rows_per_block (16..128; the same value for count, fill and apply): the block height.  A launch of one workgroup per CU  */
+/* costs whole rounds of tiles, so gp_pool_cs_rows_per_block(nv) returns the height that spreads the rows evenly over the   */
+/* rounds the scene needs on the current device (133 933 rows: 117 instead of 128 -- 9 full rounds of 9 % lighter tiles).   */
 /* nblocks = ceil(nv / rows_per_block).  bu_off i64 [nblocks+1] (padded union rows, multiples of 32), bu_n i32 [nblocks],   */
 /* bu_row i32 [total], bu_mask u32 [total/32] (bit g: group g of the step has a non-zero), wa_hi/wa_lo f16               */
-/* [total/32 * ng * 512] (weights x 2^10 in MFMA fragment order; only fragments whose bit is set are defined and read).  */
+/* [total/32 * 8 * 512] (weights x 2^10 in MFMA fragment order; only fragments whose bit is set are defined and read).   */
 /* Same numerics and operand conventions as gp_pool_mfma_apply.  Replaces the 19 torch.sparse.mm calls of                */
 /* models/affinity_module.py:1575-1589.                                                                                  */
 int32_t gp_pool_cs_rows_per_block(int64_t nv);

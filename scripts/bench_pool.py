@@ -92,8 +92,8 @@ for R in (8,):
     print(f"tiles R={R}: build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
-cs = ops.pool_cs_build(nbr, w, rows_per_block=128); torch.cuda.synchronize()   # 128: the engine variants share it
-t0 = time.time(); cs = ops.pool_cs_build(nbr, w, rows_per_block=128); torch.cuda.synchronize()
+cs = ops.pool_cs_build(nbr, w); torch.cuda.synchronize()
+t0 = time.time(); cs = ops.pool_cs_build(nbr, w); torch.cuda.synchronize()
 _bm = cs.bu_mask.cpu().numpy().astype(np.int64) & 0xFF
 print(f"cs BR=128: union rows/row (padded) {cs.total / Nv:.2f}  non-empty fragments {np.unpackbits(_bm.astype(np.uint8)[:, None], axis=1).mean():.3f}"
       f"  build (2nd call) {1e3 * (time.time() - t0):.2f} ms", flush=True)

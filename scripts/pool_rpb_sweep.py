@@ -29,8 +29,8 @@ for seed in (5557, 6557):
     auto = int(lib.gp_pool_cs_rows_per_block(Nv))
     print(f"seed {seed}: Nv {Nv}; gp_pool_cs_rows_per_block -> {auto}", flush=True)
     ref = None
-    for rpb in sorted({128, auto, 152, 150, 144, 136, 131, 120, 112}, reverse=True):
-        for lf in (False,):
+    for rpb in sorted({128, auto, 124, 120, 112, 104, 96}, reverse=True):
+        for lf in (False, True):
             op = ops.pool_cs_build(nbr, w, rows_per_block=rpb, longest_first=lf)
             steps = ((op.bu_off[1:] - op.bu_off[:-1]) // 32).float()
             sp = [ops.split_f16(X, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))]

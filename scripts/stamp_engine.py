@@ -22,7 +22,7 @@ Nv = cs.shape[0]
 w = ops.affinity_softmax(torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1), nbr, 20.0)
 X = torch.randn(Nv, 544, device="cuda")
 lib = _lib.load()
-op = ops.pool_cs_build(nbr, w, rows_per_block=128)                # (the engine holds eight groups per block)
+op = ops.pool_cs_build(nbr, w)
 xs = ops.split_f16(X, D)
 ys = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
 buf = torch.zeros(256 * 4 * 10, dtype=torch.int64, device="cuda")

@@ -89,10 +89,7 @@ def test_pooling_properties_full_size(big):
     Nv, D = nbr.shape[0], 512
     tiles = ops.pool_tiles_build(nbr, w, 8)
     mfma = {br: ops.pool_mfma_build(nbr, w, br, min_steps=9 if br == 64 else 0) for br in (64, 128)}   # (64: the persistent kernel's operator)
-    cs_op = ops.pool_cs_build(nbr, w)                       # the DEFAULT kernel's operator: block height by gp_pool_cs_rows_per_block
-    cs128 = ops.pool_cs_build(nbr, w, rows_per_block=128)   # eight groups per block: what cs_engine_kernel takes
-    cs150 = ops.pool_cs_build(nbr, w, rows_per_block=150)   # ten groups per block (cs_pool_kernel<.., 10>)
-    assert cs_op.block_rows == int(ops._lib.load().gp_pool_cs_rows_per_block(Nv)) and 128 <= cs_op.block_rows <= 152
+    cs_op = ops.pool_cs_build(nbr, w)                       # the DEFAULT kernel's operator (cs_pool_kernel / cs_engine_kernel)
     X = torch.randn(Nv, 544, device="cuda")
     Y = torch.randn(Nv, 544, device="cuda")
 
@@ -102,9 +99,8 @@ def test_pooling_properties_full_size(big):
             ops.pool_ell(z, nbr, w, D, out)
         elif mode == "tiles":
             ops.pool_tiles_apply(z, tiles, D, out)
-        elif mode in ("cs", "cs128", "cs150", "engine"):    # the benchmarked default, both block heights, the producer / consumer form
-            o_ = {"cs": cs_op, "cs128": cs128, "cs150": cs150, "engine": cs128}[mode]
-            ops.pool_cs_apply(ops.split_f16(z, D), o_, D, out_f32=out, engine=mode == "engine")
+        elif mode in ("cs", "engine"):                      # the benchmarked default and its producer / consumer form
+            ops.pool_cs_apply(ops.split_f16(z, D), cs_op, D, out_f32=out, engine=mode == "engine")
         elif isinstance(mode, str):                         # "p64": the persistent kernel (outputs padded to row blocks)
             op = mfma[int(mode[1:])]
             assert op.min_steps >= 9                        # the builder pads every row block to >= 9 steps
@@ -116,14 +112,14 @@ def test_pooling_properties_full_size(big):
             ops.pool_mfma_apply(ops.split_f16(z, D), mfma[mode], D, out_f32=out)
         return out
     ones = torch.ones(Nv, 544, device="cuda")
-    for mode in ("ell", "tiles", 64, 128, "p64", "cs", "cs128", "cs150", "engine"):
+    for mode in ("ell", "tiles", 64, 128, "p64", "cs", "engine"):
         assert (P(ones, mode) - 1).abs().max() < 1e-5                                # A 1 = 1
         lin = P((2.0 * X - 0.5 * Y).contiguous(), mode) - (2.0 * P(X, mode) - 0.5 * P(Y, mode))
         assert lin.abs().max() < 1e-4                                                 # linearity
         px = P(X, mode)
         assert (px.amax(0) <= X[:, :D].amax(0) + 1e-5).all() and (px.amin(0) >= X[:, :D].amin(0) - 1e-5).all()   # convexity
     ref = P(X, "ell")
-    for mode in ("tiles", 64, 128, "p64", "cs", "cs128", "cs150", "engine"):
+    for mode in ("tiles", 64, 128, "p64", "cs", "engine"):
         assert (P(X, mode) - ref).abs().max() < 1e-5                                  # independent kernels agree
     # the default kernel at full size: chained split hand-off == ELL twice, the engine gives the
     # default kernel's bits, and five launches over NaN-filled outputs reproduce them bit for bit
@@ -131,20 +127,20 @@ def test_pooling_properties_full_size(big):
     ref2 = torch.empty(Nv, D, device="cuda")
     ops.pool_ell(ref, nbr, w, D, ref2)
     first = {}
-    for name, o_, engine in (("cs128", cs128, False), ("engine", cs128, True), ("cs150", cs150, False), ("cs", cs_op, False)):
+    for engine in (False, True):
         mid = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
         out2 = torch.empty(Nv, D, device="cuda")
-        ops.pool_cs_apply(xs, o_, D, out_split=mid, engine=engine)
-        ops.pool_cs_apply(mid, o_, D, out_f32=out2, engine=engine)
+        ops.pool_cs_apply(xs, cs_op, D, out_split=mid, engine=engine)
+        ops.pool_cs_apply(mid, cs_op, D, out_f32=out2, engine=engine)
         assert (out2 - ref2).abs().max() < 2e-5
-        first[name] = (mid, out2)
+        first[engine] = (mid, out2)
         for _ in range(5):
             m2 = tuple(torch.full((Nv, D), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
             o2 = torch.full((Nv, D), float("nan"), device="cuda")
-            ops.pool_cs_apply(xs, o_, D, out_split=m2, engine=engine)
-            ops.pool_cs_apply(m2, o_, D, out_f32=o2, engine=engine)
+            ops.pool_cs_apply(xs, cs_op, D, out_split=m2, engine=engine)
+            ops.pool_cs_apply(m2, cs_op, D, out_f32=o2, engine=engine)
             assert torch.equal(m2[0], mid[0]) and torch.equal(m2[1], mid[1]) and torch.equal(o2, out2)
-    assert torch.equal(first["cs128"][1], first["engine"][1]) and torch.equal(first["cs128"][0][0], first["engine"][0][0])
+    assert torch.equal(first[False][1], first[True][1]) and torch.equal(first[False][0][0], first[True][0][0])
     # the persistent kernel's split (hi, lo) output feeds its next application: two chained == ELL twice
     for br in (64,):
         op = mfma[br]

@@ -588,12 +588,10 @@ def test_pooling_tuning_masks_keep_the_ring_discipline(ops):
     w = ops.affinity_softmax(torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1), nbr, 20.0)
     X = torch.randn(Nv, 512, device="cuda")
     xs = ops.split_f16(X, 512)
-    op_cs = ops.pool_cs_build(nbr, w, rows_per_block=128)
-    op_cs10 = ops.pool_cs_build(nbr, w, rows_per_block=150)               # ten groups per block: two waves stage 8 DMA per step
+    op_cs = ops.pool_cs_build(nbr, w)
     op64, op128 = ops.pool_mfma_build(nbr, w, 64), ops.pool_mfma_build(nbr, w, 128)
     new = lambda: tuple(torch.empty((Nv, 512), dtype=torch.float16, device="cuda") for _ in range(2))
     runs = {"cs": lambda y: ops.pool_cs_apply(xs, op_cs, 512, out_split=y),
-            "cs10": lambda y: ops.pool_cs_apply(xs, op_cs10, 512, out_split=y),
             "engine": lambda y: ops.pool_cs_apply(xs, op_cs, 512, out_split=y, engine=True),
             "mfma64": lambda y: ops.pool_mfma_apply(xs, op64, 512, out_split=y),
             "mfma128": lambda y: ops.pool_mfma_apply(xs, op128, 512, out_split=y)}
@@ -799,14 +797,12 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     """Dense [128, padded union] weight block of row block b rebuilt from the fragment arrays (non-empty fragments only) and
     from the ELL lists; also checks the union rows and the (step, group) masks."""
     bo, bn, br, bm = (t.cpu().numpy() for t in (op.bu_off, op.bu_n, op.bu_row, op.bu_mask))
-    rpb = op.block_rows
-    ng = 10 if rpb > 128 else 8                                        # groups a block holds (blocks beyond 128 rows: ten)
-    wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, ng, 64, 8) / 1024.0
-    rows = np.arange(b * rpb, min(b * rpb + rpb, Nv))
+    wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, 8, 64, 8) / 1024.0
+    rows = np.arange(b * 128, min(b * 128 + 128, Nv))
     u = br[bo[b]:bo[b] + bn[b]]
     assert len(set(u)) == len(u) and set(u) == set(nbc[rows].reshape(-1))
     assert (br[bo[b] + bn[b]:bo[b + 1]] == u[0]).all()
-    dense = np.zeros((ng * 16, bo[b + 1] - bo[b]), np.float64)
+    dense = np.zeros((128, bo[b + 1] - bo[b]), np.float64)
     pos = {v: i for i, v in enumerate(u)}
     for r_i, row in enumerate(rows):
         for j in range(K):
@@ -815,8 +811,7 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     got = np.zeros_like(dense)
     for s_ in range(steps):
         m = int(bm[bo[b] // 32 + s_]) & 0xFFFFFFFF
-        assert m >> ng == 0
-        for gq in range(ng):
+        for gq in range(8):
             nz = np.abs(dense[gq * 16:gq * 16 + 16, s_ * 32:s_ * 32 + 32]).max() > 0
             assert bool((m >> gq) & 1) == bool(nz), (b, s_, gq, m)
             if not nz:
@@ -825,19 +820,18 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
                 got[gq * 16 + lane % 16, s_ * 32 + (lane // 16) * 8:s_ * 32 + (lane // 16) * 8 + 8] = wa[bo[b] // 32 + s_, gq, lane]
     assert np.abs(got - dense).max() < 1e-7
     # order of the union rows: (first group, last group, group set, id) ascending
-    use = (dense[:, :len(u)] != 0).reshape(ng, 16, -1).any(1)          # [group, union row]
+    use = (dense[:, :len(u)] != 0).reshape(8, 16, -1).any(1)           # [group, union row]
     keys = []
     for i in range(len(u)):
         gs = np.flatnonzero(use[:, i])
-        keys.append((gs[0], gs[-1], int((use[:, i] * (1 << np.arange(ng))).sum()), u[i]))
+        keys.append((gs[0], gs[-1], int((use[:, i] * (1 << np.arange(8))).sum()), u[i]))
     assert keys == sorted(keys)
 
 
-@pytest.mark.parametrize("n_vox,rpb", [(2500, 128), (2531, 128), (2531, 100), (2531, 150), (2500, 152), (2531, 129)])
-def test_pool_cs_matches_ell_and_oracle(ops, n_vox, rpb):
-    """Column-sliced matrix-core pooling (blocks of `rpb` rows -- eight 16-row groups up to 128 rows, ten beyond --, union rows
-    grouped by the groups that use them, empty weight fragments skipped) against the ELL gather and the oracle
-    (models/affinity_module.py:1575-1587)."""
+@pytest.mark.parametrize("n_vox", [2500, 2531])
+def test_pool_cs_matches_ell_and_oracle(ops, n_vox):
+    """Column-sliced matrix-core pooling (128-row blocks, union rows grouped by the 16-row groups that use them, empty
+    weight fragments skipped) against the ELL gather and the oracle (models/affinity_module.py:1575-1587)."""
     rng = np.random.default_rng(14)
     c = surface_voxels(rng, n_vox)
     ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
@@ -845,17 +839,15 @@ def test_pool_cs_matches_ell_and_oracle(ops, n_vox, rpb):
     nbr = ops.knn_lattice(grid, cs, perm, K)
     E = F.normalize(torch.randn(Nv, 128), dim=1)
     w = ops.affinity_softmax(dev(E), nbr, 20.0)
-    op = ops.pool_cs_build(nbr, w, rows_per_block=rpb)
-    assert op.block_rows == rpb
+    op = ops.pool_cs_build(nbr, w)
     nbc, wc = nbr.cpu().numpy(), w.cpu().numpy()
     bo = op.bu_off.cpu().numpy()
-    assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0 and (np.diff(bo) >= 32).all() and len(bo) - 1 == -(-len(c) // rpb)
+    assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0 and (np.diff(bo) >= 32).all()
     nb = len(bo) - 1
     for b in (0, nb // 2, nb - 1):
         _cs_dense_block(op, b, K, nbc, wc, Nv)
-    ng = 10 if rpb > 128 else 8
-    bm = op.bu_mask.cpu().numpy().astype(np.int64) & ((1 << ng) - 1)
-    fill = np.mean([bin(int(v)).count("1") for v in bm]) / ng
+    bm = op.bu_mask.cpu().numpy().astype(np.int64) & 0xFF
+    fill = np.unpackbits(bm.astype(np.uint8)[:, None], axis=1).mean()
     assert 0.2 < fill < 0.9, fill                                      # the grouping leaves a good part of the fragments empty
     X = torch.randn(Nv, 544)
     Xd = dev(X)
