@@ -274,31 +274,22 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
                const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
                _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
-               int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb,
-               const int32_t *__restrict__ order) {
+               int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
     if constexpr (STAMP) { st_t0 = cs_now(); st_r0 = cs_real(); }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int64_t b;
-    int col0;
-    if (order) {
-        // longest-first order (`order` = row blocks by descending step count): the blocks are dealt round-robin over the XCDs
-        // (block index & 7 = XCD under the observed round-robin placement), the two column halves of a row block back to back on
-        // one XCD (they share the weight fragments in its L2).  A launch of equal tiles on one workgroup per CU costs whole
-        // rounds; with the long tiles first the short ones fill the last round.
-        const int64_t j = blockIdx.x >> 3, slot = (j >> 1) * 8 + (blockIdx.x & 7);
-        if (slot >= nblocks) return;
-        b = order[slot];
-        col0 = (int)(j & 1) * CS_NC;
-    } else {
-        const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);    // XCD-contiguous order
-        b = lb >> 1;
-        col0 = (int)(lb & 1) * CS_NC;
-        if (b >= nblocks) return;
-    }
+    // XCD-contiguous order: blocks b, b + 8, ... share an XCD (observed round-robin placement); each XCD walks a contiguous range of
+    // tiles, the two column halves of a row block back to back (they share the weight fragments in its L2) and Morton-adjacent row
+    // blocks side by side (their halo rows meet in its L2).  Measured and left out (round 4, profiles/r04_pool_block_height.log):
+    // starting the row blocks longest-first, dealt round-robin over the XCDs, 0.279 instead of 0.223 ms per application -- the
+    // drain of the last round is worth less than the L2 sharing between neighbouring tiles.
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t b = lb >> 1;
+    const int col0 = (int)(lb & 1) * CS_NC;
+    if (b >= nblocks) return;
     const int64_t ub0 = bu_off[b];
     const int n = (int)((bu_off[b + 1] - ub0) / CS_KS);                            // steps (>= 1)
     const int64_t ks0 = ub0 / CS_KS;
@@ -535,8 +526,8 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                        const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask, const _Float16 *__restrict__ wa_hi,                    \
                        const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks, _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo,       \
                        int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf, int64_t per_xcd, int ablate, const float *__restrict__ out_scale,       \
-                       uint64_t *__restrict__ stamp, int rpb, const int32_t *__restrict__ order
-#define CS_POOL_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp, rpb, order
+                       uint64_t *__restrict__ stamp, int rpb
+#define CS_POOL_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp, rpb
 // the product kernel (STAMP = false: no tuning bits, no stamps) and its stamped instantiation
 template <bool STAMP>
 __global__ void __launch_bounds__(512, 2) cs_pool_kernel(CS_POOL_PARAMS) { cs_pool_body<STAMP, STAMP>(CS_POOL_FWD); }
@@ -849,26 +840,11 @@ int cs_np2(int64_t n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
-// rows per block: 64 .. 128 (the kernels' blocks hold eight 16-row groups; a block of fewer rows leaves the last groups empty,
-// their weight fragments are never fetched).  gp_pool_cs_rows_per_block(nv) picks the height that spreads the rows evenly over
-// whole rounds of one workgroup per CU: a launch of near-equal tiles costs ceil(tiles / CUs) rounds, and e.g. 133 933 rows in
-// 128-row blocks are 2 094 tiles = 8.18 rounds = 9 rounds of full-height tiles; 117-row blocks are 2 290 tiles <= 9 x 256 of 9 %
-// less work each.
+// rows per block: 16 .. 128 (the kernels' blocks hold eight 16-row groups; a block of fewer rows leaves the last groups partly
+// empty, their weight fragments are never fetched).  128 is the default and the fastest: round 4 measured every height from 96
+// to 128 -- and, with a ten-group instantiation of the kernel, from 131 to 152 -- within 4 % of each other on the S scene
+// (profiles/r04_pool_block_height.log: 6.9 to 10.9 "rounds" of tiles, 0.222 - 0.232 ms): the launch is not bound by whole rounds.
 static bool cs_rpb_ok(int32_t rpb) { return rpb >= 16 && rpb <= CS_BR; }
-
-extern "C" int32_t gp_pool_cs_rows_per_block(int64_t nv) {
-    if (nv <= 0) return CS_BR;
-    const int n_cu = gp_cu_count();
-    if (n_cu <= 0) return CS_BR;
-    const int64_t half = n_cu;                            // tiles per round = CUs (one workgroup per CU); a row block is 2 tiles
-    const int64_t tiles128 = 2 * ((nv + CS_BR - 1) / CS_BR);
-    const int64_t rounds = (tiles128 + half - 1) / half;
-    const int64_t blocks = rounds * half / 2;             // row blocks that fit the rounds
-    int64_t rpb = (nv + blocks - 1) / blocks;
-    if (rpb < 64) rpb = rpb < 16 ? CS_BR : 64;            // small scenes: a round is not even full, keep the tiles tall
-    if (rpb > CS_BR) rpb = CS_BR;
-    return (int32_t)rpb;
-}
 
 extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block) {
     if (nv <= 0 || !cs_rpb_ok(rows_per_block)) return 0;
@@ -925,12 +901,10 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
 // engine = false: cs_pool_kernel (one tile per workgroup, the default); engine = true: cs_engine_kernel (persistent producer /
 // consumer form, one workgroup per CU).  The choice is an ARGUMENT of the call (round 3 selected the engine through the
 // process-global debug knob 11: a raised error left every later launch on the engine, and two host threads raced on it).
-// rows_per_block: the builder's (gp_pool_cs_count / _fill).  block_order (nullable, i32 [nblocks], a permutation of the row
-// blocks, device memory): the order in which the one-tile-per-workgroup kernel starts the row blocks -- by descending step
-// count (bu_off differences) the long tiles run first; NULL = memory order, XCD-contiguous.  The engine ignores it.
+// rows_per_block: the builder's (gp_pool_cs_count / _fill).
 static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                     const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, int32_t rpb,
-                    const int32_t *block_order, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
+                    void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
                     const float *out_scale, bool engine, void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0, "gp_pool_cs_apply: null/empty argument");
     GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply: d=%d (kernel specialised for %d columns)", d, CS_D);
@@ -942,7 +916,7 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
     GP_CHECK_ARG(!y_f32 || (ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0), "gp_pool_cs_apply: fp32 output rows must be 16-byte aligned");
     hipStream_t s = gp_stream(stream_);
     const int64_t nb = (nv + rpb - 1) / rpb;
-    const int64_t per_xcd = block_order && !engine ? 2 * ((nb + 7) / 8) : (nb * (CS_D / CS_NC) + 7) / 8;
+    const int64_t per_xcd = (nb * (CS_D / CS_NC) + 7) / 8;
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
     const int tune = g_gp_knobs[4];                       // tuning bits: only ever handed to the *_tuning_kernel twins
     if (engine) {
@@ -974,7 +948,7 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
                  g_gp_debug_bytes[0], (size_t)(per_xcd * 8) * CS_NW * 10 * sizeof(uint64_t));
 #define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
-                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp, rpb, block_order
+                static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp, rpb
     if (stamp) {
         GP_SMEM_ATTR(cs_pool_kernel<true>, CS_SMEM);
         cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
@@ -992,9 +966,9 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
 
 extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                                 const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
-                                int32_t rows_per_block, const int32_t *block_order, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
+                                int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
                                 int64_t ld_yf, const float *out_scale, void *stream_) {
-    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, block_order, y_hi, y_lo, ld_y, y_f32,
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, y_hi, y_lo, ld_y, y_f32,
                     ld_yf, out_scale, false, stream_);
 }
 
@@ -1003,6 +977,6 @@ extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64
                                        const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                                        int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
                                        const float *out_scale, void *stream_) {
-    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, nullptr, y_hi, y_lo, ld_y, y_f32, ld_yf,
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, y_hi, y_lo, ld_y, y_f32, ld_yf,
                     out_scale, true, stream_);
 }

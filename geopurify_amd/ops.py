@@ -447,23 +447,21 @@ def pool_mfma_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None
 class PoolCs:
     """Column-sliced matrix-core pooling operator (gp_pool_cs_*): blocks of up to 128 rows, fragment masks."""
 
-    def __init__(self, bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=128, order=None):
+    def __init__(self, bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=128):
         self.bu_off, self.bu_n, self.bu_row, self.bu_mask = bu_off, bu_n, bu_row, bu_mask
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
         self.block_rows = block_rows
-        self.order = order                              # i32 [nblocks]: row blocks by descending step count, or None
 
 
-def pool_cs_plan(nbr, rows_per_block=None):
+def pool_cs_plan(nbr, rows_per_block=128):
     """First half of the operator build: needs the neighbour lists only (not the weights), so a scheduler can run it -- and its
     one host sync (total padded union rows, to size the arrays) -- before the affinity weights exist.  Returns a PoolCs without
-    weights; pool_cs_fill completes it.
-    rows_per_block: None = 128 (gp_pool_cs_rows_per_block(nv) spreads the rows over whole rounds of one workgroup per CU; on the S
-    scene every height from 112 to 128 measures the same 0.223 ms per application, profiles/r04_pool_block_height.log)."""
+    weights; pool_cs_fill completes it.  rows_per_block: 16..128 (every height from 96 up measures within 4 % on the S scene,
+    profiles/r04_pool_block_height.log; 128 is the default)."""
     lib = _lib.load()
     nv, k = nbr.shape
     dev = nbr.device
-    rpb = 128 if rows_per_block is None else int(rows_per_block)
+    rpb = int(rows_per_block)
     nb = (nv + rpb - 1) // rpb
     ws = _ws(lib.gp_pool_cs_workspace_bytes(nv, rpb), dev)
     bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
@@ -475,27 +473,21 @@ def pool_cs_plan(nbr, rows_per_block=None):
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
-    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb, order=None)
+    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb)
 
 
-def pool_cs_fill(op, nbr, w, longest_first=False):
-    """Second half: union rows, fragment masks and the weights in fragment order (no host sync).
-    longest_first: also build a launch order of the row blocks by descending step count (measured SLOWER, 0.279 against 0.223 ms
-    per application: dealing the sorted blocks over the XCDs takes the halo rows of neighbouring blocks out of each other's L2;
-    kept as an option of the ABI, off by default)."""
+def pool_cs_fill(op, nbr, w):
+    """Second half: union rows, fragment masks and the weights in fragment order (no host sync)."""
     lib = _lib.load()
     nv, k = nbr.shape
     check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), int(op.block_rows), _ptr(op.bu_off), op.total, _ptr(op.bu_row),
                               _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo), _stream()), "gp_pool_cs_fill")
-    op.order = None
-    if longest_first:
-        op.order = torch.sort(op.bu_off[1:] - op.bu_off[:-1], descending=True, stable=True).indices.to(torch.int32).contiguous()
     return op
 
 
-def pool_cs_build(nbr, w, rows_per_block=None, longest_first=False):
+def pool_cs_build(nbr, w, rows_per_block=128):
     """pool_cs_plan + pool_cs_fill."""
-    return pool_cs_fill(pool_cs_plan(nbr, rows_per_block), nbr, w, longest_first)
+    return pool_cs_fill(pool_cs_plan(nbr, rows_per_block), nbr, w)
 
 
 def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, engine=False):
@@ -506,14 +498,10 @@ def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, 
     xh, xl = x_split
     assert xh.stride(0) == xl.stride(0)
     yh, yl = out_split if out_split is not None else (None, None)
-    head = (_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo),
-            op.nv, int(d), int(op.block_rows))
-    tail = (_ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0, _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
-            _ptr(out_scale), _stream())
-    if engine:
-        check(lib.gp_pool_cs_apply_engine(*head, *tail), "gp_pool_cs_apply_engine")
-    else:
-        check(lib.gp_pool_cs_apply(*head, _ptr(op.order), *tail), "gp_pool_cs_apply")
+    fn, name = (lib.gp_pool_cs_apply_engine, "gp_pool_cs_apply_engine") if engine else (lib.gp_pool_cs_apply, "gp_pool_cs_apply")
+    check(fn(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo),
+             op.nv, int(d), int(op.block_rows), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
+             _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()), name)
     return out_f32 if out_f32 is not None else out_split
 
 

@@ -234,30 +234,25 @@ int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo, int64_t ld
                                   int64_t ld_y, float *y_f32, int64_t ld_yf, int64_t y_rows,
                                   const float *out_scale, uint32_t *queue, void *stream);
 
-/* Column-sliced matrix-core variant (d = 512; the default from round 3 on): blocks of up to 128 rows x 256-column halves,  */
-/* every wave owns all rows x 32 columns; the builder orders a block's union rows by the 16-row groups that use them and   */
+/* Column-sliced matrix-core variant (d = 512; the default from round 3 on): blocks of rows x 256-column halves, every     */
+/* wave owns all rows x 32 columns; the builder orders a block's union rows by the 16-row groups that use them and         */
 /* stores one bit per (32-row step, group): all-zero 16 x 32 weight fragments are neither fetched nor multiplied.        */
-/* rows_per_block (16..128; the same value for count, fill and apply): the block height.  A launch of one workgroup per CU  */
-/* costs whole rounds of tiles, so gp_pool_cs_rows_per_block(nv) returns the height that spreads the rows evenly over the   */
-/* rounds the scene needs on the current device (133 933 rows: 117 instead of 128 -- 9 full rounds of 9 % lighter tiles).   */
+/* rows_per_block (16..128, the same value for count, fill and apply; 128 unless there is a reason): the block height.    */
 /* nblocks = ceil(nv / rows_per_block).  bu_off i64 [nblocks+1] (padded union rows, multiples of 32), bu_n i32 [nblocks],   */
 /* bu_row i32 [total], bu_mask u32 [total/32] (bit g: group g of the step has a non-zero), wa_hi/wa_lo f16               */
 /* [total/32 * 8 * 512] (weights x 2^10 in MFMA fragment order; only fragments whose bit is set are defined and read).   */
 /* Same numerics and operand conventions as gp_pool_mfma_apply.  Replaces the 19 torch.sparse.mm calls of                */
-/* models/affinity_module.py:1575-1589.                                                                                  */
-int32_t gp_pool_cs_rows_per_block(int64_t nv);
+/* models/affinity_module.py:1575-1589.  gp_pool_cs_count needs the neighbour lists only: a scheduler can run it (and the  */
+/* host read-back of bu_off[nblocks] that sizes the arrays) before the affinity weights exist.                            */
 size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block);
 int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, int64_t *bu_off, int32_t *bu_n,
                      void *workspace, size_t workspace_bytes, void *stream);
 int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
                     int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream);
-/* block_order (nullable; i32 [nblocks] in device memory, a permutation of the row blocks): the order in which the           */
-/* one-tile-per-workgroup kernel starts the row blocks.  By descending step count ((bu_off[b+1] - bu_off[b]) / 32) the long   */
-/* tiles run first and the short ones fill the last round; NULL = memory order.  Results do not depend on it.              */
 int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                      const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
-                     int32_t rows_per_block, const int32_t *block_order, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
-                     int64_t ld_yf, const float *out_scale, void *stream);
+                     int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
+                     const float *out_scale, void *stream);
 /* The same application through the persistent producer / consumer form of the kernel (cs_engine_kernel, one workgroup per */
 /* CU); bit-identical results.  Its own entry point: the choice of kernel is an argument of the call, not process state.   */
 int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""cs_pool_kernel on the S scene: block height (rows_per_block) x launch order (memory order / longest tile first).
-19 chained applications (the product's ping-pong of split planes), median of 5 chains."""
+"""cs_pool_kernel on the S scene: block height (rows_per_block).  19 chained applications (the product's ping-pong of split
+planes), median of 5 chains.  (Round 4 also ran it with a longest-tile-first launch order and with a ten-group instantiation of
+the kernel for blocks of up to 152 rows -- profiles/r04_pool_block_height.log; neither is in the tree: neither is faster.)"""
 import dataclasses
 import os
 import sys
@@ -26,12 +27,11 @@ for seed in (5557, 6557):
     Nv = cs.shape[0]
     w = ops.affinity_softmax(torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1), nbr, 20.0)
     X = torch.randn(Nv, 544, device="cuda")
-    auto = int(lib.gp_pool_cs_rows_per_block(Nv))
-    print(f"seed {seed}: Nv {Nv}; gp_pool_cs_rows_per_block -> {auto}", flush=True)
+    print(f"seed {seed}: Nv {Nv}", flush=True)
     ref = None
-    for rpb in sorted({128, auto, 124, 120, 112, 104, 96}, reverse=True):
-        for lf in (False, True):
-            op = ops.pool_cs_build(nbr, w, rows_per_block=rpb, longest_first=lf)
+    for rpb in (128, 124, 120, 117, 112, 104, 96):
+        for lf in (False,):
+            op = ops.pool_cs_build(nbr, w, rows_per_block=rpb)
             steps = ((op.bu_off[1:] - op.bu_off[:-1]) // 32).float()
             sp = [ops.split_f16(X, D), tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))]
             out = torch.empty((Nv, D), device="cuda")

@@ -798,7 +798,8 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     from the ELL lists; also checks the union rows and the (step, group) masks."""
     bo, bn, br, bm = (t.cpu().numpy() for t in (op.bu_off, op.bu_n, op.bu_row, op.bu_mask))
     wa = (op.wa_hi.float() + op.wa_lo.float()).cpu().numpy().reshape(-1, 8, 64, 8) / 1024.0
-    rows = np.arange(b * 128, min(b * 128 + 128, Nv))
+    rpb = op.block_rows
+    rows = np.arange(b * rpb, min(b * rpb + rpb, Nv))
     u = br[bo[b]:bo[b] + bn[b]]
     assert len(set(u)) == len(u) and set(u) == set(nbc[rows].reshape(-1))
     assert (br[bo[b] + bn[b]:bo[b + 1]] == u[0]).all()
@@ -828,10 +829,10 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     assert keys == sorted(keys)
 
 
-@pytest.mark.parametrize("n_vox", [2500, 2531])
-def test_pool_cs_matches_ell_and_oracle(ops, n_vox):
-    """Column-sliced matrix-core pooling (128-row blocks, union rows grouped by the 16-row groups that use them, empty
-    weight fragments skipped) against the ELL gather and the oracle (models/affinity_module.py:1575-1587)."""
+@pytest.mark.parametrize("n_vox,rpb", [(2500, 128), (2531, 128), (2531, 100), (2500, 117)])
+def test_pool_cs_matches_ell_and_oracle(ops, n_vox, rpb):
+    """Column-sliced matrix-core pooling (blocks of rpb <= 128 rows, union rows grouped by the 16-row groups that use them,
+    empty weight fragments skipped) against the ELL gather and the oracle (models/affinity_module.py:1575-1587)."""
     rng = np.random.default_rng(14)
     c = surface_voxels(rng, n_vox)
     ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
@@ -839,10 +840,10 @@ def test_pool_cs_matches_ell_and_oracle(ops, n_vox):
     nbr = ops.knn_lattice(grid, cs, perm, K)
     E = F.normalize(torch.randn(Nv, 128), dim=1)
     w = ops.affinity_softmax(dev(E), nbr, 20.0)
-    op = ops.pool_cs_build(nbr, w)
+    op = ops.pool_cs_build(nbr, w, rows_per_block=rpb)
     nbc, wc = nbr.cpu().numpy(), w.cpu().numpy()
     bo = op.bu_off.cpu().numpy()
-    assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0 and (np.diff(bo) >= 32).all()
+    assert (np.diff(bo) % 32 == 0).all() and bo[0] == 0 and (np.diff(bo) >= 32).all() and len(bo) - 1 == -(-len(c) // rpb)
     nb = len(bo) - 1
     for b in (0, nb // 2, nb - 1):
         _cs_dense_block(op, b, K, nbc, wc, Nv)
