@@ -15,7 +15,11 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if any(w in k for w in wants):
-            acc[k.split("(")[0][:90]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            name = k
+            for pre in ("void ", "(anonymous namespace)::"):
+                if name.startswith(pre):
+                    name = name[len(pre):]
+            acc[name.split("(")[0][:90]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
     out[k] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()}
