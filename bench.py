@@ -584,8 +584,12 @@ def main():
         args.schedule = "alternate" if cfg.dense_features else "split"
     split = args.schedule == "split" and args.streams >= 2          # --streams 1: everything on one stream
     if split:                                           # [0] loader + lift of the NEXT scene, [1] refine + classify
-        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        # the look-ahead stream has the HIGHER priority: its small kernels run beside the convolutions, whose workgroups hold a CU for
+        # ~40 us each; the host's read-backs in the look-ahead (voxel count, per-view counts, pair count, union rows) wait for them
+        side_prio = int(os.environ.get("GP_BENCH_SIDE_PRIORITY", "-1"))
+        streams = [torch.cuda.Stream(device=dev, priority=side_prio), torch.cuda.Stream(device=dev)]
     pending = {}                                        # scene index -> (batch, F, text, scale, lift-done event), lifted ahead
+    host_t = {"hook": 0.0, "step": 0.0}                 # host seconds inside the look-ahead hook / inside step() (timed region)
 
     def _tensors(obj):
         if torch.is_tensor(obj):
@@ -638,9 +642,11 @@ def main():
             started.record(streams[1])
 
             def hook():
+                t_h = time.perf_counter()
                 if prefetch:
                     _lift_ahead(i + 1, after=started)
                     streams[1].wait_event(pending[i + 1][4])
+                host_t["hook"] += time.perf_counter() - t_h
             feats = hp.refine(batch, F, after_student=hook, prepared=prep)
             hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale},
                                   batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
@@ -701,8 +707,11 @@ def main():
     t0 = time.perf_counter()
     last = None
     n_local = args.steps if args.scenes else 0
+    host_t["hook"] = 0.0
     for i in range(n_local):
+        t_s = time.perf_counter()
         last = step(i, prefetch=i + 1 < n_local)
+        host_t["step"] += time.perf_counter() - t_s
     join_streams()                                    # every scene's histogram atomics precede the collective
     busy_ev = torch.cuda.Event(enable_timing=False)
     busy_ev.record()
@@ -842,6 +851,10 @@ def main():
             "stages_ms_per_scene": {k: round(v / side, 3) for k, v in stages.items()},
             "stages_note": f"one-stream side pass over {side} scene(s) after the timed region",
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
+            "host_ms_per_scene": {"enqueue_total": round(host_t["step"] / max(n_local, 1) * 1e3, 3),
+                                  "look_ahead_hook": round(host_t["hook"] / max(n_local, 1) * 1e3, 3),
+                                  "note": "host wall time inside step() per scene (kernel enqueue incl. the look-ahead's read-backs); when it "
+                                          "approaches ms_per_step the host, not the GPU, paces the scenes"},
             "iou_target_points": iou_target_points,
             "iou_intersection_points": iou_intersection_points,
         }
