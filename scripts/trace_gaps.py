@@ -60,3 +60,19 @@ for t, d in ev:
     depth += d
     last = t
 print(f"GPU busy with at least one kernel: {any_busy / 1e6 / nsc:.3f} ms per scene; idle {span / nsc - any_busy / 1e6 / nsc:.3f} ms per scene")
+
+# per scene: when does the look-ahead queue work, relative to the student's first convolution launch on the main queue?
+main_q = max(byq, key=lambda q: len(byq[q]))
+side_qs = [q for q in byq if q != main_q]
+convs = [s for s, e, q, n in sel if q == main_q and "conv_phase1" in n]
+l2 = [(s, e) for s, e, q, n in sel if q == main_q and "l2norm_rows" in n]
+aff = [(s, e) for s, e, q, n in sel if q == main_q and "affinity_block" in n]
+print("per scene (ms after the student's l2norm END): affinity start | look-ahead queue: first kernel start, last kernel end (relative to the PREVIOUS l2norm end)")
+for i in range(1, len(l2)):
+    t_l2 = l2[i][1]
+    a = [s for s, e in aff if s >= t_l2]
+    side = [(s, e, n) for s, e, q, n in sel if q in side_qs and l2[i - 1][1] <= s < t_l2]
+    if not a or not side:
+        continue
+    print(f"  scene {i}: affinity starts {(a[0] - t_l2) / 1e6:6.3f} ms after l2norm; look-ahead kernels {len(side):4d}: first {(side[0][0] - l2[i - 1][1]) / 1e6:7.3f} ms, "
+          f"last ends {(side[-1][1] - l2[i - 1][1]) / 1e6:7.3f} ms after the previous l2norm (this l2norm ends at {(t_l2 - l2[i - 1][1]) / 1e6:7.3f}); last look-ahead kernel: {short(side[-1][2])}")
