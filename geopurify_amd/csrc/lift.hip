@@ -1,7 +1,6 @@
 // Rows 5-7: 2D->3D feature lift.  Dense-map lift, per-view mask-embedding lift (bicubic-antialias
 // resize evaluated only at the sampled pixels), point->view CSR, consensus top-3 fusion.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "gp_common.h"
@@ -174,28 +173,15 @@ __global__ void transpose_views_kernel(const float *__restrict__ src, int rows, 
         if (orow < cols && ocol < rows) dst[vo + (int64_t)orow * rows + ocol] = tile[tx][r];
     }
 }
-// The entries of a view come in POINT order, i.e. scattered over the image: every wave then pulls its 16 taps x Q logits (12.8 KB)
-// from anywhere in the view's 17 MB of transposed logits, and the kernel fetched 4.6 GB from beyond L2 per S scene for 0.39 GB of
-// logits (round-4 PMC, profiles/r04_small_pmc_summary.json: 53 % L2 hits).  `perm` (nullable) = the entries sorted by (view, 8 x 8
-// pixel tile): consecutive waves share taps.  Same per-entry arithmetic, same results.
-__global__ void lift_entry_keys_kernel(const int64_t *__restrict__ ent_x, const int64_t *__restrict__ ent_y,
-                                       const int32_t *__restrict__ ent_view, int64_t total, uint32_t *__restrict__ key,
-                                       uint32_t *__restrict__ val) {
-    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    key[e] = ((uint32_t)ent_view[e] << 14) | ((((uint32_t)ent_x[e] >> 3) & 127u) << 7) | (((uint32_t)ent_y[e] >> 3) & 127u);
-    val[e] = (uint32_t)e;
-}
 __global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, Q]*/, int Q, int h, int w,
                                         const float *__restrict__ scores /*[V,Q]*/, const int32_t *__restrict__ tx0,
                                         const float *__restrict__ twx, const int32_t *__restrict__ ty0,
                                         const float *__restrict__ twy, int out_h, int out_w,
                                         const int64_t *__restrict__ ent_x, const int64_t *__restrict__ ent_y,
                                         const int32_t *__restrict__ ent_view, const uint8_t *__restrict__ keep, int64_t total,
-                                        const uint32_t *__restrict__ perm, int32_t *__restrict__ seg) {
+                                        int32_t *__restrict__ seg) {
     int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     if (e >= total) return;
-    if (perm) e = perm[e];
     int lane = gp_lane();
     const int v = ent_view[e];
     int sg = -1;
@@ -578,14 +564,7 @@ static size_t lv_scan64_tmp(int64_t n) {
 struct LvWork {
     float *mt; int32_t *cov, *rs, *rent, *qent; float *rxyz; double *part_d; int32_t *part_i; unsigned long long *vmask; int4 *tab;
     int64_t *cnt; char *tmp; size_t tmp_bytes;
-    uint32_t *key_in, *key_out, *val_in, *val_out;
 };
-static size_t lv_sort_tmp(int64_t n) {
-    size_t t = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, t, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                    (size_t)n, 0, 21, (hipStream_t)0);
-    return t;
-}
 static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n, int64_t fill_cap,
                        LvWork &k) {
     GpCarver cv(ws, bytes);
@@ -600,13 +579,8 @@ static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t 
     k.vmask = cv.take<unsigned long long>(n * 2);
     k.cnt = cv.take<int64_t>(n + 1);
     k.tab = cv.take<int4>(130);
-    k.key_in = cv.take<uint32_t>(total);
-    k.key_out = cv.take<uint32_t>(total);
-    k.val_in = cv.take<uint32_t>(total);
-    k.val_out = cv.take<uint32_t>(total);
-    size_t a = lv_scan32_tmp(total + 1), b = lv_scan64_tmp(n + 1), c = lv_sort_tmp(total);
+    size_t a = lv_scan32_tmp(total + 1), b = lv_scan64_tmp(n + 1);
     k.tmp_bytes = a > b ? a : b;
-    if (c > k.tmp_bytes) k.tmp_bytes = c;
     k.tmp = cv.take<char>(k.tmp_bytes);
     return cv.off;
 }
@@ -645,16 +619,8 @@ extern "C" int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_
     hipStream_t s = gp_stream(stream_);
     const int hw = h * w;
     transpose_views_kernel<<<dim3((hw + 63) / 64, (q + 63) / 64, nviews), 256, 0, s>>>(pred_masks, q, hw, k.mt);
-    // entries in (view, 8 x 8 pixel tile) order for the lift kernel (pixel coordinates < 1024, <= 128 views: 21-bit keys)
-    const uint32_t *perm = nullptr;
-    if (out_h <= 1024 && out_w <= 1024) {
-        lift_entry_keys_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(ent_x, ent_y, ent_view, total, k.key_in, k.val_in);
-        size_t stb = k.tmp_bytes;
-        GP_CHECK_HIP(rocprim::radix_sort_pairs(k.tmp, stb, k.key_in, k.key_out, k.val_in, k.val_out, (size_t)total, 0, 21, s));
-        perm = k.val_out;
-    }
     lift_masks_views_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, s>>>(k.mt, q, h, w, scores, tap_x0, tap_wx, tap_y0, tap_wy,
-                                                                               out_h, out_w, ent_x, ent_y, ent_view, keep, total, perm, seg);
+                                                                               out_h, out_w, ent_x, ent_y, ent_view, keep, total, seg);
     // in-view fill
     const unsigned eb = (unsigned)((total + 1 + 255) / 256);
     fill_flags_kernel<<<eb, 256, 0, s>>>(seg, total, k.cov);
