@@ -173,6 +173,10 @@ __global__ void transpose_views_kernel(const float *__restrict__ src, int rows, 
         if (orow < cols && ocol < rows) dst[vo + (int64_t)orow * rows + ocol] = tile[tx][r];
     }
 }
+// Measured and left out (round 4): the entries of a view come in POINT order, scattered over the image, and the kernel fetches 4.6 GB
+// from beyond L2 per S scene for 0.39 GB of transposed logits (PMC: 53 % L2 hits); with the entries radix-sorted by (view, 8 x 8 pixel
+// tile) it takes 524 instead of 545 us and the sort costs 80 us: the wave's 16 taps x Q multiply-adds and their dependent loads
+// bound it, not the bytes.
 __global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, Q]*/, int Q, int h, int w,
                                         const float *__restrict__ scores /*[V,Q]*/, const int32_t *__restrict__ tx0,
                                         const float *__restrict__ twx, const int32_t *__restrict__ ty0,
