@@ -98,50 +98,7 @@ __device__ __forceinline__ void lift_masks_point(const float *__restrict__ mt /*
     bool inb = (unsigned)row < (unsigned)out_h && (unsigned)col < (unsigned)out_w;
     float best = -1.f, best_logit = 0.f;
     int best_q = -1;
-    if (inb && (Q & 3) == 0 && Q <= 256 && (((uintptr_t)mt | (uintptr_t)scores) & 15) == 0) {
-        // four consecutive queries per lane, 16-byte loads: Q = 200 is ONE pass of 16 loads per lane (50 lanes) instead of four passes
-        // of 16 dword loads (the last with 8 live lanes).  Per query the same multiply / fma sequence, hence the same bits; a lane
-        // keeps its first maximum in ascending q, the wave reduction below prefers the smaller q on ties -- the order of the loop.
-        const int x0 = tx0[col], y0 = ty0[row];
-        float wx[4], wy[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { wx[t] = twx[col * 4 + t]; wy[t] = twy[row * 4 + t]; }
-        const int q4 = lane * 4;
-        if (q4 < Q) {
-            float hr[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int yy = min(y0 + j, h - 1);
-                const float *r = mt + ((int64_t)yy * w) * Q + q4;
-                float4 s[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) s[a] = *reinterpret_cast<const float4 *>(r + (int64_t)min(x0 + a, w - 1) * Q);
-                const float s0[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, s1[4] = {s[1].x, s[1].y, s[1].z, s[1].w},
-                            s2[4] = {s[2].x, s[2].y, s[2].z, s[2].w}, s3[4] = {s[3].x, s[3].y, s[3].z, s[3].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float t = __fmul_rn(s0[c], wx[0]);
-                    t = fmaf(s1[c], wx[1], t);
-                    t = fmaf(s2[c], wx[2], t);
-                    t = fmaf(s3[c], wx[3], t);
-                    hr[j][c] = t;
-                }
-            }
-            const float4 sc4 = *reinterpret_cast<const float4 *>(scores + q4);
-            const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = __fmul_rn(hr[0][c], wy[0]);
-#pragma unroll
-                for (int j = 1; j < 4; ++j) v = fmaf(hr[j][c], wy[j], v);
-                if (scv[c] > 0.f) {
-                    float sg = 1.f / (1.f + expf(-v));
-                    float pr = __fmul_rn(scv[c], sg);
-                    if (pr > best) { best = pr; best_q = q4 + c; best_logit = v; }   // ascending q: first max kept
-                }
-            }
-        }
-    } else if (inb) {
+    if (inb) {
         int x0 = tx0[col], y0 = ty0[row];
         float wx[4], wy[4];
 #pragma unroll
