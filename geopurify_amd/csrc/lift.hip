@@ -176,7 +176,9 @@ __global__ void transpose_views_kernel(const float *__restrict__ src, int rows, 
 // Measured and left out (round 4): the entries of a view come in POINT order, scattered over the image, and the kernel fetches 4.6 GB
 // from beyond L2 per S scene for 0.39 GB of transposed logits (PMC: 53 % L2 hits); with the entries radix-sorted by (view, 8 x 8 pixel
 // tile) it takes 524 instead of 545 us and the sort costs 80 us: the wave's 16 taps x Q multiply-adds and their dependent loads
-// bound it, not the bytes.
+// bound it, not the bytes.  Four consecutive queries per lane with 16-byte loads (Q = 200: one pass of 16 loads on 50 lanes instead of
+// four passes of 16 dword loads, the last with 8 live lanes; same bits) is SLOWER: 733 us -- the four passes keep four times as many
+// loads in flight.
 __global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, Q]*/, int Q, int h, int w,
                                         const float *__restrict__ scores /*[V,Q]*/, const int32_t *__restrict__ tx0,
                                         const float *__restrict__ twx, const int32_t *__restrict__ ty0,
