@@ -273,12 +273,11 @@ __device__ __forceinline__ uint64_t cv_real() {
 // XCC id | pairs << 8, cycles of the loop spent issuing LDS-DMA, cycles of the loop spent in the end-of-step wait + barrier}
 // Round-4 stamps of this loop (scripts/stamp_conv.py, profiles/r04_conv_stamps.log): per step 550-820 cycles of DMA issue during
 // which neither wave of a SIMD feeds the matrix pipe, 2 150 of reads + MFMA, 1 850 waiting at the barrier for the SIMD partner's
-// MFMAs -- 4 550-4 800 cycles for 3 072 cycles of matrix work.  Measured and left out (SPLIT = true, kept here as the switch of the
-// experiment): waves 0-3 issue ALL of a stage's LDS-DMA (64 rows of each operand), waves 4-7 none, so that a SIMD's second wave
+// MFMAs -- 4 550-4 800 cycles for 3 072 cycles of matrix work.  Measured and left out: waves 0-3 issue ALL of a stage's LDS-DMA (64 rows of each operand), waves 4-7 none, so that a SIMD's second wave
 // multiplies while the first absorbs the memory pipeline's back-pressure: the step falls to 4 150 cycles (-8.6 %), the in-kernel
 // clock from 2.04 to 1.99 GHz, and the layer takes the same 1.929 ms -- on all-zero operands the same cycle count runs at
 // 2.37 GHz and 1.664 ms: the layer is bound by the clock the chip holds under this load, not by the schedule.
-template <bool TUNE, bool STAMP, bool SPLIT>
+template <bool TUNE, bool STAMP>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
                      const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
@@ -305,10 +304,10 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     const int4 td = tile_desc[mt];
     const int k = td.x, base = td.y, cnt = td.z;
     const int n0 = nt * TN;
-    // DMA roles: an issuing wave stages RPW rows of each array, NI instructions of 16 rows per plane.  Symmetric form: every
-    // wave 32 rows; SPLIT: waves 0-3 64 rows each, waves 4-7 nothing.  The lo planes sit at a uniform distance from the hi planes.
-    constexpr int NI = SPLIT ? 4 : 2, RPW = 16 * NI;
-    const bool issuer = !SPLIT || wv < 4;                                     // wave-uniform
+    // DMA roles: every wave stages RPW = 32 rows of each array, NI = 2 instructions of 16 rows per plane.  The lo planes sit at a
+    // uniform distance from the hi planes.
+    constexpr int NI = 2, RPW = 16 * NI;
+    constexpr bool issuer = true;
     const int lrow = lane >> 2, lp = lane & 3;
     const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;         // logical 8-half slot this lane fetches
     const int64_t da = x_lo - x_hi, db = w_lo - w_hi;                         // (in halfs)
@@ -458,9 +457,9 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 #define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp
 // the product kernel (tuning bits compiled out) and its twin with the bits of knob 3 live, under its own name in a trace
 // (bench.py's data-movement ceiling of the convolution and scripts/bench_conv.py's ablations launch the twin)
-__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, false>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false, false>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true>(P1_FWD); }
 
 #undef P1_PARAMS
 #undef P1_FWD

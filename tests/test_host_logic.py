@@ -204,8 +204,22 @@ def test_compat_shims_resolve_reference_module_names():
 def test_bench_line_contract_on_the_committed_run():
     """The bench.py JSON lines of the committed default runs (profiles/r01e_... and r02_bench_default_run.json, produced on
     the MI355X box by `python bench.py`) carry every key of the driver's contract with consistent values."""
-    for name in ("r01e_bench_default_run.json", "r02_bench_default_run.json"):
+    for name in ("r01e_bench_default_run.json", "r02_bench_default_run.json", "r04_bench_default_run.json"):
         _check_bench_line(name)
+    # round 4: a roofline line per stage (VERDICT r3 next 6), the convolution layer's ceilings (next 4 ii), host enqueue time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r04_bench_default_run.json")))
+    st = d["roofline_stages"]
+    for k in ("voxelize", "project+lists", "lift+fuse+fill", "scatter_mean", "kNN", "affinity", "pooling", "gather", "classify+iou"):
+        assert st[k]["ms"] > 0 and abs(st[k]["frac"] - st[k]["achieved"] / 8000.0) < 1e-3, k
+        assert abs(st[k]["achieved"] - st[k]["algorithmic_bytes"] / (st[k]["ms"] * 1e-3) / 1e9) < 0.002 * st[k]["achieved"] + 1.0, k   # (ms is rounded)
+    assert st["student"]["ms"] > 10 * st["affinity"]["ms"]
+    c = d["roofline_conv"]["ceilings"]
+    assert c["mfma_floor_ms"] < c["no_mfma_ms"] < c["layer_ms"] and c["zero_operand_ms"] < c["layer_ms"]
+    assert abs(c["mfma_floor_ms"] - 3 * 2.0 * c["pairs"] * 512 * 512 / 2.5e15 * 1e3) < 1e-3
+    assert 0 < d["host_ms_per_scene"]["look_ahead_hook"] <= d["host_ms_per_scene"]["enqueue_total"] < d["ms_per_step"]
+    assert d["roofline"]["gather_store_ceiling"]["frac"] > d["roofline"]["frac_isolated"]
+    assert "r04_pool_pmc_summary" in d["roofline"]["traffic_source"]
 
 
 def _check_bench_line(name):
