@@ -569,6 +569,24 @@ def test_error_paths(ops):
             ops.pool_mfma_apply(xs2, opm, 512, out_split=ys2)
     finally:
         assert lib.gp_debug_ptr(0, None, 0) == 0
+    # the convolution's stamped twin: too small a buffer is rejected, a fitting one is written, the result keeps its bits
+    hi5, lo5 = ops.conv_weights_split(torch.randn(27, 64, 256, device="cuda") * 0.05, 1.0)
+    xs5 = ops.split_f16(torch.randn(len(c), 64, device="cuda"))
+    good5 = ops.sparse_conv_f16x3(None, pairs, hi5, lo5, x_split=xs5)
+    stamps = torch.zeros(4096 * 10, dtype=torch.int64, device="cuda")
+    try:
+        assert lib.gp_debug_ptr(1, small.data_ptr(), small.numel() * 8) == 0
+        with pytest.raises(GeoPurifyHipError, match="stamp buffer"):
+            ops.sparse_conv_f16x3(None, pairs, hi5, lo5, x_split=xs5)
+        assert lib.gp_debug_ptr(1, stamps.data_ptr(), stamps.numel() * 8) == 0
+        y5 = ops.sparse_conv_f16x3(None, pairs, hi5, lo5, x_split=xs5)
+        torch.cuda.synchronize()
+    finally:
+        assert lib.gp_debug_ptr(1, None, 0) == 0
+    assert torch.equal(y5, good5)
+    st = stamps.view(-1, 10).cpu()
+    st = st[st[:, 6] > 0]
+    assert len(st) > 0 and bool((st[:, 2] + st[:, 3] <= st[:, 6]).all())   # prologue + K loop inside the tile's total cycles
 
 
 def test_pooling_tuning_masks_keep_the_ring_discipline(ops):
@@ -658,6 +676,13 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
                                out_split=ys)
     assert torch.equal(y2, y)
     assert (ys[0].float() + ys[1].float() - y2).abs().max() <= 2e-6 * max(1.0, float(y2.abs().max()))
+    # launch grouping (ConvPairs.regroup): the same pairs in the same order, g chunks per launch => the same bits
+    for g in (2, 5):
+        grouped = pairs.regroup(g)
+        assert grouped.num_chunks == -(-pairs.num_chunks // min(g, pairs.num_chunks)) and grouped.num_pairs == pairs.num_pairs
+        assert grouped.max_chunk_pairs >= pairs.max_chunk_pairs
+        yg = ops.sparse_conv_f16x3(None, grouped, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs)
+        assert torch.equal(yg, y), g
 
 
 # ------------------------------------------------------------------------------------------ row 12 fast path

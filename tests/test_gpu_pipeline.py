@@ -87,6 +87,29 @@ def test_refine_every_pooling_kernel_d512(env, env512, pool_mode, block_rows):
     assert hp.stats["pool_kernel"] in want[pool_mode]
 
 
+def test_refine_with_a_state_prepared_ahead_on_another_stream(env, env512):
+    """HotPath.prepare run ahead on a side stream (bench.py's look-ahead) and handed to refine: the same bits as refine alone,
+    and the after_student hook is called exactly once between the student and the affinity kernels."""
+    pl, b, ref = env["pl"], env["batch"], env512["ref"]
+    hp = pl.HotPath(pl.StudentWeights(env512["sd"], "cuda"), env512["cfg"].mask_shape, K=env512["K"],
+                    num_iters=env512["T"], device="cuda")
+    F = ref["lifted"].cuda().contiguous()
+    plain = hp.refine(b, F).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        state = hp.prepare(b, F)
+        done = torch.cuda.Event()
+        done.record(side)
+    assert set(state) >= {"X", "rank", "nbr_map", "pairs", "nbr", "Nv", "D", "pool"} and state["pool"] is not None
+    torch.cuda.current_stream().wait_event(done)
+    calls = []
+    ahead = hp.refine(b, F, after_student=lambda: calls.append(hp.stats.get("pool_kernel")), prepared=state)
+    assert calls and len(calls) == 1
+    assert torch.equal(ahead, plain)
+    assert (ahead.cpu() - ref["scene_features"]).abs().max() < 1e-4
+
+
 def test_end_to_end_features_and_labels(env):
     hp, b, pl, cfg, ref = env["hp"], env["batch"], env["pl"], env["cfg"], env["ref"]
     res = hp.evaluate_scene(b, pl.SyntheticVLM(env["vlm_np"], "cuda"))
