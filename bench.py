@@ -187,8 +187,8 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
             out[name] = {"ms": round(ms[name], 4), "note": {"morton order": "internal row order of the voxels (sort of Nv keys): index work, no SURVEY 8(d) figure",
                                                            "grid+kernel_map": "lattice grid + 27-offset kernel map: index work, no SURVEY 8(d) figure",
                                                            "student": "matrix-core bound: see roofline_conv",
-                                                           "pool plan+split": "once per scene, needs the kNN lists only: union sizes of the pooling operator + the f16 hi/lo split of X",
-                                                           "pool operator fill": "once per scene: union rows, fragment masks and the weights in fragment order"}[name]}
+                                                           "pool plan+split": "once per scene, needs the kNN lists only: the pooling operator's union sizes and structure (union rows, fragment masks, the element of every (row, neighbour) weight) + the f16 hi/lo splits of X",
+                                                           "pool operator fill": "empty since round 4: the affinity kernel writes the weights straight into fragment order (GP_POOL_STRUCTURE_AHEAD=0: the separate fill pass)"}[name]}
     out["note"] = ("one-stream side pass after the timed region, HIP events at stage boundaries, mean over the side scenes; "
                    "achieved = SURVEY 8(d) algorithmic bytes / stage time; peak 8000 GB/s")
     return out
@@ -612,18 +612,29 @@ def main():
         with torch.cuda.stream(stream if stream is not None else streams[i % len(streams)]):
             return _step(i, stage)
 
+    timeline = [] if os.environ.get("GP_BENCH_TIMELINE") == "1" else None
+    student_end = {}
+
     def _lift_ahead(i, after=None):
         """Loader + lift + HotPath.prepare (voxel means, kernel map and pairs, kNN lists, pooling plan: everything of refine that
         does not need the student) of scene i on streams[0], after the event `after` (recorded on streams[1])."""
         j = i % max(args.scenes, 1)
+        tl = timeline is not None and after is not None
+        mk = (lambda: (lambda e: (e.record(streams[0]), e)[1])(torch.cuda.Event(enable_timing=True))) if tl else (lambda: None)
+        h0 = time.perf_counter()
         with torch.cuda.stream(streams[0]):
             if after is not None:
                 streams[0].wait_event(after)
+            e_first = mk()
             batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
+            e_load, h1 = mk(), time.perf_counter()
             F, text, scale = hp.lift_dense(batch, vlms[j]) if cfg.dense_features else hp.lift_masks(batch, vlms[j])
+            e_lift, h2 = mk(), time.perf_counter()
             prep = hp.prepare(batch, F)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=tl)
             done.record(streams[0])
+        if tl:      # GP_BENCH_TIMELINE=1: where the look-ahead ran relative to the student it was meant to run beside
+            timeline.append({"after": after, "gpu": (e_first, e_load, e_lift, done), "host": (h0, h1, h2, time.perf_counter())})
         for t in _tensors([batch, F, text, prep]):      # the consumer stream: the allocator keeps the blocks until its kernels ran
             t.record_stream(streams[1])
         pending[i] = (batch, F, text, scale, done, prep)
@@ -638,11 +649,16 @@ def main():
         batch, F, text, scale, done, prep = pending.pop(i)
         with torch.cuda.stream(streams[1]):
             streams[1].wait_event(done)
-            started = torch.cuda.Event()
+            started = torch.cuda.Event(enable_timing=timeline is not None)
             started.record(streams[1])
+            t_started = time.perf_counter()
 
             def hook():
                 t_h = time.perf_counter()
+                if timeline is not None:
+                    e_st = torch.cuda.Event(enable_timing=True)
+                    e_st.record(streams[1])
+                    student_end[started] = (e_st, t_h, t_started)
                 if prefetch:
                     _lift_ahead(i + 1, after=started)
                     streams[1].wait_event(pending[i + 1][4])
@@ -727,6 +743,17 @@ def main():
     if world == 1:
         busy = dt
     pool_timer.enabled = conv_timer.enabled = False
+    if timeline:
+        torch.cuda.synchronize()
+        for rec in timeline[-6:]:
+            st0 = rec["after"]
+            e_st, t_hook, t_started = student_end[st0]
+            g = [st0.elapsed_time(e) for e in rec["gpu"]]
+            h = [(t - t_started) * 1e3 for t in rec["host"]]
+            log(f"timeline (ms after this refine's start): student ends {st0.elapsed_time(e_st):6.2f} on the GPU (host done enqueuing it at {(t_hook - t_started) * 1e3:5.2f}); "
+                f"look-ahead on the GPU: first {g[0]:6.2f}, loader done {g[1]:6.2f}, lift done {g[2]:6.2f}, prepare done {g[3]:6.2f}; "
+                f"on the host: starts {h[0]:6.2f}, loader returned {h[1]:6.2f}, lift returned {h[2]:6.2f}, prepare returned {h[3]:6.2f}")
+        timeline = None
     total_steps = n_local
     busy_all = [busy]
     if world > 1:

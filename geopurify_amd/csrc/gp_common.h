@@ -11,6 +11,10 @@
 
 #define GP_WAVE 64
 
+// gp_pool_cs_*: the affinity weights (<= 1) are stored x 2^10 in the operator's f16 fragments so that their lo parts stay normal
+// (shared by the builder in pool_mfma_cs.hip and the affinity kernels that write fragments directly, pool.hip)
+#define GP_POOL_CS_WSCALE 1024.f
+
 extern "C" void gp_set_error(const char *fmt, ...);
 
 #define GP_CHECK_ARG(cond, ...)                \

@@ -84,9 +84,18 @@ __global__ void l2norm_rows_kernel(float *__restrict__ x, int64_t ld, int d, int
 // ------------------------------------------------------------------------------------------------
 // affinity: one wave per voxel row.  4 lanes share a neighbour (each reads d/4 contiguous floats),
 // 16 neighbours per pass; dot products reduced with two shuffles; softmax over K with wave reductions.
-template <int D>
+// SCATTER: each weight also goes, x GP_POOL_CS_WSCALE and split hi + lo, to element dst[i * k + j] of the pooling operator's
+// fragment arrays (gp_pool_cs_structure) -- the same value gp_pool_cs_fill would read back from w, so the operator keeps its bits.
+__device__ __forceinline__ void affinity_emit_fragment(float wgt, int32_t idx, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
+    const float v = wgt * GP_POOL_CS_WSCALE;
+    const _Float16 h = (_Float16)v;
+    wa_hi[idx] = h;
+    wa_lo[idx] = (_Float16)(v - (float)h);
+}
+template <int D, bool SCATTER>
 __global__ void affinity_softmax_kernel(const float *__restrict__ e, int64_t ld_e, const int32_t *__restrict__ nbr,
-                                        int k, int64_t nv, float sharpen, float *__restrict__ w) {
+                                        int k, int64_t nv, float sharpen, float *__restrict__ w, const int32_t *__restrict__ dst,
+                                        _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
     int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     if (i >= nv) return;
     int lane = gp_lane();
@@ -131,7 +140,11 @@ __global__ void affinity_softmax_kernel(const float *__restrict__ e, int64_t ld_
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         int j = p * 16 + grp;
-        if (sub == 0 && j < k) w[i * k + j] = logit[p] / sum;
+        if (sub == 0 && j < k) {
+            const float wgt = logit[p] / sum;
+            w[i * k + j] = wgt;
+            if constexpr (SCATTER) affinity_emit_fragment(wgt, dst[i * k + j], wa_hi, wa_lo);
+        }
     }
 }
 
@@ -198,10 +211,10 @@ template <int R> struct AbGeo {                               // R rows per work
     static constexpr int HS = R * 128, CAP = R == 16 ? 240 : 120;
     static constexpr size_t SMEM = (size_t)CAP * AB_LD * 4 + HS * 4 + HS * 2 + HS * 4;
 };
-template <int R>
+template <int R, bool SCATTER>
 __global__ void __launch_bounds__(R * 64)
 affinity_block_kernel(const float *__restrict__ e, int64_t ld_e, const int32_t *__restrict__ nbr, int k, int64_t nv, float sharpen,
-                      float *__restrict__ w) {
+                      float *__restrict__ w, const int32_t *__restrict__ dst, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
     constexpr int AB_ROWS = R, AB_HS = AbGeo<R>::HS, AB_CAP = AbGeo<R>::CAP, NT = R * 64;
     extern __shared__ __align__(16) unsigned char ab_smem[];
     float *rows = reinterpret_cast<float *>(ab_smem);                                   // [AB_CAP][AB_LD]
@@ -326,7 +339,11 @@ affinity_block_kernel(const float *__restrict__ e, int64_t ld_e, const int32_t *
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int j = p * 16 + grp;
-        if (sub == 0 && j < k) w[i * k + j] = logit[p] / sum;
+        if (sub == 0 && j < k) {
+            const float wgt = logit[p] / sum;
+            w[i * k + j] = wgt;
+            if constexpr (SCATTER) affinity_emit_fragment(wgt, dst[i * k + j], wa_hi, wa_lo);
+        }
     }
 }
 
@@ -367,32 +384,49 @@ extern "C" int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *
     return GP_OK;
 }
 
+// dst / wa_hi / wa_lo all NULL: the weights only.  All set: every weight also lands in the pooling operator's fragment arrays.
+template <bool SCATTER>
+static int affinity_launch(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k, int64_t nv, float sharpen, float *w,
+                           const int32_t *dst, _Float16 *wa_hi, _Float16 *wa_lo, hipStream_t s) {
+    int blocks = (int)((nv * 64 + 255) / 256);
+    if (d == 128 && g_gp_knobs[15] != 1) {              // block form: distinct neighbour rows of R rows staged once in LDS
+        GP_SMEM_ATTR((affinity_block_kernel<16, SCATTER>), AbGeo<16>::SMEM);
+        GP_SMEM_ATTR((affinity_block_kernel<8, SCATTER>), AbGeo<8>::SMEM);
+        if (g_gp_knobs[15] == 2)                        // measured on config S: 16 rows 0.49 ms, 8 rows 0.55 ms, wave form 0.81 ms
+            affinity_block_kernel<8, SCATTER><<<(unsigned)((nv + 7) / 8), 512, AbGeo<8>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w, dst, wa_hi, wa_lo);
+        else
+            affinity_block_kernel<16, SCATTER><<<(unsigned)((nv + 15) / 16), 1024, AbGeo<16>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w, dst, wa_hi, wa_lo);
+        GP_CHECK_LAUNCH();
+        return GP_OK;
+    }
+    switch (d) {
+        case 128: affinity_softmax_kernel<128, SCATTER><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w, dst, wa_hi, wa_lo); break;
+        case 64: affinity_softmax_kernel<64, SCATTER><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w, dst, wa_hi, wa_lo); break;
+        case 32: affinity_softmax_kernel<32, SCATTER><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w, dst, wa_hi, wa_lo); break;
+        case 16: affinity_softmax_kernel<16, SCATTER><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w, dst, wa_hi, wa_lo); break;
+        default: gp_set_error("gp_affinity_softmax: embedding dim %d not in {16,32,64,128}", d); return GP_EINVAL;
+    }
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
 extern "C" int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k,
                                    int64_t nv, float sharpen, float *w, void *stream_) {
     GP_CHECK_ARG(e && nbr && w && nv > 0, "gp_affinity_softmax: null/empty argument");
     GP_CHECK_ARG(k > 0 && k <= 128, "gp_affinity_softmax: k=%d not in 1..128", k);
     GP_CHECK_ARG(ld_e % 4 == 0 && (uintptr_t)e % 16 == 0, "gp_affinity_softmax: rows must be 16-byte aligned");
-    int blocks = (int)((nv * 64 + 255) / 256);
-    hipStream_t s = gp_stream(stream_);
-    if (d == 128 && g_gp_knobs[15] != 1) {              // block form: distinct neighbour rows of R rows staged once in LDS
-        GP_SMEM_ATTR(affinity_block_kernel<16>, AbGeo<16>::SMEM);
-        GP_SMEM_ATTR(affinity_block_kernel<8>, AbGeo<8>::SMEM);
-        if (g_gp_knobs[15] == 2)                        // measured on config S: 16 rows 0.49 ms, 8 rows 0.55 ms, wave form 0.81 ms
-            affinity_block_kernel<8><<<(unsigned)((nv + 7) / 8), 512, AbGeo<8>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w);
-        else
-            affinity_block_kernel<16><<<(unsigned)((nv + 15) / 16), 1024, AbGeo<16>::SMEM, s>>>(e, ld_e, nbr, k, nv, sharpen, w);
-        GP_CHECK_LAUNCH();
-        return GP_OK;
-    }
-    switch (d) {
-        case 128: affinity_softmax_kernel<128><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
-        case 64: affinity_softmax_kernel<64><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
-        case 32: affinity_softmax_kernel<32><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
-        case 16: affinity_softmax_kernel<16><<<blocks, 256, 0, s>>>(e, ld_e, nbr, k, nv, sharpen, w); break;
-        default: gp_set_error("gp_affinity_softmax: embedding dim %d not in {16,32,64,128}", d); return GP_EINVAL;
-    }
-    GP_CHECK_LAUNCH();
-    return GP_OK;
+    return affinity_launch<false>(e, ld_e, d, nbr, k, nv, sharpen, w, nullptr, nullptr, nullptr, gp_stream(stream_));
+}
+
+// The same weights, written to w AND -- x 2^10, split hi + lo -- to element dst[row * k + j] of the pooling operator's fragment arrays
+// (dst, wa_hi, wa_lo from gp_pool_cs_structure): the operator is complete when this returns, no gp_pool_cs_fill pass.
+extern "C" int gp_affinity_softmax_scatter(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k, int64_t nv,
+                                           float sharpen, float *w, const int32_t *dst, void *wa_hi, void *wa_lo, void *stream_) {
+    GP_CHECK_ARG(e && nbr && w && dst && wa_hi && wa_lo && nv > 0, "gp_affinity_softmax_scatter: null/empty argument");
+    GP_CHECK_ARG(k > 0 && k <= 128, "gp_affinity_softmax_scatter: k=%d not in 1..128", k);
+    GP_CHECK_ARG(ld_e % 4 == 0 && (uintptr_t)e % 16 == 0, "gp_affinity_softmax_scatter: rows must be 16-byte aligned");
+    return affinity_launch<true>(e, ld_e, d, nbr, k, nv, sharpen, w, dst, static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo),
+                                 gp_stream(stream_));
 }
 
 extern "C" int gp_pool_ell(const float *x, int64_t ld_x, const int32_t *nbr, const float *w, int32_t k, int64_t nv,

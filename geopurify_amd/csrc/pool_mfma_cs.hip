@@ -43,7 +43,7 @@ constexpr int CS_WC = CS_NC / CS_NW;   // columns per wave
 constexpr int CS_MAXID = 16384;        // sort buffers of the builder (a power of two)
 constexpr int CS_MAXNK = 12288;        // block_rows x K ids per block (K <= 96): with the position table the builder's LDS is full
 constexpr int CS_HS = 16384;           // hash slots of the builder
-constexpr float CS_WSCALE = 1024.f;    // weights (<= 1) are stored x 2^10 so that their f16 lo parts stay normal
+constexpr float CS_WSCALE = GP_POOL_CS_WSCALE;    // weights (<= 1) are stored x 2^10 so that their f16 lo parts stay normal
 
 // LDS stage: X hi [32 rows][512 B] | X lo | weights hi [8 groups][1 KiB] | weights lo
 constexpr int CS_RB = CS_NC * 2;                   // bytes per staged row and plane
@@ -174,9 +174,14 @@ cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int rpb, int
 // pass 2: the block's union rows in (first group, last group, group set, id) order, one bit per (step, group) that says
 // whether the 16 x 32 weight fragment holds a non-zero, and the ELL weights scattered into MFMA fragment order:
 // wa[(step * 8 + group) * 64 + lane][8], lane = (k >> 3) * 16 + m  (k = union row within the step, m = row within the group).
+// WEIGHTS = false (gp_pool_cs_structure): everything that needs the neighbour lists only -- union rows, masks, zeroed fragments --
+// and, instead of the weights, dst[row * k + j] = the element index of (row, neighbour j) in the fragment arrays: whoever produces the
+// weights later (gp_affinity_softmax_scatter) stores them straight into fragment order.
+template <bool WEIGHTS>
 __global__ void __launch_bounds__(1024)
 cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int rpb, const int64_t *__restrict__ bu_off,
-               int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
+               int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo,
+               int32_t *__restrict__ dst) {
     extern __shared__ int s_mem[];                           // A[16384] | B[16384] | npos u16 [br*k]
     int *A = s_mem, *B = s_mem + CS_HS;
     unsigned short *npos = reinterpret_cast<unsigned short *>(s_mem + CS_HS + CS_MAXID);
@@ -249,10 +254,14 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
         const int64_t ks = ks0 + p / CS_KS;
         const int kk = p % CS_KS;
         const int64_t idx = ((ks * CS_NG + (rl >> 4)) * 64 + (kk >> 3) * 16 + (rl & 15)) * 8 + (kk & 7);
-        const float v = w[r0 * k + t] * CS_WSCALE;
-        const _Float16 h = (_Float16)v;
-        wa_hi[idx] = h;
-        wa_lo[idx] = (_Float16)(v - (float)h);
+        if constexpr (WEIGHTS) {
+            const float v = w[r0 * k + t] * GP_POOL_CS_WSCALE;
+            const _Float16 h = (_Float16)v;
+            wa_hi[idx] = h;
+            wa_lo[idx] = (_Float16)(v - (float)h);
+        } else {
+            dst[r0 * k + t] = (int32_t)idx;                              // (the host checks total_rows * 128 < 2^31)
+        }
     }
 }
 
@@ -890,9 +899,32 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
     size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
-    GP_SMEM_ATTR(cs_fill_kernel, sm_max);
-    cs_fill_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
-                                                  static_cast<_Float16 *>(wa_lo));
+    GP_SMEM_ATTR(cs_fill_kernel<true>, sm_max);
+    cs_fill_kernel<true><<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
+                                                        static_cast<_Float16 *>(wa_lo), nullptr);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// pass 2 without the weights: the operator's structure (bu_row, bu_mask, zeroed fragments) and dst i32 [nv, k], the element of
+// wa_hi / wa_lo that (row, neighbour j) owns.  gp_affinity_softmax_scatter then writes the weights in place; a scheduler runs this
+// before the student's embeddings exist (it needs the kNN lists only).
+extern "C" int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
+                                    int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, int32_t *dst,
+                                    void *stream_) {
+    GP_CHECK_ARG(nbr && dst && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
+                 "gp_pool_cs_structure: bad argument");
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_structure: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_structure: k=%d too large (128*k <= %d)", k, CS_MAXNK);
+    GP_CHECK_ARG(total_rows * (CS_NG * 64 * 8 / CS_KS) < (int64_t)INT32_MAX,
+                 "gp_pool_cs_structure: %lld union rows: fragment element indices do not fit 32 bits (use gp_pool_cs_fill)", (long long)total_rows);
+    int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
+    hipStream_t s = gp_stream(stream_);
+    const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
+    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
+    GP_SMEM_ATTR(cs_fill_kernel<false>, sm_max);
+    cs_fill_kernel<false><<<(unsigned)nb, 1024, sm, s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
+                                                         static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), dst);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

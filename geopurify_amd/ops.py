@@ -325,6 +325,24 @@ def l2norm_rows_(x, d=None):
     return x
 
 
+def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=True, out=None):
+    """The student's 1x1x1 output layer on pre-split rows, fused with F.normalize (affinity_module.py:66,71,1547).
+    x_split = (hi, lo) f16 [nv, >=cin]; w_hi / w_lo f16 [1, cout, cin] or [cout, cin] (conv_weights_split of the [1, cin, cout]
+    kernel with a power-of-two pre-scale whose inverse is out_scale)."""
+    lib = _lib.load()
+    hi, lo = x_split
+    cout, cin = w_hi.shape[-2:]
+    nv = hi.shape[0]
+    _chk(hi, torch.float16, "x_hi"), _chk(lo, torch.float16, "x_lo")
+    if hi.stride(0) != lo.stride(0) or hi.shape[1] < cin:
+        raise ValueError("embed_head_f16x3: the hi / lo planes must share a row stride and hold cin channels")
+    if out is None:
+        out = torch.empty((nv, cout), dtype=torch.float32, device=hi.device)
+    check(lib.gp_embed_head_f16x3(_ptr(hi), _ptr(lo), hi.stride(0), _ptr(x_row_inv), _ptr(w_hi), _ptr(w_lo), nv, int(cin), int(cout),
+                                  float(out_scale), int(bool(normalize)), _ptr(out), out.stride(0), _stream()), "gp_embed_head_f16x3")
+    return out
+
+
 def knn_lattice(grid, coords_sorted, ids, k):
     lib = _lib.load()
     nv = coords_sorted.shape[0]
@@ -336,11 +354,21 @@ def knn_lattice(grid, coords_sorted, ids, k):
     return nbr
 
 
-def affinity_softmax(e, nbr, sharpen=20.0, d=None):
+def affinity_softmax(e, nbr, sharpen=20.0, d=None, into=None):
+    """into: a PoolCs whose structure is built (pool_cs_plan(structure=True)): the weights also go straight into its fragment
+    arrays -- the operator is complete when this returns (no pool_cs_fill)."""
     lib = _lib.load()
     nv, k = nbr.shape
     d = e.shape[1] if d is None else d
     w = torch.empty((nv, k), dtype=torch.float32, device=e.device)
+    if into is not None:
+        if into.dst is None or into.nv != nv or tuple(into.dst.shape) != (nv, k):
+            raise ValueError("affinity_softmax: `into` needs a PoolCs structure built from these neighbour lists")
+        check(lib.gp_affinity_softmax_scatter(_ptr(e), e.stride(0), int(d), _ptr(nbr), int(k), nv, float(sharpen), _ptr(w),
+                                              _ptr(into.dst), _ptr(into.wa_hi), _ptr(into.wa_lo), _stream()),
+              "gp_affinity_softmax_scatter")
+        into.filled = True
+        return w
     check(lib.gp_affinity_softmax(_ptr(e), e.stride(0), int(d), _ptr(nbr), int(k), nv, float(sharpen), _ptr(w),
                                   _stream()), "gp_affinity_softmax")
     return w
@@ -451,9 +479,11 @@ class PoolCs:
         self.bu_off, self.bu_n, self.bu_row, self.bu_mask = bu_off, bu_n, bu_row, bu_mask
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
         self.block_rows = block_rows
+        self.dst = None            # i32 [nv, k]: fragment element of (row, neighbour) once the structure is built ahead
+        self.filled = False        # the weights are in the fragments
 
 
-def pool_cs_plan(nbr, rows_per_block=128):
+def pool_cs_plan(nbr, rows_per_block=128, structure=False):
     """First half of the operator build: needs the neighbour lists only (not the weights), so a scheduler can run it -- and its
     one host sync (total padded union rows, to size the arrays) -- before the affinity weights exist.  Returns a PoolCs without
     weights; pool_cs_fill completes it.  rows_per_block: 16..128 (every height from 96 up measures within 4 % on the S scene,
@@ -473,7 +503,14 @@ def pool_cs_plan(nbr, rows_per_block=128):
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
-    return PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb)
+    op = PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb)
+    if structure and total * 128 < 2 ** 31:
+        # everything of the fill pass that needs the lists only, + where each (row, neighbour) weight goes: affinity_softmax(into=op)
+        # then completes the operator
+        op.dst = torch.empty((nv, k), dtype=torch.int32, device=dev)
+        check(lib.gp_pool_cs_structure(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
+                                       _ptr(wa_lo), _ptr(op.dst), _stream()), "gp_pool_cs_structure")
+    return op
 
 
 def pool_cs_fill(op, nbr, w):
@@ -482,6 +519,7 @@ def pool_cs_fill(op, nbr, w):
     nv, k = nbr.shape
     check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), int(op.block_rows), _ptr(op.bu_off), op.total, _ptr(op.bu_row),
                               _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo), _stream()), "gp_pool_cs_fill")
+    op.filled = True
     return op
 
 

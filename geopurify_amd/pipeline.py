@@ -57,6 +57,15 @@ class StudentWeights:
             self.num_blocks += 1
         self.w_out = sd["output_layer.kernel"].float().to(device).contiguous()
         self.embed = self.w_out.shape[1]
+        # the 1x1x1 output layer on the same f16 hi/lo operator as the 3x3x3 layers, fused with F.normalize (gp_embed_head_f16x3)
+        self.head = None
+        # (GP_EMBED_HEAD=f32: the exact-fp32 kernel + l2norm_rows_ of rounds 1-3, for A/B timing)
+        if (mode == "f16x3" and self.embed == 128 and self.hidden % 64 == 0 and all(l[0] == "f16x3" for l in self.layers)
+                and os.environ.get("GP_EMBED_HEAD", "f16x3") != "f32"):
+            amax = float(self.w_out.abs().max().item())
+            p2 = 2.0 ** int(np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
+            hi, lo = ops.conv_weights_split(self.w_out.reshape(1, self.hidden, self.embed), p2)
+            self.head = (hi, lo, 1.0 / p2)
 
     @staticmethod
     def _fold(sd, prefix, eps):
@@ -97,22 +106,35 @@ class StudentWeights:
             return y, out_split
         return ops.sparse_conv(x, ctx["nbr_map"], w, scale, shift, residual=residual, relu=True), None
 
-    def forward(self, x, nbr_map, pairs=None):
+    @property
+    def fast(self):
+        """every 3x3x3 layer runs on the f16 hi/lo operator (operands pre-split, LDS-DMA staging)"""
+        return all(l[0] == "f16x3" for l in self.layers)
+
+    def split_input(self, x):
+        """The first layer's operand in the form the fast path stages it: (hi, lo, row_inv_scale) of x[:, :cin_pad].  Needs the voxel
+        means only, so a scheduler can run it ahead (HotPath.prepare)."""
+        return ops.split_f16(x, self.cin_pad, per_row=True) if self.fast else None
+
+    def forward(self, x, nbr_map, pairs=None, x_split=None):
         """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed].
         On the f16x3 path every layer also emits its output pre-split (hi/lo f16) so that the next
-        layer stages both operands by LDS-DMA."""
+        layer stages both operands by LDS-DMA.  x_split: split_input(x) when it was made ahead."""
         ctx = {"nbr_map": nbr_map, "pairs": pairs}
-        fast = all(l[0] == "f16x3" for l in self.layers)
+        fast = self.fast
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
             ctx["pairs"] = ops.conv_pairs_build(nbr_map)
-        xs = ops.split_f16(x, self.cin_pad, per_row=True) if fast else None
+        xs = (x_split if x_split is not None else self.split_input(x)) if fast else None
         h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast)
         for b in range(self.num_blocks):
             t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast, want_f32=not fast)   # conv1 output: next conv only
             last = b == self.num_blocks - 1
-            h, hs = self._conv(2 + 2 * b, t, ctx, residual=h, x_split=ts, want_split=fast and not last)
-        e = ops.sparse_conv(h, None, self.w_out)
+            head = last and fast and self.head is not None          # the output layer reads the split planes only
+            h, hs = self._conv(2 + 2 * b, t, ctx, residual=h, x_split=ts, want_split=fast and (not last or head), want_f32=not head)
         self.last_pairs = ctx["pairs"]
+        if fast and self.head is not None and hs is not None:
+            return ops.embed_head_f16x3(hs[:2], self.head[0], self.head[1], self.head[2], x_row_inv=hs[2], normalize=True)
+        e = ops.sparse_conv(h, None, self.w_out)
         return ops.l2norm_rows_(e)
 
     def flops(self, num_pairs, nv):
@@ -325,6 +347,10 @@ class HotPath:
         # grid search; beyond 2e11 (a scene with views of several hundred thousand visible points) the view-by-view path is taken.
         self.all_views_max_pairs = float(os.environ.get("GP_ALL_VIEWS_MAX_PAIRS", "2e11"))
         self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
+        # `prepare` also builds the pooling operator's structure (gp_pool_cs_structure) so that the affinity kernel writes the
+        # weights in fragment order and no fill pass sits between the student and the pooling (GP_POOL_STRUCTURE_AHEAD=0: the
+        # two-pass form of rounds 3-4, for A/B timing)
+        self.pool_structure_ahead = os.environ.get("GP_POOL_STRUCTURE_AHEAD", "1") != "0"
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
         self.device = torch.device(device)
@@ -502,11 +528,13 @@ class HotPath:
         mark("grid+kernel_map")
         nbr = ops.knn_lattice(grid, cs, perm, self.K)
         mark("kNN")
-        state = {"X": X, "rank": rank, "nbr_map": nbr_map, "pairs": pairs, "nbr": nbr, "Nv": Nv, "D": D, "pool": None}
+        state = {"X": X, "rank": rank, "nbr_map": nbr_map, "pairs": pairs, "nbr": nbr, "Nv": Nv, "D": D, "pool": None,
+                 "xs": st.split_input(X)}                   # the first layer's pre-split operand (per-row scales)
         mode = self._pool_mode(D)
         if mode in ("mfma_cs", "mfma_engine"):
             sc = ops.pow2_scale(X, D)
-            state["pool"] = {"op": ops.pool_cs_plan(nbr), "sc": sc, "x_split": ops.split_f16(X, D, scale=sc[0:1]),
+            state["pool"] = {"op": ops.pool_cs_plan(nbr, structure=self.pool_structure_ahead), "sc": sc,
+                             "x_split": ops.split_f16(X, D, scale=sc[0:1]),
                              "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
             mark("pool plan+split")
         return state
@@ -520,11 +548,13 @@ class HotPath:
         p = prepared if prepared is not None else self.prepare(batch, F)
         X, rank, nbr, Nv, D = p["X"], p["rank"], p["nbr"], p["Nv"], p["D"]
         mark = self.stage_mark if self.stage_mark is not None else (lambda name: None)
-        E = self.student.forward(X, p["nbr_map"], p["pairs"])
+        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"))
         mark("student")
         if after_student is not None:
             after_student()
-        w = ops.affinity_softmax(E, nbr, self.sharpen)
+        # the operator's structure was built ahead: the affinity kernel writes its weights straight into fragment order
+        op = p["pool"]["op"] if p["pool"] is not None else None
+        w = ops.affinity_softmax(E, nbr, self.sharpen, into=op if op is not None and op.dst is not None else None)
         mark("affinity")
         self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12
         out = self._pool(X, nbr, w, Nv, D, plan=p["pool"])
@@ -569,7 +599,7 @@ class HotPath:
                 sc = ops.pow2_scale(X, D)
                 plan = {"op": ops.pool_cs_plan(nbr), "sc": sc, "x_split": ops.split_f16(X, D, scale=sc[0:1]),
                         "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
-            op = ops.pool_cs_fill(plan["op"], nbr, w)
+            op = plan["op"] if plan["op"].filled else ops.pool_cs_fill(plan["op"], nbr, w)
             out = torch.empty((Nv, D), dtype=torch.float32, device=dev)
             sc = plan["sc"]
             sp = [plan["x_split"], plan["pong"]]

@@ -164,6 +164,14 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
 /* chunk_tile_off_host / chunk_pair_off_host = tile_start / seg_off at the chunk boundaries [num_chunks+1]. */
 /* in-place row L2 normalisation, F.normalize(p=2, dim=1, eps=1e-12) (affinity_module.py:1547)     */
 int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
+/* The student's 1x1x1 output convolution (hidden -> 128 embedding channels, affinity_module.py:66,71) on the pre-split rows   */
+/* the last 3x3x3 layer writes, fused with the row normalisation above (:1547) when l2_normalize != 0:                        */
+/* y[r, :] = out_scale * x_row_inv_scale[r] * sum_c (x_hi + x_lo)[r, c] * (w_hi + w_lo)[:, c]   (three exact f16 products per  */
+/* element, fp32 accumulation, fixed order).  w_hi / w_lo f16 [cout, cin] from gp_conv_weights_split(kv = 1, scale 2^k),       */
+/* out_scale = 2^-k; x_row_inv_scale nullable (unscaled planes).  cout = 128, cin a multiple of 64.                            */
+int gp_embed_head_f16x3(const void *x_hi, const void *x_lo, int64_t ld_x, const float *x_row_inv_scale, const void *w_hi,
+                        const void *w_lo, int64_t nv, int32_t cin, int32_t cout, float out_scale, int32_t l2_normalize,
+                        float *y, int64_t ld_y, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row 10: faiss.IndexFlatL2.search(K+1) on integer voxel coordinates, self dropped              */
@@ -179,6 +187,11 @@ int gp_knn_lattice(const void *grid, const int32_t *coords, const int32_t *ids, 
 /* w[i,j] = softmax_j( sharpen * <E_i, E_nbr[i,j]> ),  E fp32 [nv, ld_e], first d columns.         */
 int gp_affinity_softmax(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k,
                         int64_t nv, float sharpen, float *w, void *stream);
+/* The same weights, written to w AND -- x 2^10, split hi + lo -- to element dst[i * k + j] of the pooling operator's fragment   */
+/* arrays (dst, wa_hi, wa_lo from gp_pool_cs_structure): the value gp_pool_cs_fill would read back from w, so the operator has  */
+/* the same bits and no fill pass runs between the student and the 19 applications.                                          */
+int gp_affinity_softmax_scatter(const float *e, int64_t ld_e, int32_t d, const int32_t *nbr, int32_t k, int64_t nv,
+                                float sharpen, float *w, const int32_t *dst, void *wa_hi, void *wa_lo, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row 12: one application of the row-stochastic affinity operator, torch.sparse.mm(A, X)        */
@@ -249,6 +262,12 @@ int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per
                      void *workspace, size_t workspace_bytes, void *stream);
 int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
                     int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream);
+/* gp_pool_cs_fill without the weights: bu_row, bu_mask, zeroed fragments and dst i32 [nv, k] = the element of wa_hi / wa_lo that  */
+/* (row, neighbour j) owns; gp_affinity_softmax_scatter completes the operator.  Needs the neighbour lists only (a scheduler runs */
+/* it ahead, like gp_pool_cs_count).  total_rows * 128 must fit 32 bits (else: gp_pool_cs_fill).                               */
+int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
+                         int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, int32_t *dst,
+                         void *stream);
 int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                      const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                      int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,

@@ -16,3 +16,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _seeded_torch(request):
+    """Every test starts from a torch generator state that depends on its own name only (CPU and GPU generators): a test that draws
+    with torch.randn(...) sees the same numbers whichever tests ran before it (round 4: a tolerance at the edge passed or failed with
+    the selection of tests on the command line)."""
+    import zlib
+
+    import torch
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield

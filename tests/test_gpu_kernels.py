@@ -685,6 +685,42 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
         assert torch.equal(yg, y), g
 
 
+def test_embed_head_f16x3_matches_fp64_and_the_fp32_kernel(ops):
+    """The student's 1x1x1 output layer + F.normalize in one kernel on pre-split rows (affinity_module.py:66,71,1547): fp32-class
+    accuracy against fp64, the error class of the exact-fp32 kernel + l2norm_rows_ it replaces; ragged row count, an all-zero row
+    (F.normalize: 0 / max(0, 1e-12) = 0), wide dynamic range across rows (the per-row scales)."""
+    from geopurify_amd._lib import GeoPurifyHipError
+    g = torch.Generator().manual_seed(21)
+    nv, cin, cout = 2500 + 37, 512, 128
+    X = torch.relu(torch.randn(nv, cin, generator=g)) * torch.exp(torch.randn(nv, 1, generator=g) * 3.0)
+    X[17] = 0.0
+    W = torch.randn(cin, cout, generator=g) * 0.04
+    p2 = 2.0 ** int(np.floor(np.log2(16384.0 / float(W.abs().max()))))
+    hi, lo = ops.conv_weights_split(dev(W.reshape(1, cin, cout)), p2)
+    xs = ops.split_f16(dev(X), cin, per_row=True)
+    e = ops.embed_head_f16x3(xs[:2], hi, lo, 1.0 / p2, x_row_inv=xs[2])
+    ref = X.double() @ W.double()
+    refn = ref / ref.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    err = (e.cpu().double() - refn).abs().max().item()
+    e32 = ops.l2norm_rows_(ops.sparse_conv(dev(X), None, dev(W)))
+    err32 = (e32.cpu().double() - refn).abs().max().item()
+    assert err < 2e-6 and err < 4 * err32 + 5e-7, (err, err32)
+    assert torch.equal(e[17], torch.zeros(cout, device="cuda"))
+    assert (e.norm(dim=1).cpu() - 1.0).abs()[torch.arange(nv) != 17].max() < 1e-6
+    # without the normalisation: the plain product, relative to the row's magnitude
+    y = ops.embed_head_f16x3(xs[:2], hi, lo, 1.0 / p2, x_row_inv=xs[2], normalize=False)
+    rel = ((y.cpu().double() - ref).abs().max(dim=1).values / ref.abs().max(dim=1).values.clamp_min(1e-30))
+    assert rel[torch.arange(nv) != 17].max() < 4e-6, rel.max()
+    # bitwise repeatable, and independent of how many rows share a launch (rows 0..1279 alone = the same bits)
+    assert torch.equal(ops.embed_head_f16x3(xs[:2], hi, lo, 1.0 / p2, x_row_inv=xs[2]), e)
+    part = ops.embed_head_f16x3((xs[0][:1280], xs[1][:1280]), hi, lo, 1.0 / p2, x_row_inv=xs[2][:1280])
+    assert torch.equal(part, e[:1280])
+    with pytest.raises(GeoPurifyHipError, match="embedding channels"):
+        ops.embed_head_f16x3(xs[:2], hi[:, :64].contiguous(), lo[:, :64].contiguous(), 1.0 / p2)
+    with pytest.raises(ValueError):
+        ops.embed_head_f16x3((xs[0][:, :256].contiguous(), xs[1][:, :256].contiguous()), hi, lo, 1.0 / p2)
+
+
 # ------------------------------------------------------------------------------------------ row 12 fast path
 @pytest.mark.parametrize("R", [4, 8, 16])
 def test_pool_tiles_matches_ell_and_oracle(ops, R):
@@ -897,6 +933,21 @@ def test_pool_cs_matches_ell_and_oracle(ops, n_vox, rpb):
     o3 = torch.empty((Nv, D), device="cuda")
     ops.pool_cs_apply(sp[0], op, D, out_f32=o3)
     assert torch.equal(o2, o3)
+    # the operator built in the other order -- structure first (lists only), weights written in place by the affinity kernel --
+    # is the same operator: same weights, same union rows and masks, same bits out of an application
+    op2 = ops.pool_cs_plan(nbr, rows_per_block=rpb, structure=True)
+    assert op2.dst is not None and not op2.filled
+    w2 = ops.affinity_softmax(dev(E), nbr, 20.0, into=op2)
+    assert op2.filled and torch.equal(w2, w)
+    assert torch.equal(op2.bu_row, op.bu_row) and torch.equal(op2.bu_mask, op.bu_mask) and torch.equal(op2.bu_off, op.bu_off)
+    dstc = op2.dst.cpu().long()
+    assert dstc.min() >= 0 and dstc.max() < op2.wa_hi.numel() and dstc.unique().numel() == dstc.numel()   # one element per (row, j)
+    assert torch.equal(op2.wa_hi[op2.dst.long()], op.wa_hi[op2.dst.long()]) and torch.equal(op2.wa_lo[op2.dst.long()], op.wa_lo[op2.dst.long()])
+    o4 = torch.empty((Nv, D), device="cuda")
+    ops.pool_cs_apply(sp[0], op2, D, out_f32=o4)
+    assert torch.equal(o4, o3)
+    with pytest.raises(ValueError):
+        ops.affinity_softmax(dev(E), nbr[:-1].contiguous(), 20.0, into=op2)
 
 
 @pytest.mark.parametrize("n_vox,K", [(130, 96), (70, 32), (257, 32), (65, 8), (129, 1)])

@@ -143,7 +143,7 @@ def test_small_magnitude_inputs_keep_relative_accuracy(env):
     assert err0 > 4 * err                                             # the unscaled split is visibly worse on such inputs
     # pooling: 19 applications on features of magnitude ~1e-3, relative to the pooled magnitude
     nbr = ops.knn_lattice(grid, cs, perm, K)
-    E = torch.nn.functional.normalize(torch.randn(Nv, 128, device="cuda"), dim=1)
+    E = torch.nn.functional.normalize(torch.from_numpy(rng.normal(0, 1, size=(Nv, 128)).astype(np.float32)).cuda(), dim=1)   # (seeded)
     w = ops.affinity_softmax(E, nbr, 20.0)
     F = torch.zeros((Nv, 544), device="cuda")
     F[:, :512] = torch.from_numpy((rng.normal(0, 1, size=(Nv, 512)) * 1e-3).astype(np.float32)).cuda()
@@ -152,4 +152,6 @@ def test_small_magnitude_inputs_keep_relative_accuracy(env):
         hp = pl.HotPath(None, (8, 8), K=K, num_iters=T, device="cuda", pool_mode=mode)
         Y = hp._pool(F, nbr, w, Nv, 512)
         rel = (Y.cpu().double() - ref_p).abs().max().item() / ref_p.abs().max().item()
-        assert rel <= 2e-6, (mode, rel)
+        # bound: 19 applications x 2^-22 per hi + lo split = 4.5e-6; measured 1.5e-6 .. 2.3e-6 over unseeded embeddings (rounds 3-4:
+        # the draw used to come from torch's global generator, so the figure depended on which tests ran before)
+        assert rel <= 3e-6, (mode, rel)
