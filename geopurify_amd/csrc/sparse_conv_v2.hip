@@ -811,7 +811,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     // of making an HBM round trip; `partial` then only needs room for the largest chunk.
     // Measured and left out: pipelining the chunks over helper streams (phase 2 of chunk c beside phase 1 of chunk c+1, two
     // partial slots) -- 2.13 vs 2.07 ms per 512->512 layer: phase 1 is co-limited by its own L2 traffic (A gather + weight
-    // tiles + partial stores), so a memory-bound neighbour only takes bandwidth from it.
+    // tiles + partial stores), so a memory-bound neighbour only takes bandwidth from it.  Round 4, again with both slots inside the
+    // Infinity Cache (scripts/conv_pipeline_probe.py, profiles/r04_conv_pipelined_chunks.log): 8192-row chunks 2.08 vs 1.89 ms,
+    // 6144 rows 2.26 vs 2.23, 4096 rows 2.82 vs 2.72 -- slower at every height, same bits; the 2 x 17 cross-stream event waits cost
+    // more than phase 2's 25 us launches hide.
     // chunk tables (host copies of the per-chunk tile / pair offsets) give EXACT tile counts; without them tile_count is an
     // upper bound and only the one-tile-per-workgroup kernels (which test tile_start[nseg] on the device) may run
     // (The round-2 fault -- a memory access fault in scripts/bench_conv.py and an abort in the unchunked case of
