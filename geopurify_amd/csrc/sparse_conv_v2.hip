@@ -22,6 +22,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
 #include "gp_common.h"
 
 namespace {
@@ -524,18 +526,24 @@ __device__ __forceinline__ void conv_gather_sum2(const float *__restrict__ P, in
     }
 }
 // phase 2: one wave per output voxel; lanes hold 2 x float4 of the 512 (or cout) channels
-__global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *__restrict__ pair_pos, int64_t nv, int kv,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) conv_phase2_kernel(const float *__restrict__ P, const int32_t *__restrict__ pair_pos, int64_t nv, int kv,
                                    int cout, const float *__restrict__ scale, const float *__restrict__ shift,
                                    const float *__restrict__ residual, int64_t ld_res, int relu,
                                    float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ y_hi,
                                    _Float16 *__restrict__ y_lo, int64_t ld_yh, int64_t row_begin, int64_t row_count,
                                    int pair_base, float *__restrict__ y_inv_scale) {
-    int64_t u = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    if (u >= row_count) return;
-    u += row_begin;
-    if (u >= nv) return;
-    int lane = gp_lane();
-    int mypos = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    // Waves walk the chunk's rows with a stride of the whole grid (row w, w + W, ...), the NEXT row's 27 positions loaded while this
+    // row's partial rows are gathered: the host sizes the grid to what is resident at once (6 waves per SIMD at 80 registers), so
+    // that a chunk is not one full round of waves plus a third of one, and the position -> rows dependency is paid once per wave.
+    const int lane = gp_lane();
+    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t row_end = (row_begin + row_count < nv) ? row_begin + row_count : nv;
+    int64_t u = row_begin + wave0;
+    if (u >= row_end) return;
+    int mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    for (; u < row_end; u += n_waves) {
+    const int mypos = mypos_next;
+    if (u + n_waves < row_end) mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u + n_waves] : -1;
     if (y_inv_scale && y_hi && cout <= 1024) {
         // pre-split output with a per-row power of two: hi + lo = y * 2^e, 2^e chosen so that the row's largest magnitude
         // lands in [2^13, 2^14) -- every element within 2^-18 of it keeps a NORMAL f16 lo half, i.e. the full 2^-22 relative
@@ -578,7 +586,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
                 *reinterpret_cast<f16x4 *>(y_lo + u * ld_yh + c) = l;
             }
         }
-        return;
+        continue;
     }
     for (int c = lane * 4; c < cout; c += 256) {
         float4 a = conv_gather_sum<GS_NL>(P, mypos, kv, cout, c, pair_base);
@@ -601,6 +609,7 @@ __global__ void conv_phase2_kernel(const float *__restrict__ P, const int32_t *_
             *reinterpret_cast<f16x4 *>(y_lo + u * ld_yh + c) = l;
         }
     }
+    }   // rows of this wave
 }
 
 // fp32 rows -> hi/lo f16 rows with a power-of-two pre-scale: global (device scalar `scale`, from gp_pow2_scale) or per row
@@ -828,6 +837,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                  "gp_sparse_conv_f16x3: %d chunks of %d rows do not cover nv=%lld", num_chunks, chunk_rows, (long long)nv);
     const bool chunked = num_chunks >= 1;
     const int nchunk = chunked ? num_chunks : 1;
+    static const int p2_wg_per_cu = [] { const char *e = getenv("GP_CONV_P2_WG_PER_CU"); return e ? atoi(e) : 6; }();
     // Measured and left out (round 2): a persistent phase 1 (one workgroup per CU, 3-deep ring for the gathered rows issued two
     // steps ahead, weight tiles one step ahead, split staging roles, rings and epilogue stores running through tile boundaries,
     // swapped MFMA operands for 16-byte partial stores): bit-identical results, 1.99 vs 1.96 ms per 512->512 layer.  Its
@@ -864,7 +874,9 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
             }
 #undef P1_ARGS
         }
-        conv_phase2_kernel<<<(unsigned)((row_count * 64 + 255) / 256), 256, 0, s>>>(
+        // one resident round: 6 workgroups of 4 waves per CU (80 registers per lane); GP_CONV_P2_WG_PER_CU for the sweep
+        const int64_t p2_full = (row_count * 64 + 255) / 256, p2_res = (int64_t)gp_cu_count() * p2_wg_per_cu;
+        conv_phase2_kernel<<<(unsigned)((p2_res > 0 && p2_res < p2_full) ? p2_res : p2_full), 256, 0, s>>>(
             partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
             static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale);
     }
