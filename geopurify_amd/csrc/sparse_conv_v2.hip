@@ -45,36 +45,91 @@ __device__ __forceinline__ int sw_slot(int row, int slot) {
 // Pairs are ordered by (chunk of CH Morton-consecutive output rows, offset k, output row): a chunk's
 // 27 offset segments gather from the same few thousand input rows, so the A operand stays in the
 // XCD's L2 while the chunk is processed (k-major order re-read every input row ~7x from beyond L2).
-__device__ __forceinline__ void pair_decode(int64_t i, int64_t nv, int kv, int ch, int &c, int &k, int64_t &u) {
-    int64_t per = (int64_t)kv * ch;
-    c = (int)(i / per);
-    int64_t rem = i - (int64_t)c * per;
-    int64_t rows_c = nv - (int64_t)c * ch < ch ? nv - (int64_t)c * ch : ch;
+// (the chunks are given by their row offsets R[0 .. nchunks], R[0] = 0, R[nchunks] = nv: equal heights, or heights chosen so that
+// every chunk is a whole number of rounds of phase-1 tiles -- gp_conv_chunk_plan)
+__device__ __forceinline__ void pair_decode(int64_t i, int kv, const int32_t *__restrict__ R, int nchunks, int &c, int &k, int64_t &u) {
+    const int row_q = (int)(i / kv);                          // chunk c starts at pair slot kv * R[c]
+    int lo = 0, hi = nchunks - 1;
+    while (lo < hi) {                                         // last c with R[c] <= row_q
+        const int mid = (lo + hi + 1) >> 1;
+        if (R[mid] <= row_q) lo = mid; else hi = mid - 1;
+    }
+    c = lo;
+    const int64_t r0 = R[c], rows_c = R[c + 1] - r0;
+    const int64_t rem = i - (int64_t)kv * r0;
     k = (int)(rem / rows_c);
-    u = (int64_t)c * ch + (rem - (int64_t)k * rows_c);
+    u = r0 + (rem - (int64_t)k * rows_c);
 }
-__global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t nv, int kv, int ch, int32_t *__restrict__ f) {
+__global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t nv, int kv, const int32_t *__restrict__ R, int nchunks,
+                                  int32_t *__restrict__ f) {
     int64_t total = (int64_t)kv * nv;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= total) return;
     int c, k; int64_t u;
-    pair_decode(i, nv, kv, ch, c, k, u);
+    pair_decode(i, kv, R, nchunks, c, k, u);
     f[i] = nm[(int64_t)k * nv + u] >= 0 ? 1 : 0;
 }
-__global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *__restrict__ sc, int64_t nv, int kv, int ch,
-                                 int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_pos,
+__global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *__restrict__ sc, int64_t nv, int kv,
+                                 const int32_t *__restrict__ R, int nchunks, int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_pos,
                                  int32_t *__restrict__ seg_off /*[nseg+1]*/) {
     int64_t total = (int64_t)kv * nv;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= total) return;
     int c, k; int64_t u;
-    pair_decode(i, nv, kv, ch, c, k, u);
+    pair_decode(i, kv, R, nchunks, c, k, u);
     int in = nm[(int64_t)k * nv + u];
     int s = sc[i];
     pair_pos[(int64_t)k * nv + u] = in >= 0 ? s : -1;
     if (in >= 0) pair_in[s] = in;
-    if (u == (int64_t)c * ch) seg_off[c * kv + k] = s;           // first row of the (chunk, offset) segment
+    if (u == (int64_t)R[c]) seg_off[c * kv + k] = s;             // first row of the (chunk, offset) segment
     if (i == total - 1) seg_off[(c + 1) * kv] = s + (in >= 0 ? 1 : 0);
+}
+// ---- chunk heights chosen for the phase-1 launch: per granule of rows and offset, the number of pairs; then ONE wave walks the
+// granules (lane = offset) and closes a chunk when its tile count -- sum over offsets of ceil(pairs / TM), times the column tiles --
+// would pass the target (a whole number of rounds of one-tile workgroups on the chip)
+__global__ void chunk_count_kernel(const int32_t *__restrict__ nm, int64_t nv, int kv, int granule, int32_t *__restrict__ cnt /*[ngran][32]*/) {
+    const int g = blockIdx.x, k = blockIdx.y;
+    const int64_t r0 = (int64_t)g * granule, r1 = r0 + granule < nv ? r0 + granule : nv;
+    int c = 0;
+    for (int64_t u = r0 + threadIdx.x; u < r1; u += blockDim.x) c += nm[(int64_t)k * nv + u] >= 0;
+    c = gp_wave_sum(c);
+    __shared__ int s_c[4];
+    if (gp_lane() == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[g * 32 + k] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+// (256 threads stage windows of 512 granules' counts in LDS as u16 -- a count is at most the granule's rows -- and wave 0 walks them:
+// a dependent global load per granule made this one-wave loop 0.23 ms on the S scene)
+constexpr int CP_WIN = 512;
+__global__ void __launch_bounds__(256)
+chunk_plan_kernel(const int32_t *__restrict__ cnt, int ngran, int kv, int granule, int64_t nv, int col_tiles, int target,
+                  int max_chunks, int32_t *__restrict__ R, int32_t *__restrict__ n_chunks) {
+    __shared__ unsigned short s_cnt[CP_WIN * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int sum = 0, nc = 0, start_g = 0;
+    if (tid == 0) R[0] = 0;
+    for (int g0 = 0; g0 < ngran; g0 += CP_WIN) {
+        const int n = ngran - g0 < CP_WIN ? ngran - g0 : CP_WIN;
+        __syncthreads();
+        for (int i = tid; i < n * 32; i += 256) s_cnt[i] = (unsigned short)((i & 31) < kv ? cnt[(int64_t)g0 * 32 + i] : 0);
+        __syncthreads();
+        if (tid < 64) {
+            for (int gl = 0; gl < n; ++gl) {
+                const int g = g0 + gl;
+                const int add = lane < 32 ? s_cnt[gl * 32 + lane] : 0;
+                const int tiles_with = gp_wave_sum_i((sum + add + TM - 1) / TM) * col_tiles;
+                if (tiles_with > target && g != start_g && nc + 1 < max_chunks) {      // close the chunk in front of this granule
+                    ++nc;
+                    if (lane == 0) R[nc] = g * granule;
+                    sum = add;
+                    start_g = g;
+                } else {
+                    sum += add;
+                }
+            }
+        }
+    }
+    if (tid == 0) { R[nc + 1] = (int32_t)nv; n_chunks[0] = nc + 1; }
 }
 // one descriptor per 256-pair tile: {offset k, first pair, pair count} -- a single 16-byte load in the
 // GEMM prologue instead of a dependent binary search over tile_start
@@ -723,12 +778,12 @@ extern "C" size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv) {
     return cv.off;
 }
 
-extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t chunk_rows, int32_t *pair_in,
-                                   int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start, int32_t *tile_desc,
+extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t num_chunks, const int32_t *chunk_row_off,
+                                   int32_t *pair_in, int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start, int32_t *tile_desc,
                                    void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(nbr_map && pair_in && pair_pos && seg_off && tile_start && tile_desc && workspace && nv > 0 && kv > 0, "gp_conv_pairs_build: null/empty argument");
     GP_CHECK_ARG((int64_t)kv * nv < (1ll << 31), "gp_conv_pairs_build: kernel map too large");
-    GP_CHECK_ARG(chunk_rows >= TM, "gp_conv_pairs_build: chunk_rows=%d must be >= %d", chunk_rows, TM);
+    GP_CHECK_ARG(num_chunks >= 1 && chunk_row_off, "gp_conv_pairs_build: num_chunks=%d needs the chunk row offsets (device, [num_chunks + 1], 0 .. nv ascending)", num_chunks);
     int64_t total = (int64_t)kv * nv;
     GpCarver cv(workspace, workspace_bytes);
     int32_t *f = cv.take<int32_t>(total), *sc = cv.take<int32_t>(total);
@@ -737,12 +792,35 @@ extern "C" int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t k
     if (!cv.ok()) { gp_set_error("gp_conv_pairs_build: workspace too small (%zu < %zu)", workspace_bytes, cv.off); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     int blocks = (int)((total + 255) / 256);
-    int nseg = (int)((nv + chunk_rows - 1) / chunk_rows) * kv;
-    pair_flags_kernel<<<blocks, 256, 0, s>>>(nbr_map, nv, kv, chunk_rows, f);
+    int nseg = num_chunks * kv;
+    pair_flags_kernel<<<blocks, 256, 0, s>>>(nbr_map, nv, kv, chunk_row_off, num_chunks, f);
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, f, sc, (int32_t)0, (size_t)total, rocprim::plus<int32_t>(), s));
-    pair_emit_kernel<<<blocks, 256, 0, s>>>(nbr_map, sc, nv, kv, chunk_rows, pair_in, pair_pos, seg_off);
+    pair_emit_kernel<<<blocks, 256, 0, s>>>(nbr_map, sc, nv, kv, chunk_row_off, num_chunks, pair_in, pair_pos, seg_off);
     tile_start_kernel<<<1, 64, 0, s>>>(seg_off, nseg, tile_start);
     tile_desc_kernel<<<(nseg + 255) / 256, 256, 0, s>>>(seg_off, tile_start, nseg, kv, reinterpret_cast<int4 *>(tile_desc));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// Chunk heights for gp_conv_pairs_build chosen from the kernel map: chunks are closed at multiples of granule_rows so that a chunk's
+// phase-1 launch -- sum over the offsets of ceil(pairs / 256) row tiles, times col_tiles column tiles -- stays within target_tiles
+// (2 x the CU count: two rounds of one-tile workgroups; equal heights leave 4-8 % of the tile slots of their rounds empty).
+// chunk_row_off i32 [max_chunks + 1] and n_chunks i32 [1] are device outputs (read back by the caller to size the pair arrays).
+extern "C" size_t gp_conv_chunk_plan_workspace_bytes(int64_t nv, int32_t granule_rows) {
+    if (nv <= 0 || granule_rows <= 0) return 0;
+    return (size_t)((nv + granule_rows - 1) / granule_rows) * 32 * sizeof(int32_t);
+}
+extern "C" int gp_conv_chunk_plan(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t granule_rows, int32_t col_tiles,
+                                  int32_t target_tiles, int32_t max_chunks, int32_t *chunk_row_off, int32_t *n_chunks, void *workspace,
+                                  size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(nbr_map && chunk_row_off && n_chunks && workspace && nv > 0 && kv > 0 && kv <= 32, "gp_conv_chunk_plan: null/empty argument");
+    GP_CHECK_ARG(granule_rows >= 64 && granule_rows <= 65535 && col_tiles >= 1 && target_tiles >= col_tiles && max_chunks >= 1, "gp_conv_chunk_plan: bad sizes");
+    const int64_t ngran = (nv + granule_rows - 1) / granule_rows;
+    GP_CHECK_ARG(workspace_bytes >= gp_conv_chunk_plan_workspace_bytes(nv, granule_rows), "gp_conv_chunk_plan: workspace too small");
+    hipStream_t s = gp_stream(stream_);
+    int32_t *cnt = static_cast<int32_t *>(workspace);
+    chunk_count_kernel<<<dim3((unsigned)ngran, (unsigned)kv), 256, 0, s>>>(nbr_map, nv, kv, granule_rows, cnt);
+    chunk_plan_kernel<<<1, 256, 0, s>>>(cnt, (int)ngran, kv, granule_rows, nv, col_tiles, target_tiles, max_chunks, chunk_row_off, n_chunks);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -794,7 +872,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                                     const float *scale, const float *shift, const float *residual, int64_t ld_res,
                                     int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
-                                    int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
+                                    int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
                                     const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
                                     void *stream_) {
     GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && tile_desc && nseg > 0 && w_hi && w_lo && partial && (y || y_hi), "gp_sparse_conv_f16x3: null argument");
@@ -832,11 +910,15 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     // test_f16x3_student_chain_vs_fp64_oracle -- was an experimental persistent phase 1 that walked tile_count tiles without
     // that device-side test; it was removed in 27fdcb6.  Every kernel launched here tests `mt >= tile_start[nseg]`.)
     // Half-specified chunking is an error, not a silent fall-back to the upper bound: the caller sized `partial` for chunks.
-    GP_CHECK_ARG((num_chunks >= 1) == (chunk_tile_off_host != nullptr) && (num_chunks >= 1) == (chunk_pair_off_host != nullptr),
-                 "gp_sparse_conv_f16x3: num_chunks=%d needs BOTH host chunk tables (tile and pair offsets), num_chunks=0 needs neither",
+    GP_CHECK_ARG((num_chunks >= 1) == (chunk_tile_off_host != nullptr) && (num_chunks >= 1) == (chunk_pair_off_host != nullptr) &&
+                     (num_chunks >= 1) == (chunk_row_off_host != nullptr),
+                 "gp_sparse_conv_f16x3: num_chunks=%d needs ALL THREE host chunk tables (row, tile and pair offsets), num_chunks=0 needs none",
                  num_chunks);
-    GP_CHECK_ARG(num_chunks < 1 || (chunk_rows >= TM && (int64_t)num_chunks * chunk_rows >= nv),
-                 "gp_sparse_conv_f16x3: %d chunks of %d rows do not cover nv=%lld", num_chunks, chunk_rows, (long long)nv);
+    if (num_chunks >= 1) {
+        bool rows_ok = chunk_row_off_host[0] == 0 && chunk_row_off_host[num_chunks] == nv;
+        for (int c = 0; c < num_chunks && rows_ok; ++c) rows_ok = chunk_row_off_host[c + 1] > chunk_row_off_host[c];
+        GP_CHECK_ARG(rows_ok, "gp_sparse_conv_f16x3: the %d chunk row offsets do not cover rows 0 .. %lld in ascending order", num_chunks, (long long)nv);
+    }
     const bool chunked = num_chunks >= 1;
     const int nchunk = chunked ? num_chunks : 1;
     static const int p2_wg_per_cu = [] { const char *e = getenv("GP_CONV_P2_WG_PER_CU"); return e ? atoi(e) : 6; }();
@@ -850,8 +932,8 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         int tile_begin = chunked ? chunk_tile_off_host[c] : 0;
         int tile_count = chunked ? chunk_tile_off_host[c + 1] - tile_begin : (int)(num_pairs / TM + nseg);
         int pair_base = chunked ? chunk_pair_off_host[c] : 0;
-        int64_t row_begin = chunked ? (int64_t)c * chunk_rows : 0;
-        int64_t row_count = chunked ? ((row_begin + chunk_rows < nv) ? chunk_rows : nv - row_begin) : nv;
+        int64_t row_begin = chunked ? chunk_row_off_host[c] : 0;
+        int64_t row_count = chunked ? chunk_row_off_host[c + 1] - row_begin : nv;
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
             const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits

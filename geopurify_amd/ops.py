@@ -4,6 +4,7 @@ Every function takes/returns torch CUDA tensors but hands the library raw device
 and the current HIP stream.  PyTorch is plumbing here: allocation and stream ownership only.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -198,7 +199,15 @@ class ConvPairs:
         self.pair_in, self.pair_pos, self.pair_off, self.tile_start = pair_in, pair_pos, seg_off, tile_start
         self.nseg, self.num_pairs, self.nv = nseg, num_pairs, nv
         self.partial = None
-        self.chunk_rows, self.num_chunks, self.chunk_tile_off, self.chunk_pair_off = 0, 0, None, None   # 0 = not chunked
+        self.num_chunks, self.chunk_row_off, self.chunk_tile_off, self.chunk_pair_off = 0, None, None, None   # 0 = not chunked
+
+    def _set_chunks(self, rows, tiles, pairs):
+        n = len(rows) - 1
+        self.num_chunks = n
+        self.chunk_row_off = (ctypes.c_int32 * (n + 1))(*rows)
+        self.chunk_tile_off = (ctypes.c_int32 * (n + 1))(*tiles)
+        self.chunk_pair_off = (ctypes.c_int32 * (n + 1))(*pairs)
+        self.max_chunk_pairs = max(pairs[i + 1] - pairs[i] for i in range(n))
 
     def regroup(self, g):
         """The same pair ORDER (chunk-major: a chunk's 27 offset segments gather from the same few thousand input rows, which
@@ -210,45 +219,65 @@ class ConvPairs:
         cp.tile_desc = self.tile_desc
         n = self.num_chunks
         idx = list(range(0, n, g)) + [n]
-        po, to = list(self.chunk_pair_off), list(self.chunk_tile_off)
-        cp.chunk_rows, cp.num_chunks = self.chunk_rows * g, len(idx) - 1
-        cp.chunk_pair_off = (ctypes.c_int32 * len(idx))(*[po[i] for i in idx])
-        cp.chunk_tile_off = (ctypes.c_int32 * len(idx))(*[to[i] for i in idx])
-        cp.max_chunk_pairs = max(po[idx[i + 1]] - po[idx[i]] for i in range(len(idx) - 1))
+        ro, po, to = list(self.chunk_row_off), list(self.chunk_pair_off), list(self.chunk_tile_off)
+        cp._set_chunks([ro[i] for i in idx], [to[i] for i in idx], [po[i] for i in idx])
         return cp
 
 
-def conv_pairs_build(nbr_map, chunk_rows=8192):
-    """nbr_map i32 [27,nv] -> ConvPairs.  One host sync (number of pairs, to size the partial buffer).
-    chunk_rows: pairs are ordered chunk-major and phase 1 / phase 2 run chunk by chunk, so the partial
-    buffer only holds one chunk.  Round 4 on the S scene (profiles/r04_conv_launch_groups.log), per 512->512 layer:
-    8192-row chunks (17 launches, 128 MB of partial rows -- inside the Infinity Cache) 1.87 ms, 16384 rows (the earlier
-    default, 250 MB) 1.96 ms, 4096 rows 2.65 ms (33 launches: too many partly filled last rounds); several chunks per
-    launch (ConvPairs.regroup) never wins.  None = one chunk."""
+# phase-1 tiles per chunk launch of the balanced chunking: None = two rounds of one-tile workgroups = 2 x the CU count (512 on MI355X)
+CONV_TARGET_TILES = int(os.environ["GP_CONV_TARGET_TILES"]) if os.environ.get("GP_CONV_TARGET_TILES") else None
+
+
+def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
+    """nbr_map i32 [27,nv] -> ConvPairs.  Pairs are ordered chunk-major and phase 1 / phase 2 run chunk by chunk, so the partial
+    buffer only holds one chunk.  chunk_rows:
+      "balanced" (default): chunk heights chosen on the device from the kernel map (gp_conv_chunk_plan) so that every chunk's
+          phase-1 launch is at most 2 x CUs tiles = two full rounds of workgroups (col_tiles = cout / 256 column tiles
+          per row tile); two host syncs (the plan, the pair bounds);
+      an int: equal heights.  Round 4 on the S scene (profiles/r04_conv_launch_groups.log), per 512->512 layer: 8192 rows (17
+          launches, 128 MB of partial rows -- inside the Infinity Cache) 1.87 ms, 16384 rows (250 MB) 1.96 ms, 4096 rows 2.65 ms;
+          a layer's time follows the rounds of 256 tiles its launches need (profiles/r04_conv_rounds.log); several chunks per
+          launch (ConvPairs.regroup) never wins;  None = one chunk.  One host sync."""
     lib = _lib.load()
     kv, nv = nbr_map.shape
     dev = nbr_map.device
-    chunk_rows = nbr_map.shape[1] if chunk_rows is None else max(int(chunk_rows), 256)
-    chunk_rows = max(chunk_rows, 256)
-    nseg = ((nv + chunk_rows - 1) // chunk_rows) * kv
+    if isinstance(chunk_rows, str):
+        if chunk_rows != "balanced":
+            raise ValueError(f"conv_pairs_build: chunk_rows={chunk_rows!r}")
+        if os.environ.get("GP_CONV_CHUNK_ROWS"):                      # A/B timing: equal heights instead (8192 = rounds 3-4)
+            chunk_rows = int(os.environ["GP_CONV_CHUNK_ROWS"])
+    if isinstance(chunk_rows, str):
+        granule = 256
+        max_chunks = (nv + granule - 1) // granule
+        plan = torch.empty(max_chunks + 2, dtype=torch.int32, device=dev)          # [0 .. max_chunks]: row offsets, [-1]: count
+        ws = _ws(lib.gp_conv_chunk_plan_workspace_bytes(nv, granule), dev)
+        target = CONV_TARGET_TILES or 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+        check(lib.gp_conv_chunk_plan(_ptr(nbr_map), nv, kv, granule, int(col_tiles), int(target), max_chunks, _ptr(plan),
+                                     _ptr(plan[max_chunks + 1:]), _ptr(ws), ws.numel(), _stream()), "gp_conv_chunk_plan")
+        host = plan.cpu().tolist()                                                   # host sync 1 of 2
+        nchunks = host[max_chunks + 1]
+        rows = host[:nchunks + 1]
+        row_off = plan[:nchunks + 1]
+    else:
+        ch = nv if chunk_rows is None else max(int(chunk_rows), 256)
+        rows = list(range(0, nv, ch)) + [nv]
+        nchunks = len(rows) - 1
+        row_off = torch.tensor(rows, dtype=torch.int32, device=dev)
+    nseg = nchunks * kv
     ws = _ws(lib.gp_conv_pairs_workspace_bytes(nv, kv), dev)
     pair_in = torch.empty(kv * nv, dtype=torch.int32, device=dev)
     pair_pos = torch.empty((kv, nv), dtype=torch.int32, device=dev)
     seg_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     tile_start = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     tile_desc = torch.empty(((kv * nv) // 256 + nseg + 1, 4), dtype=torch.int32, device=dev)
-    check(lib.gp_conv_pairs_build(_ptr(nbr_map), nv, kv, chunk_rows, _ptr(pair_in), _ptr(pair_pos), _ptr(seg_off),
+    check(lib.gp_conv_pairs_build(_ptr(nbr_map), nv, kv, nchunks, _ptr(row_off), _ptr(pair_in), _ptr(pair_pos), _ptr(seg_off),
                                   _ptr(tile_start), _ptr(tile_desc), _ptr(ws), ws.numel(), _stream()), "gp_conv_pairs_build")
-    nchunks = nseg // kv
-    bounds = torch.stack([seg_off[::kv], tile_start[::kv]]).cpu().tolist()     # the one host sync of this call
+    bounds = torch.stack([seg_off[::kv], tile_start[::kv]]).cpu().tolist()     # the host sync of this call (number of pairs)
     num_pairs = bounds[0][-1]
     cp = ConvPairs(pair_in, pair_pos, seg_off, tile_start, nseg, num_pairs, nv)
     cp.tile_desc = tile_desc
-    # host copies of the chunk boundaries (exact tile / pair counts per chunk; a single chunk included)
-    cp.chunk_rows, cp.num_chunks = chunk_rows, nchunks
-    cp.chunk_pair_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[0])
-    cp.chunk_tile_off = (ctypes.c_int32 * (nchunks + 1))(*bounds[1])
-    cp.max_chunk_pairs = max(bounds[0][i + 1] - bounds[0][i] for i in range(nchunks))
+    # host copies of the chunk boundaries (exact row / tile / pair counts per chunk; a single chunk included)
+    cp._set_chunks(rows, bounds[1], bounds[0])
     return cp
 
 
@@ -312,7 +341,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    _ptr(pairs.partial), _ptr(scale), _ptr(shift), _ptr(residual),
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
                                    out.stride(0) if out is not None else 0, _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
-                                   int(pairs.chunk_rows), int(pairs.num_chunks), pairs.chunk_tile_off, pairs.chunk_pair_off,
+                                   int(pairs.num_chunks), pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off,
                                    _ptr(x_row_inv), _ptr(out_row_inv), _stream()),
           "gp_sparse_conv_f16x3")
     return out

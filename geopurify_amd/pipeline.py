@@ -123,7 +123,7 @@ class StudentWeights:
         ctx = {"nbr_map": nbr_map, "pairs": pairs}
         fast = self.fast
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
-            ctx["pairs"] = ops.conv_pairs_build(nbr_map)
+            ctx["pairs"] = ops.conv_pairs_build(nbr_map, col_tiles=max(1, self.hidden // 256))
         xs = (x_split if x_split is not None else self.split_input(x)) if fast else None
         h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast)
         for b in range(self.num_blocks):
@@ -524,7 +524,7 @@ class HotPath:
         else:
             grid = ops.grid_build(cs)
         nbr_map = ops.kernel_map_build(grid, cs)
-        pairs = ops.conv_pairs_build(nbr_map) if any(l[0] == "f16x3" for l in st.layers) else None
+        pairs = ops.conv_pairs_build(nbr_map, col_tiles=max(1, st.hidden // 256)) if any(l[0] == "f16x3" for l in st.layers) else None
         mark("grid+kernel_map")
         nbr = ops.knn_lattice(grid, cs, perm, self.K)
         mark("kNN")

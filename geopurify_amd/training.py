@@ -58,7 +58,7 @@ def _anchor_similarities(Fn, anchor_indices):
         Fp = torch.zeros((Np, Dt), dtype=torch.float32, device=Fn.device)
         Fp[:N] = Fn
     hi, lo = ops.split_f16(Fp)
-    pairs = ops.conv_pairs_build(anchor_indices.to(torch.int32).view(1, -1).contiguous())
+    pairs = ops.conv_pairs_build(anchor_indices.to(torch.int32).view(1, -1).contiguous(), chunk_rows=None)      # one gather-GEMM, one chunk
     sim = ops.sparse_conv_f16x3(None, pairs, hi.view(1, Np, Dt), lo.view(1, Np, Dt), None, None, relu=False, x_split=(hi, lo))
     return sim[:, :N]
 
@@ -177,7 +177,7 @@ class StudentTrainer:
         P, B = self.params, self.buffers
         dev = X.device
         Nv = X.shape[0]
-        ctx = {"nbr_map": nbr_map, "pairs": ops.conv_pairs_build(nbr_map) if self.fast else None,
+        ctx = {"nbr_map": nbr_map, "pairs": ops.conv_pairs_build(nbr_map, col_tiles=max(1, self.hidden // 256)) if self.fast else None,
                "inv_pow2": {c: torch.full((c,), 1.0 / W_POW2, dtype=torch.float32, device=dev) for c in {self.hidden}}}
         ctx["offset_pairs"] = []
         for k in range(27):

@@ -121,18 +121,28 @@ int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t
 /* Fast path of the same convolution on the f16 matrix cores with fp32-class accuracy (operands     */
 /* split x = hi + lo in f16, products hi*hi + hi*lo + lo*hi accumulated in fp32; relative error of   */
 /* a product <= 2^-21).  gp_conv_pairs_build compacts the kernel map once per scene: pair_in i32     */
-/* [num_pairs] (input row per pair, ordered by (chunk of chunk_rows output rows, k, output row)),      */
+/* [num_pairs] (input row per pair, ordered by (chunk of output rows, k, output row)),                  */
 /* pair_pos i32 [kv,nv] (pair index or -1), seg_off i32 [nseg+1] (first pair of each (chunk,k) segment, */
-/* nseg = ceil(nv/chunk_rows)*kv; seg_off[nseg] = num_pairs), tile_start i32 [nseg+1] (256-pair tiles    */
-/* before each segment).                                                                              */
+/* nseg = num_chunks*kv; seg_off[nseg] = num_pairs), tile_start i32 [nseg+1] (256-pair tiles before     */
+/* each segment).  The chunks are given by their row offsets chunk_row_off (DEVICE i32 [num_chunks+1], */
+/* 0 = first, nv = last, ascending): equal heights, or the heights of gp_conv_chunk_plan.              */
 /* gp_conv_weights_split: w fp32 [kv,cin,cout] -> w_hi/w_lo f16 [kv,cout,cin] of scale_pow2 * w.       */
 /* gp_sparse_conv_f16x3: partial fp32 [num_pairs,cout] workspace; epilogue as gp_sparse_conv (the     */
 /* caller folds 1/scale_pow2 into `scale`).  cin % 32 == 0, cout % 256 == 0, |x| < 65504.              */
 size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv);
-int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t chunk_rows,
+int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t num_chunks, const int32_t *chunk_row_off,
                         int32_t *pair_in, int32_t *pair_pos, int32_t *seg_off, int32_t *tile_start,
                         int32_t *tile_desc /* i32 [num_pairs/256 + nseg, 4]: {k, first pair, count, 0} per tile */,
                         void *workspace, size_t workspace_bytes, void *stream);
+/* Chunk heights chosen from the kernel map so that every chunk's phase-1 launch -- sum over the offsets of ceil(pairs / 256)  */
+/* row tiles, times col_tiles (= cout / 256) column tiles -- stays within target_tiles (2 x the CU count = two rounds of        */
+/* one-tile workgroups; equal heights leave 4-8 % of the tile slots of their rounds empty).  Chunks close at multiples of        */
+/* granule_rows (>= 64).  Outputs on the DEVICE: chunk_row_off i32 [max_chunks + 1], n_chunks i32 [1]; the caller reads them      */
+/* back to size the pair arrays and to pass the host copy to gp_sparse_conv_f16x3.                                               */
+size_t gp_conv_chunk_plan_workspace_bytes(int64_t nv, int32_t granule_rows);
+int gp_conv_chunk_plan(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t granule_rows, int32_t col_tiles,
+                       int32_t target_tiles, int32_t max_chunks, int32_t *chunk_row_off, int32_t *n_chunks, void *workspace,
+                       size_t workspace_bytes, void *stream);
 int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2,
                           void *w_hi, void *w_lo, void *stream);
 /* Optional pre-split operands: x_hi/x_lo f16 [nv, ld_xh] (from gp_split_f16 or a previous layer's   */
@@ -157,11 +167,12 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          const void *w_hi, const void *w_lo, int32_t cin, int32_t cout, float *partial,
                          const float *scale, const float *shift, const float *residual, int64_t ld_res,
                          int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
-                         int32_t chunk_rows, int32_t num_chunks, const int32_t *chunk_tile_off_host,
+                         int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
                          const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale, void *stream);
-/* Chunked execution (num_chunks > 1, pairs built with the same chunk_rows): phase 1 / phase 2 alternate  */
+/* Chunked execution (num_chunks >= 1, the chunks the pairs were built with): phase 1 / phase 2 alternate  */
 /* per chunk so that `partial` (then sized for the largest chunk) stays in the Infinity Cache;             */
-/* chunk_tile_off_host / chunk_pair_off_host = tile_start / seg_off at the chunk boundaries [num_chunks+1]. */
+/* chunk_row_off_host = HOST copy of the row offsets, chunk_tile_off_host / chunk_pair_off_host =           */
+/* tile_start / seg_off at the chunk boundaries, all [num_chunks+1]; num_chunks = 0: none of them.          */
 /* in-place row L2 normalisation, F.normalize(p=2, dim=1, eps=1e-12) (affinity_module.py:1547)     */
 int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
 /* The student's 1x1x1 output convolution (hidden -> 128 embedding channels, affinity_module.py:66,71) on the pre-split rows   */

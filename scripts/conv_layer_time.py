@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One 512->512 layer of the S scene (pre-split operands in, split planes out), median of 5 x 12 launches after 30 warm ones.
-usage: conv_layer_time.py [chunk_rows ...]     (environment switches of the library apply, e.g. GP_CONV_P2_WG_PER_CU)"""
+usage: conv_layer_time.py [chunk_rows | balanced ...]     (environment switches apply: GP_CONV_P2_WG_PER_CU, GP_CONV_TARGET_TILES, GP_SCENE_SEED)"""
 import os
 import sys
 import dataclasses
@@ -12,8 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geopurify_amd import ops, pipeline as pl, synthetic as syn  # noqa: E402
 
 cfg = dataclasses.replace(syn.CONFIGS["S"], num_views=1)
-sc = syn.make_scene(cfg, 5557)
-rigid = pl.scene_rigid_transform(cfg.voxel_size, 5557)
+SEED = int(os.environ.get("GP_SCENE_SEED", "5557"))
+sc = syn.make_scene(cfg, SEED)
+rigid = pl.scene_rigid_transform(cfg.voxel_size, SEED)
 vox = ops.voxelize(torch.from_numpy(sc.coords).cuda(), rigid)
 coords = vox["coords_aug"].to(torch.int32).contiguous()
 perm, rank = ops.morton_order(coords)
@@ -25,7 +26,7 @@ X, W = torch.randn(Nv, 512, device="cuda", generator=g), torch.randn(27, 512, 51
 hi, lo = ops.conv_weights_split(W, 64.0)
 xs = ops.split_f16(X, per_row=True)
 sc_, sh = torch.ones(512, device="cuda"), torch.zeros(512, device="cuda")
-for chunk_rows in [int(a) for a in sys.argv[1:]] or [8192]:
+for chunk_rows in [a if a == "balanced" else int(a) for a in sys.argv[1:]] or ["balanced"]:
     pairs = ops.conv_pairs_build(nm, chunk_rows)
     ys = tuple(torch.empty((Nv, 512), dtype=torch.float16, device="cuda") for _ in range(2)) + (torch.empty(Nv, device="cuda"),)
     run = lambda: ops.sparse_conv_f16x3(None, pairs, hi, lo, sc_, sh, relu=True, x_split=xs[:2], x_row_inv=xs[2], out_split=ys[:2],
@@ -43,5 +44,8 @@ for chunk_rows in [int(a) for a in sys.argv[1:]] or [8192]:
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 12)
     chk = float(ys[0].float().sum() + ys[1].float().sum() + ys[2].sum())
-    print(f"{os.environ.get('GP_CONV_P2_WG_PER_CU', 'default'):>8s} workgroups per CU in phase 2, chunk {chunk_rows:6d}: layer {np.median(ts):6.3f} ms "
+    to = np.array(list(pairs.chunk_tile_off))
+    tiles = np.diff(to) * 2
+    print(f"      seed {SEED}: Nv {Nv}, {pairs.num_chunks} launches, tiles per launch {tiles.min()}..{tiles.max()}, rounds of 256: {int(np.ceil(tiles / 256).sum())}", flush=True)
+    print(f"{os.environ.get('GP_CONV_P2_WG_PER_CU', 'default'):>8s} workgroups per CU in phase 2, chunk {str(chunk_rows):>8s} (target {ops.CONV_TARGET_TILES or 'auto'}): layer {np.median(ts):6.3f} ms "
           f"(min {min(ts):6.3f}, max {max(ts):6.3f}); checksum {chk:.6e}", flush=True)

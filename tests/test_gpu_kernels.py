@@ -3,6 +3,8 @@ seeded inputs (sizes the oracle finishes in seconds) and against the committed g
 Bar: bit-exact for integer / index outputs, stated tolerances for fp32."""
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -544,10 +546,18 @@ def test_error_paths(ops):
     with pytest.raises(GeoPurifyHipError, match="chunk tables"):
         ops.sparse_conv_f16x3(xin, pairs, hi, lo)
     pairs.chunk_tile_off = saved
-    pairs.chunk_rows = 128                                             # chunks that do not cover the rows
-    with pytest.raises(GeoPurifyHipError):
+    saved_rows = pairs.chunk_row_off
+    bad = list(saved_rows)
+    bad[-1] -= 1                                                       # chunks that do not cover the rows
+    pairs.chunk_row_off = (ctypes.c_int32 * len(bad))(*bad)
+    with pytest.raises(GeoPurifyHipError, match="do not cover"):
         ops.sparse_conv_f16x3(xin, pairs, hi, lo)
-    pairs.chunk_rows = 256
+    bad = list(saved_rows)
+    bad[1] = bad[2]                                                    # an empty chunk: not ascending
+    pairs.chunk_row_off = (ctypes.c_int32 * len(bad))(*bad)
+    with pytest.raises(GeoPurifyHipError, match="do not cover"):
+        ops.sparse_conv_f16x3(xin, pairs, hi, lo)
+    pairs.chunk_row_off = saved_rows
     assert torch.equal(ops.sparse_conv_f16x3(xin, pairs, hi, lo), good)
     # the matrix-core pooling builder pads row blocks only on request: 0 by default, 9 for the persistent kernel
     nb2 = torch.randint(0, 200, (200, 16), dtype=torch.int32, device="cuda")
@@ -676,6 +686,26 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
                                out_split=ys)
     assert torch.equal(y2, y)
     assert (ys[0].float() + ys[1].float() - y2).abs().max() <= 2e-6 * max(1.0, float(y2.abs().max()))
+    # chunk heights chosen from the kernel map (gp_conv_chunk_plan): every launch within the tile target, the chunk tables consistent
+    # with the map, and -- a row's sum does not depend on which rows share its tiles -- the same bits
+    for target in (32, 64):
+        old_target, ops.CONV_TARGET_TILES = ops.CONV_TARGET_TILES, target
+        try:
+            bal = ops.conv_pairs_build(nm, "balanced", col_tiles=1)
+        finally:
+            ops.CONV_TARGET_TILES = old_target
+        rows_b, tiles_b, pairs_b = list(bal.chunk_row_off), list(bal.chunk_tile_off), list(bal.chunk_pair_off)
+        assert rows_b[0] == 0 and rows_b[-1] == Nv and all(b > a and (b % 256 == 0 or b == Nv) for a, b in zip(rows_b[:-1], rows_b[1:]))
+        assert bal.num_chunks > 1 and bal.num_pairs == pairs.num_pairs
+        for ci in range(bal.num_chunks):
+            cnt_k = (nmc[:, rows_b[ci]:rows_b[ci + 1]] >= 0).sum(1)
+            assert pairs_b[ci + 1] - pairs_b[ci] == cnt_k.sum() and tiles_b[ci + 1] - tiles_b[ci] == ((cnt_k + 255) // 256).sum()
+            assert tiles_b[ci + 1] - tiles_b[ci] <= target or rows_b[ci + 1] - rows_b[ci] <= 256
+            if ci + 1 < bal.num_chunks:                                 # greedy: one more granule would have passed the target
+                more = (nmc[:, rows_b[ci]:rows_b[ci + 1] + 256] >= 0).sum(1)
+                assert ((more + 255) // 256).sum() > target
+        yb = ops.sparse_conv_f16x3(None, bal, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs)
+        assert torch.equal(yb, y), target
     # launch grouping (ConvPairs.regroup): the same pairs in the same order, g chunks per launch => the same bits
     for g in (2, 5):
         grouped = pairs.regroup(g)
