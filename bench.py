@@ -587,7 +587,8 @@ def main():
         # the look-ahead stream has the HIGHER priority: its small kernels run beside the convolutions, whose workgroups hold a CU for
         # ~40 us each; the host's read-backs in the look-ahead (voxel count, per-view counts, pair count, union rows) wait for them
         side_prio = int(os.environ.get("GP_BENCH_SIDE_PRIORITY", "-1"))
-        streams = [torch.cuda.Stream(device=dev, priority=side_prio), torch.cuda.Stream(device=dev)]
+        main_prio = int(os.environ.get("GP_BENCH_MAIN_PRIORITY", "0"))
+        streams = [torch.cuda.Stream(device=dev, priority=side_prio), torch.cuda.Stream(device=dev, priority=main_prio)]
     pending = {}                                        # scene index -> (batch, F, text, scale, lift-done event), lifted ahead
     host_t = {"hook": 0.0, "step": 0.0}                 # host seconds inside the look-ahead hook / inside step() (timed region)
 
