@@ -101,6 +101,15 @@ __global__ void chunk_count_kernel(const int32_t *__restrict__ nm, int64_t nv, i
 // (256 threads stage windows of 512 granules' counts in LDS as u16 -- a count is at most the granule's rows -- and wave 0 walks them:
 // a dependent global load per granule made this one-wave loop 0.23 ms on the S scene)
 constexpr int CP_WIN = 512;
+// sum over lanes 0..31 (wave-uniform result) with DPP adds inside the 16-lane rows and two v_readlane: the shuffle form (six
+// ds_bpermute round trips) made the one-wave walk below 0.28 us per granule
+__device__ __forceinline__ int cp_sum32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+}
 __global__ void __launch_bounds__(256)
 chunk_plan_kernel(const int32_t *__restrict__ cnt, int ngran, int kv, int granule, int64_t nv, int col_tiles, int target,
                   int max_chunks, int32_t *__restrict__ R, int32_t *__restrict__ n_chunks) {
@@ -117,7 +126,7 @@ chunk_plan_kernel(const int32_t *__restrict__ cnt, int ngran, int kv, int granul
             for (int gl = 0; gl < n; ++gl) {
                 const int g = g0 + gl;
                 const int add = lane < 32 ? s_cnt[gl * 32 + lane] : 0;
-                const int tiles_with = gp_wave_sum_i((sum + add + TM - 1) / TM) * col_tiles;
+                const int tiles_with = cp_sum32(lane < 32 ? (sum + add + TM - 1) / TM : 0) * col_tiles;
                 if (tiles_with > target && g != start_g && nc + 1 < max_chunks) {      // close the chunk in front of this granule
                     ++nc;
                     if (lane == 0) R[nc] = g * granule;
