@@ -706,6 +706,24 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
                 assert ((more + 255) // 256).sum() > target
         yb = ops.sparse_conv_f16x3(None, bal, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs)
         assert torch.equal(yb, y), target
+    # edge shapes of the plan: fewer rows than one granule (one chunk), a target no granule fits (one granule per chunk), bad arguments
+    from geopurify_amd import _lib as _l
+    lib_ = _l.load()
+    tiny = ops.conv_pairs_build(nm[:, :100].clamp(max=99).contiguous(), "balanced", col_tiles=1)
+    assert tiny.num_chunks == 1 and list(tiny.chunk_row_off) == [0, 100]
+    old_target, ops.CONV_TARGET_TILES = ops.CONV_TARGET_TILES, 1
+    try:
+        one = ops.conv_pairs_build(nm, "balanced", col_tiles=1)
+    finally:
+        ops.CONV_TARGET_TILES = old_target
+    assert list(one.chunk_row_off) == list(range(0, Nv, 256)) + [Nv]
+    assert torch.equal(ops.sparse_conv_f16x3(None, one, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs), y)
+    buf = torch.zeros(64, dtype=torch.int32, device="cuda")
+    wsb = torch.zeros(lib_.gp_conv_chunk_plan_workspace_bytes(Nv, 256), dtype=torch.uint8, device="cuda")
+    assert lib_.gp_conv_chunk_plan(nm.data_ptr(), Nv, 27, 32, 1, 64, 16, buf.data_ptr(), buf[40:].data_ptr(), wsb.data_ptr(), wsb.numel(), None) == -22   # granule < 64
+    assert lib_.gp_conv_chunk_plan(nm.data_ptr(), Nv, 27, 256, 1, 64, 16, buf.data_ptr(), buf[40:].data_ptr(), wsb.data_ptr(), 8, None) == -22            # workspace
+    assert lib_.gp_conv_chunk_plan(nm.data_ptr(), Nv, 27, 256, 1, 64, 2, buf.data_ptr(), buf[40:].data_ptr(), wsb.data_ptr(), wsb.numel(), None) == 0        # max_chunks caps the plan
+    assert int(buf[40]) == 2 and buf[:3].tolist()[0] == 0 and buf[:3].tolist()[2] == Nv
     # launch grouping (ConvPairs.regroup): the same pairs in the same order, g chunks per launch => the same bits
     for g in (2, 5):
         grouped = pairs.regroup(g)
