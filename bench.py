@@ -33,8 +33,8 @@ FP32_MFMA_PEAK_TF = 157.3        # dense fp32-input MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 6; config V: every scene of this rank once)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 24; config V: every scene of this rank once)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="S", choices=["P", "S", "M", "T", "V"],
                     help="S = BASELINE configs[1] (default); V = configs[2]: ScanNet-val scene SIZES (tests/golden/"
                          "scannet_val_point_counts.txt), a fixed subset of --val-scenes per GPU, sharded over the ranks")
@@ -62,7 +62,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 0 if a.config == "V" else 6            # 0 = resolved to the rank's scene count below
+        # 24 scenes = 0.6 s of timed region on S.  The schedule has edges: the first timed scene does its own loader + lift + prepare
+        # in front of its student (the warm-up's last scene did not look ahead) and the last one has no look-ahead beside it -- with
+        # 6 steps the edges cost 1 % of the rate (25.9 vs 25.65 ms per scene at 24 or 64 steps, profiles/r04_steps_sweep.log)
+        a.steps = 0 if a.config == "V" else 24           # 0 = resolved to the rank's scene count below
     return a
 
 
