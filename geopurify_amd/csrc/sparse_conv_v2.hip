@@ -55,10 +55,14 @@ __device__ __forceinline__ void pair_decode(int64_t i, int kv, const int32_t *__
         if (R[mid] <= row_q) lo = mid; else hi = mid - 1;
     }
     c = lo;
-    const int64_t r0 = R[c], rows_c = R[c + 1] - r0;
+    // (the table lives on the device and is not validated there: a malformed one -- not ascending, not ending at nv -- must give
+    // wrong pairs, never an access outside the map; gp_sparse_conv_f16x3 checks the host copy)
+    const int64_t r0 = R[c], rows_raw = R[c + 1] - r0, rows_c = rows_raw > 0 ? rows_raw : 1;
     const int64_t rem = i - (int64_t)kv * r0;
-    k = (int)(rem / rows_c);
-    u = r0 + (rem - (int64_t)k * rows_c);
+    int64_t kk = rem / rows_c;
+    kk = kk < 0 ? 0 : (kk >= kv ? kv - 1 : kk);
+    k = (int)kk;
+    u = r0 + (rem - kk * rows_c);
 }
 __global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t nv, int kv, const int32_t *__restrict__ R, int nchunks,
                                   int32_t *__restrict__ f) {
@@ -67,6 +71,7 @@ __global__ void pair_flags_kernel(const int32_t *__restrict__ nm, int64_t nv, in
     if (i >= total) return;
     int c, k; int64_t u;
     pair_decode(i, kv, R, nchunks, c, k, u);
+    u = u < 0 ? 0 : (u >= nv ? nv - 1 : u);
     f[i] = nm[(int64_t)k * nv + u] >= 0 ? 1 : 0;
 }
 __global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *__restrict__ sc, int64_t nv, int kv,
@@ -77,6 +82,7 @@ __global__ void pair_emit_kernel(const int32_t *__restrict__ nm, const int32_t *
     if (i >= total) return;
     int c, k; int64_t u;
     pair_decode(i, kv, R, nchunks, c, k, u);
+    u = u < 0 ? 0 : (u >= nv ? nv - 1 : u);
     int in = nm[(int64_t)k * nv + u];
     int s = sc[i];
     pair_pos[(int64_t)k * nv + u] = in >= 0 ? s : -1;
