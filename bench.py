@@ -171,6 +171,7 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
         "project+lists": ("row 3 + loader glue: V x N x (24 in + 24 out) + V x H x W x 8 (depth maps)", views * n * 48.0 + views * H * W * 8.0),
         "lift+fuse+fill": ("rows 5-7: N x D x 4 written + sum n_v x 8 (entry ids)", n * d * 4.0 + n_vis * 8.0),
         "scatter_mean": ("row 8: N x (D+6) x 4 read + Nv x (D+6) x 4 written + N x 8", n * (d + 6) * 4.0 + nv * (d + 6) * 4.0 + n * 8.0),
+        "embed head": ("row 9, output layer + F.normalize: Nv x (512 x 4 split planes + 128 x 4)", nv * (512 * 4.0 + 128 * 4.0)),
         "kNN": ("row 10: Nv x (12 + K x 4)", nv * (12.0 + K * 4)),
         "affinity": ("row 11: Nv x (128 x 4 + K x 4 + K x 4)", nv * (128 * 4.0 + K * 8)),
         "pooling": (f"row 12: {pool_iters} x Nv x (2 x D x 4 + K x 8)", pool_iters * nv * (2.0 * d * 4 + K * 8)),
@@ -185,11 +186,13 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
         gbs = b / (t * 1e-3) / 1e9
         out[name] = {"ms": round(t, 4), "algorithmic_bytes": int(b), "achieved": round(gbs, 1), "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": what}
+    if "student convolutions" in ms:                          # the fine pass splits the student: its nine 3x3x3 layers | the head
+        ms = dict(ms, student=ms["student convolutions"])
     for name in ("morton order", "grid+kernel_map", "student", "pool plan+split", "pool operator fill"):
         if name in ms:
             out[name] = {"ms": round(ms[name], 4), "note": {"morton order": "internal row order of the voxels (sort of Nv keys): index work, no SURVEY 8(d) figure",
                                                            "grid+kernel_map": "lattice grid + 27-offset kernel map: index work, no SURVEY 8(d) figure",
-                                                           "student": "matrix-core bound: see roofline_conv",
+                                                           "student": "the nine 3x3x3 layers, matrix-core bound: see roofline_conv (the 1x1x1 output layer is the `embed head` line)",
                                                            "pool plan+split": "once per scene, needs the kNN lists only: the pooling operator's union sizes and structure (union rows, fragment masks, the element of every (row, neighbour) weight) + the f16 hi/lo splits of X",
                                                            "pool operator fill": "empty since round 4: the affinity kernel writes the weights straight into fragment order (GP_POOL_STRUCTURE_AHEAD=0: the separate fill pass)"}[name]}
     out["note"] = ("one-stream side pass after the timed region, HIP events at stage boundaries, mean over the side scenes; "

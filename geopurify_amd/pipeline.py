@@ -116,7 +116,7 @@ class StudentWeights:
         means only, so a scheduler can run it ahead (HotPath.prepare)."""
         return ops.split_f16(x, self.cin_pad, per_row=True) if self.fast else None
 
-    def forward(self, x, nbr_map, pairs=None, x_split=None):
+    def forward(self, x, nbr_map, pairs=None, x_split=None, mark=None):
         """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed].
         On the f16x3 path every layer also emits its output pre-split (hi/lo f16) so that the next
         layer stages both operands by LDS-DMA.  x_split: split_input(x) when it was made ahead."""
@@ -132,6 +132,8 @@ class StudentWeights:
             head = last and fast and self.head is not None          # the output layer reads the split planes only
             h, hs = self._conv(2 + 2 * b, t, ctx, residual=h, x_split=ts, want_split=fast and (not last or head), want_f32=not head)
         self.last_pairs = ctx["pairs"]
+        if mark is not None:
+            mark("student convolutions")                  # (stage marks of bench.py's per-stage pass)
         if fast and self.head is not None and hs is not None:
             return ops.embed_head_f16x3(hs[:2], self.head[0], self.head[1], self.head[2], x_row_inv=hs[2], normalize=True)
         e = ops.sparse_conv(h, None, self.w_out)
@@ -548,8 +550,8 @@ class HotPath:
         p = prepared if prepared is not None else self.prepare(batch, F)
         X, rank, nbr, Nv, D = p["X"], p["rank"], p["nbr"], p["Nv"], p["D"]
         mark = self.stage_mark if self.stage_mark is not None else (lambda name: None)
-        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"))
-        mark("student")
+        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"), mark=self.stage_mark)
+        mark("embed head" if self.stage_mark is not None else "student")
         if after_student is not None:
             after_student()
         # the operator's structure was built ahead: the affinity kernel writes its weights straight into fragment order
