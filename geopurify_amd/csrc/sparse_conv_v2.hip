@@ -126,20 +126,57 @@ chunk_plan_kernel(const int32_t *__restrict__ cnt, int ngran, int kv, int granul
     for (int g0 = 0; g0 < ngran; g0 += CP_WIN) {
         const int n = ngran - g0 < CP_WIN ? ngran - g0 : CP_WIN;
         __syncthreads();
-        for (int i = tid; i < n * 32; i += 256) s_cnt[i] = (unsigned short)((i & 31) < kv ? cnt[(int64_t)g0 * 32 + i] : 0);
+        {   // 16-byte loads, four in flight per thread (one dword load per iteration was one memory round trip per 256 counts)
+            const int4 *c4 = reinterpret_cast<const int4 *>(cnt + (int64_t)g0 * 32);
+            const int n4 = n * 8;
+            for (int i0 = tid; i0 < n4; i0 += 1024) {
+                int4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (i0 + q * 256 < n4) ? c4[i0 + q * 256] : make_int4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + q * 256;
+                    if (i < n4) {
+                        const int k0 = (i * 4) & 31;                      // columns kv .. 31 of the workspace are not written
+                        s_cnt[i * 4 + 0] = (unsigned short)(k0 + 0 < kv ? v[q].x : 0);
+                        s_cnt[i * 4 + 1] = (unsigned short)(k0 + 1 < kv ? v[q].y : 0);
+                        s_cnt[i * 4 + 2] = (unsigned short)(k0 + 2 < kv ? v[q].z : 0);
+                        s_cnt[i * 4 + 3] = (unsigned short)(k0 + 3 < kv ? v[q].w : 0);
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (tid < 64) {
-            for (int gl = 0; gl < n; ++gl) {
-                const int g = g0 + gl;
-                const int add = lane < 32 ? s_cnt[gl * 32 + lane] : 0;
-                const int tiles_with = cp_sum32(lane < 32 ? (sum + add + TM - 1) / TM : 0) * col_tiles;
+            // four granules per round: their running sums and tile counts are computed as if no chunk closed among them (four
+            // independent reductions in flight instead of one dependent chain per granule); a close -- 16 in 524 granules --
+            // invalidates what follows it in the round, which is then redone one granule at a time
+            auto step = [&](int g, int add, int tiles_with) {
                 if (tiles_with > target && g != start_g && nc + 1 < max_chunks) {      // close the chunk in front of this granule
                     ++nc;
                     if (lane == 0) R[nc] = g * granule;
                     sum = add;
                     start_g = g;
-                } else {
-                    sum += add;
+                    return true;
+                }
+                sum += add;
+                return false;
+            };
+            for (int gl = 0; gl < n; gl += 4) {
+                int a[4], run[4], t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = (lane < 32 && gl + j < n) ? s_cnt[(gl + j) * 32 + lane] : 0;
+                run[0] = sum + a[0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) run[j] = run[j - 1] + a[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = cp_sum32(lane < 32 ? (run[j] + TM - 1) / TM : 0) * col_tiles;
+                bool redo = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (gl + j >= n) break;
+                    const int tiles_with = redo ? cp_sum32(lane < 32 ? (sum + a[j] + TM - 1) / TM : 0) * col_tiles : t[j];
+                    redo = step(g0 + gl + j, a[j], tiles_with) || redo;
                 }
             }
         }
