@@ -6,7 +6,7 @@ pointers, sizes and a hipStream_t.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgeopurify_hip.so")
@@ -70,6 +70,11 @@ SIGNATURES = {
     "gp_pool_cs_structure": (c_int32, [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gp_pool_cs_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_pool_cs_apply_engine": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
+    "gp_pool_cs_apply_half": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
+    "gp_pool_cs_deps": (c_int32, [_P, _P, c_int64, c_int32, _P, _P, _P]),
+    "gp_pool_cs_chain_flag_words": (c_size_t, [c_int64, c_int32]),
+    "gp_pool_cs_apply_chain": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P,
+                                         c_uint32, _P]),
     "gp_lift_dense_accum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_lift_dense_bilinear_accum": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P,
                                                c_int64, _P, _P]),

@@ -67,9 +67,26 @@ __device__ __forceinline__ uint64_t cs_real() {
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+// AUX: the cache-policy bits of the instruction (0 = default; 16 = sc1: served by L2, never by this CU's L1)
+template <int AUX = 0>
 __device__ __forceinline__ void cs_glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, AUX);
+}
+// agent-visible accesses of the chained launch (cs_chain_kernel): sc1 stores are written through to memory, sc1 loads are never
+// served by a CU's L1 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility")
+__device__ __forceinline__ uint32_t cs_ld_sc1(const uint32_t *p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void cs_st_sc1(uint32_t *p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void cs_st16_sc1(void *p, V v) {
+    static_assert(sizeof(V) == 16, "16-byte store");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void cs_tr(s16x4 &d, uint32_t addr) {
@@ -277,14 +294,43 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
 // `s_waitcnt vmcnt(6); s_barrier` (6 = the DMA instructions of the younger stage; vector memory operations complete in
 // issue order and the loop issues no other).  Row ids and fragment masks are scalar loads issued one step ahead.
 // (TUNE: the ablation bits of `ablate_` are honoured; the production instantiation compiles them out)
-template <bool STAMP, bool TUNE>
+// The chained launch (CHAIN, cs_chain_kernel): ALL T applications of a scene in one grid of T x tiles workgroups.  Workgroup
+// blockIdx = 8 j + label is tile j mod per_xcd of application t = j / per_xcd in its label's range, so the hardware dispatcher
+// is the work queue (in-order, compact front: what kept the XCD's L2 window together in every persistent experiment of rounds 2-3)
+// and a workgroup only ever waits for workgroups with a smaller blockIdx.  Application t reads plane set (t even ? A : B) and writes
+// the other one (the last one writes fp32); a row block's tile of application t may start once every row block in its dependency
+// list has PUBLISHED application t - 1: flags[half][block] = base + applications done, one sc1 store by one lane after every wave
+// of the workgroup has drained its (sc1, written-through) output stores behind a barrier; the consumer polls the flags with sc1
+// loads and gathers the rows with sc1 LDS-DMA (the XCDs' L2s are not coherent with each other, a CU's L1 is never refreshed).
+// The lists are symmetric (d in list(b) <=> b in list(d), built by gp_pool_cs_deps), so "my inputs are published" also means
+// "nobody still reads the rows I am about to overwrite" and two plane sets are enough.  Odd labels walk their range backwards:
+// the two ends of neighbouring ranges then finish an application together and no range's first tile waits for another range's
+// last one (CPU study on the S scene: 10 of 16 191 edges with less than a tenth of a sweep of slack, 136 walking all forwards).
+// A wait is bounded (2 s of the constant 100 MHz clock): on expiry the workgroup sets abort and returns, every later poll sees
+// abort and returns -- the grid always drains; the host reads the word (gp_pool_cs_apply_chain's contract).
+struct CsChain {
+    const _Float16 *a_hi, *a_lo;       // plane set A (application 0's input; rewritten by applications 1, 3, ...)
+    _Float16 *b_hi, *b_lo;             // plane set B
+    int64_t ld;                        // row pitch of both sets (elements)
+    uint32_t *flags;                   // [32 header words: word 0 = abort] [2 halves][nblocks]
+    const int32_t *dep;                // [nblocks][64]: word 0 = n, words 1 .. min(n, 63) = row blocks (n > 63: wait for every block)
+    int32_t T;                         // applications (>= 2)
+    uint32_t base;                     // flags epoch: a published application t reads base + t + 1
+    int32_t half_sel = -1;             // (not chained) 0 / 1: the grid covers this 256-column half only (cs_pool_half_kernel)
+};
+constexpr int CS_DEP_CAP = 64;
+constexpr int CS_FLAG_HDR = 32;
+
+template <bool STAMP, bool TUNE, bool CHAIN = false>
 __device__ __forceinline__ void
-cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x,
+cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_lo_, int64_t ld_x_,
                const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
                const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks,
-               _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_y, float *__restrict__ y_f32, int64_t ld_yf,
-               int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb) {
+               _Float16 *__restrict__ y_hi_, _Float16 *__restrict__ y_lo_, int64_t ld_y_, float *__restrict__ y_f32_, int64_t ld_yf,
+               int64_t per_xcd, int ablate_, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb,
+               const CsChain &ch) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int AUX = CHAIN ? 16 : 0;
     const int ablate = TUNE ? ablate_ : 0;
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_work = 0, st_wait = 0, st_issue = 0;
     if constexpr (STAMP) { st_t0 = cs_now(); st_r0 = cs_real(); }
@@ -295,10 +341,68 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
     // blocks side by side (their halo rows meet in its L2).  Measured and left out (round 4, profiles/r04_pool_block_height.log):
     // starting the row blocks longest-first, dealt round-robin over the XCDs, 0.279 instead of 0.223 ms per application -- the
     // drain of the last round is worth less than the L2 sharing between neighbouring tiles.
-    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int64_t lb;
+    int app = 0;
+    bool app_last = true;
+    const _Float16 *x_hi = x_hi_, *x_lo = x_lo_;
+    _Float16 *y_hi = y_hi_, *y_lo = y_lo_;
+    float *y_f32 = y_f32_;
+    int64_t ld_x = ld_x_, ld_y = ld_y_;
+    if constexpr (CHAIN) {
+        const int64_t j = blockIdx.x >> 3;
+        const int label = blockIdx.x & 7;
+        app = (int)(j / per_xcd);
+        const int64_t r = j - (int64_t)app * per_xcd;
+        lb = (int64_t)label * per_xcd + ((label & 1) ? per_xcd - 1 - r : r);
+        app_last = app == ch.T - 1;
+        const bool even = (app & 1) == 0;
+        x_hi = even ? ch.a_hi : ch.b_hi;
+        x_lo = even ? ch.a_lo : ch.b_lo;
+        y_hi = app_last ? nullptr : even ? ch.b_hi : const_cast<_Float16 *>(ch.a_hi);
+        y_lo = app_last ? nullptr : even ? ch.b_lo : const_cast<_Float16 *>(ch.a_lo);
+        y_f32 = app_last ? y_f32_ : nullptr;
+        ld_x = ld_y = ch.ld;
+    } else {
+        lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (ch.half_sel >= 0) lb = 2 * lb + ch.half_sel;         // (per_xcd then counts row blocks, not tiles)
+    }
     const int64_t b = lb >> 1;
     const int col0 = (int)(lb & 1) * CS_NC;
     if (b >= nblocks) return;
+    uint32_t *my_flag = nullptr;
+    if constexpr (CHAIN) {
+        uint32_t *fl = ch.flags + CS_FLAG_HDR + (lb & 1) * nblocks;
+        my_flag = fl + b;
+        if (app > 0) {
+            // every wave polls for itself (no barrier in front of the first DMA): lane 0 watches abort, lanes 1 .. n the row blocks
+            const uint32_t want = ch.base + (uint32_t)app;
+            const int32_t dv = ch.dep[b * CS_DEP_CAP + lane];
+            const int n = __builtin_amdgcn_readfirstlane(dv);
+            const uint64_t w0 = cs_real();
+            for (int64_t i0 = 0;;) {
+                uint32_t v = want, ab = 0;
+                if (n < CS_DEP_CAP) {
+                    if (lane >= 1 && lane <= n) v = cs_ld_sc1(fl + dv);
+                } else if (i0 + lane < nblocks) {
+                    v = cs_ld_sc1(fl + i0 + lane);
+                }
+                if (lane == 0) ab = cs_ld_sc1(ch.flags);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(ab)::"memory");
+                if (__builtin_amdgcn_readfirstlane(ab) != 0) return;                       // (all eight waves see it: the workgroup leaves)
+                if (__ballot((int32_t)(v - want) < 0) == 0ull) {
+                    if (n < CS_DEP_CAP || (i0 += 64) >= nblocks) break;
+                    continue;
+                }
+                if (cs_real() - w0 > 200000000ull) {                                       // 2 s: a dependency that never comes
+                    if (lane == 0) cs_st_sc1(ch.flags, 1u);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if constexpr (STAMP) st_issue = cs_now() - st_t0;                              // (slot 5 of the stamps: the dependency wait)
+        }
+    }
     const int64_t ub0 = bu_off[b];
     const int n = (int)((bu_off[b + 1] - ub0) / CS_KS);                            // steps (>= 1)
     const int64_t ks0 = ub0 / CS_KS;
@@ -323,10 +427,10 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
         // 64-row kernel of pool_mfma.hip, whose row ids ride in the ring, read stale ids and faulted).
         const bool hot_x = (ablate & 2) != 0, hot_w = (ablate & 8) != 0;
         const int64_t s0 = hot_x ? 0 : (int64_t)ida * ld_x + dsrc0, s1 = hot_x ? 0 : (int64_t)idb * ld_x + dsrc1;
-        cs_glds16(x_hi + s0, dst + (4 * wv) * CS_RB);
-        cs_glds16(x_lo + s0, dst + CS_PLANE + (4 * wv) * CS_RB);
-        cs_glds16(x_hi + s1, dst + (4 * wv) * CS_RB + 1024);
-        cs_glds16(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
+        cs_glds16<AUX>(x_hi + s0, dst + (4 * wv) * CS_RB);
+        cs_glds16<AUX>(x_lo + s0, dst + CS_PLANE + (4 * wv) * CS_RB);
+        cs_glds16<AUX>(x_hi + s1, dst + (4 * wv) * CS_RB + 1024);
+        cs_glds16<AUX>(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
         // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line)
         const int lo = (((mk >> wv) & 1u) && !hot_w) ? lane * 8 : 0;
         cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
@@ -507,8 +611,13 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                     f16x8 h, l;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { h[i] = (_Float16)xv[i]; l[i] = (_Float16)(xv[i] - (float)h[i]); }
-                    *reinterpret_cast<f16x8 *>(y_hi + grow * ld_y + colw + ec) = h;
-                    *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + colw + ec) = l;
+                    if constexpr (CHAIN) {                  // written through: another XCD gathers these rows in the same launch
+                        cs_st16_sc1(y_hi + grow * ld_y + colw + ec, h);
+                        cs_st16_sc1(y_lo + grow * ld_y + colw + ec, l);
+                    } else {
+                        *reinterpret_cast<f16x8 *>(y_hi + grow * ld_y + colw + ec) = h;
+                        *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + colw + ec) = l;
+                    }
                 }
                 if (y_f32) {
                     float *yp = y_f32 + grow * ld_yf + colw + ec;
@@ -516,6 +625,14 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
                     *reinterpret_cast<float4 *>(yp + 4) = make_float4(xv[4] * so, xv[5] * so, xv[6] * so, xv[7] * so);
                 }
             }
+        }
+    }
+    if constexpr (CHAIN) {
+        // publish: every wave's stores have left (vmcnt(0)), the workgroup meets, ONE lane stores the flag
+        if (!app_last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) cs_st_sc1(my_flag, ch.base + (uint32_t)app + 1u);
         }
     }
     if constexpr (STAMP) {
@@ -526,7 +643,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_work; o[4] = st_wait; o[5] = st_issue;
-            o[6] = t3 - st_e0; o[7] = t3 - st_t0; o[8] = (uint64_t)n; o[9] = xcc;
+            o[6] = t3 - st_e0; o[7] = t3 - st_t0; o[8] = (uint64_t)n; o[9] = xcc | ((uint64_t)app << 8);
         }
     }
 }
@@ -539,12 +656,93 @@ cs_pool_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_l
 #define CS_POOL_FWD x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, y_hi, y_lo, ld_y, y_f32, ld_yf, per_xcd, ablate, out_scale, stamp, rpb
 // the product kernel (STAMP = false: no tuning bits, no stamps) and its stamped instantiation
 template <bool STAMP>
-__global__ void __launch_bounds__(512, 2) cs_pool_kernel(CS_POOL_PARAMS) { cs_pool_body<STAMP, STAMP>(CS_POOL_FWD); }
+__global__ void __launch_bounds__(512, 2) cs_pool_kernel(CS_POOL_PARAMS) { cs_pool_body<STAMP, STAMP>(CS_POOL_FWD, CsChain{}); }
 // the same body with the tuning bits live, under its own name: launches with parts of the kernel switched off (bench.py's
 // gather + store ceiling, scripts/bench_pool.py ablations) do not mix into the product kernel's rows of a kernel trace
-__global__ void __launch_bounds__(512, 2) cs_pool_tuning_kernel(CS_POOL_PARAMS) { cs_pool_body<false, true>(CS_POOL_FWD); }
+__global__ void __launch_bounds__(512, 2) cs_pool_tuning_kernel(CS_POOL_PARAMS) { cs_pool_body<false, true>(CS_POOL_FWD, CsChain{}); }
+// one column half only (gp_pool_cs_apply_half: two independent chains of launches, one per half, on two streams)
+__global__ void __launch_bounds__(512, 2) cs_pool_half_kernel(CS_POOL_PARAMS, int half) {
+    CsChain ch{};
+    ch.half_sel = half;
+    cs_pool_body<false, false>(CS_POOL_FWD, ch);
+}
 #undef CS_POOL_PARAMS
 #undef CS_POOL_FWD
+// all T applications in one launch (see CsChain above)
+template <bool STAMP>
+__global__ void __launch_bounds__(512, 2)
+cs_chain_kernel(CsChain ch, const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
+                const _Float16 *__restrict__ wa_hi, const _Float16 *__restrict__ wa_lo, int64_t nv, int64_t nblocks, float *__restrict__ y_f32,
+                int64_t ld_yf, int64_t per_xcd, const float *__restrict__ out_scale, uint64_t *__restrict__ stamp, int rpb) {
+    cs_pool_body<STAMP, false, true>(nullptr, nullptr, 0, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, nblocks, nullptr, nullptr, 0, y_f32, ld_yf,
+                                     per_xcd, 0, out_scale, stamp, rpb, ch);
+}
+
+// ---- dependency lists of the chained launch: row block d is in list(b) iff a union row of b lies in d, or one of d lies in b
+__device__ __forceinline__ void cs_dep_bitmap(const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, int64_t b, int rpb,
+                                              int words, unsigned *bm) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x) bm[i] = 0u;
+    __syncthreads();
+    const int64_t o = bu_off[b];
+    const int up = (int)(bu_off[b + 1] - o);
+    for (int u = threadIdx.x; u < up; u += blockDim.x) {
+        const int d = bu_row[o + u] / rpb;
+        atomicOr(&bm[d >> 5], 1u << (d & 31));
+    }
+    if (threadIdx.x == 0) atomicOr(&bm[b >> 5], 1u << (b & 31));     // a block always waits for itself (its own rows are rewritten)
+    __syncthreads();
+}
+// pass 1: the forward list, ascending (word 0 = its length n, complete only while n < CS_DEP_CAP), nfwd[b] = n
+__global__ void __launch_bounds__(256)
+cs_deps_fwd_kernel(const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, int64_t nblocks, int rpb, int words,
+                   int32_t *__restrict__ dep, int32_t *__restrict__ nfwd) {
+    extern __shared__ unsigned s_bm[];
+    __shared__ int s_cnt[256];
+    const int64_t b = blockIdx.x;
+    cs_dep_bitmap(bu_off, bu_row, b, rpb, words, s_bm);
+    const int tid = threadIdx.x;
+    const int per = (words + 255) / 256, w0 = tid * per, w1 = min(words, w0 + per);
+    int c = 0;
+    for (int w = w0; w < w1; ++w) c += __popc(s_bm[w]);
+    s_cnt[tid] = c;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = 0; i < 256; ++i) { const int v = s_cnt[i]; if (i < tid) before += v; total += v; }
+    for (int w = w0; w < w1; ++w) {
+        unsigned m = s_bm[w];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            ++before;
+            if (before < CS_DEP_CAP) dep[b * CS_DEP_CAP + before] = w * 32 + bit;
+        }
+    }
+    if (tid == 0) { dep[b * CS_DEP_CAP] = total; nfwd[b] = total; }
+}
+// pass 2: b joins list(d) for every d in list(b) that does not name b itself (a list that overflows waits for every block)
+__global__ void __launch_bounds__(256)
+cs_deps_sym_kernel(const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, int64_t nblocks, int rpb, int words,
+                   int32_t *__restrict__ dep, const int32_t *__restrict__ nfwd) {
+    extern __shared__ unsigned s_bm[];
+    const int64_t b = blockIdx.x;
+    cs_dep_bitmap(bu_off, bu_row, b, rpb, words, s_bm);
+    for (int w = threadIdx.x; w < words; w += blockDim.x) {
+        unsigned m = s_bm[w];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            const int64_t d = (int64_t)w * 32 + bit;
+            if (d == b) continue;
+            const int nd = nfwd[d];
+            if (nd >= CS_DEP_CAP) continue;                           // d waits for every block anyway
+            bool found = false;
+            for (int i = 1; i <= nd; ++i) found |= dep[d * CS_DEP_CAP + i] == (int32_t)b;   // (entries 1 .. nfwd are pass 1's: immutable here)
+            if (found) continue;
+            const int slot = atomicAdd(&dep[d * CS_DEP_CAP], 1) + 1;
+            if (slot < CS_DEP_CAP) dep[d * CS_DEP_CAP + slot] = (int32_t)b;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ engine
 // Producer / consumer form of the same operator ("engine"): ONE persistent 512-thread workgroup per CU.
@@ -937,8 +1135,9 @@ extern "C" int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, i
 static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                     const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d, int32_t rpb,
                     void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
-                    const float *out_scale, bool engine, void *stream_) {
+                    const float *out_scale, bool engine, void *stream_, int half = -1) {
     GP_CHECK_ARG(x_hi && x_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0, "gp_pool_cs_apply: null/empty argument");
+    GP_CHECK_ARG(half >= -1 && half <= 1 && !(engine && half >= 0), "gp_pool_cs_apply_half: half=%d (0 or 1)", half);
     GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply: d=%d (kernel specialised for %d columns)", d, CS_D);
     GP_CHECK_ARG(cs_rpb_ok(rpb), "gp_pool_cs_apply: rows_per_block=%d (16..%d)", rpb, CS_BR);
     GP_CHECK_ARG((y_hi && y_lo) || y_f32, "gp_pool_cs_apply: no output requested");
@@ -948,7 +1147,7 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
     GP_CHECK_ARG(!y_f32 || (ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0), "gp_pool_cs_apply: fp32 output rows must be 16-byte aligned");
     hipStream_t s = gp_stream(stream_);
     const int64_t nb = (nv + rpb - 1) / rpb;
-    const int64_t per_xcd = (nb * (CS_D / CS_NC) + 7) / 8;
+    const int64_t per_xcd = half >= 0 ? (nb + 7) / 8 : (nb * (CS_D / CS_NC) + 7) / 8;
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
     const int tune = g_gp_knobs[4];                       // tuning bits: only ever handed to the *_tuning_kernel twins
     if (engine) {
@@ -981,7 +1180,10 @@ static int cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int6
 #define CS_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, bu_off, bu_row, bu_mask,              \
                 static_cast<const _Float16 *>(wa_hi), static_cast<const _Float16 *>(wa_lo), nv, nb, static_cast<_Float16 *>(y_hi),     \
                 static_cast<_Float16 *>(y_lo), ld_y, y_f32, ld_yf, per_xcd, tune, out_scale, stamp, rpb
-    if (stamp) {
+    if (half >= 0) {
+        GP_SMEM_ATTR(cs_pool_half_kernel, CS_SMEM);
+        cs_pool_half_kernel<<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS, half);
+    } else if (stamp) {
         GP_SMEM_ATTR(cs_pool_kernel<true>, CS_SMEM);
         cs_pool_kernel<true><<<(unsigned)(per_xcd * 8), 512, CS_SMEM, s>>>(CS_ARGS);
     } else if (tune != 0) {
@@ -1004,6 +1206,17 @@ extern "C" int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x
                     ld_yf, out_scale, false, stream_);
 }
 
+// One 256-column half (0 or 1) of the same application: columns 256 half .. 256 half + 255 of every row.  The halves are
+// independent, so two streams can each carry one half's chain of applications (measured in round 5).
+extern "C" int gp_pool_cs_apply_half(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                                     const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
+                                     int32_t rows_per_block, int32_t half, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
+                                     int64_t ld_yf, const float *out_scale, void *stream_) {
+    GP_CHECK_ARG(half == 0 || half == 1, "gp_pool_cs_apply_half: half=%d (0 or 1)", half);
+    return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, y_hi, y_lo, ld_y, y_f32,
+                    ld_yf, out_scale, false, stream_, half);
+}
+
 // The same application through the persistent producer / consumer engine (cs_engine_kernel); bit-identical results.
 extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                                        const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
@@ -1011,4 +1224,87 @@ extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64
                                        const float *out_scale, void *stream_) {
     return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, y_hi, y_lo, ld_y, y_f32, ld_yf,
                     out_scale, true, stream_);
+}
+
+// ------------------------------------------------------------------------------------------------ the chained launch
+// Dependency lists for gp_pool_cs_apply_chain: dep i32 [nblocks * 64] (word 0 of a row block = n, words 1 .. min(n, 63) = the row
+// blocks whose previous application it waits for; n > 63: every block), scratch i32 [nblocks].  Needs the operator's structure
+// only (bu_off, bu_row: gp_pool_cs_fill or gp_pool_cs_structure), so a scheduler runs it ahead with them.
+extern "C" int gp_pool_cs_deps(const int64_t *bu_off, const int32_t *bu_row, int64_t nv, int32_t rows_per_block, int32_t *dep,
+                               int32_t *scratch, void *stream_) {
+    GP_CHECK_ARG(bu_off && bu_row && dep && scratch && nv > 0, "gp_pool_cs_deps: null/empty argument");
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_deps: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    const int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
+    const int64_t words = (nb + 31) / 32;
+    GP_CHECK_ARG(words * 4 <= 64 * 1024, "gp_pool_cs_deps: %lld row blocks (the block bitmap holds 524288)", (long long)nb);
+    hipStream_t s = gp_stream(stream_);
+    cs_deps_fwd_kernel<<<(unsigned)nb, 256, (size_t)words * 4, s>>>(bu_off, bu_row, nb, rows_per_block, (int)words, dep, scratch);
+    cs_deps_sym_kernel<<<(unsigned)nb, 256, (size_t)words * 4, s>>>(bu_off, bu_row, nb, rows_per_block, (int)words, dep, scratch);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// words of the flags array of gp_pool_cs_apply_chain: 32 header words (word 0 = abort) + 2 column halves x nblocks
+extern "C" size_t gp_pool_cs_chain_flag_words(int64_t nv, int32_t rows_per_block) {
+    if (nv <= 0 || !cs_rpb_ok(rows_per_block)) return 0;
+    return (size_t)CS_FLAG_HDR + 2 * (size_t)((nv + rows_per_block - 1) / rows_per_block);
+}
+
+// ALL `applications` (>= 2) of y = A x in ONE launch: application t reads plane set (t even ? x : p) and writes the other one, the
+// last one writes y_f32 (x out_scale[0]) only -- the same sequence, planes and bits as `applications` calls of gp_pool_cs_apply
+// that ping-pong between x and p.  x_hi / x_lo are REWRITTEN (from application 1 on), as in that sequence.
+//   dep    gp_pool_cs_deps' lists.
+//   flags  u32 [gp_pool_cs_chain_flag_words]: zeroed ONCE by the caller when allocated, never again; word 0 is the abort word: the
+//          kernel sets it to 1 if a workgroup waited 2 s for a dependency (the launch then drains without computing; the outputs
+//          are invalid) -- the caller reads it at its next synchronisation point and must treat non-zero as an error.
+//   epoch  a counter the caller keeps per flags array: every call passes a value at least `applications` above the previous call's
+//          (the published values are epoch + 1 .. epoch + applications - 1; 32-bit wrap-around is handled by signed differences).
+// One flags array serves one launch at a time (launches on one stream are ordered; do not share it between streams).
+// Workgroups wait only for workgroups with a smaller index, so the grid needs no co-residency guarantee beyond the in-order
+// dispatch of workgroups; should that order ever not hold, the bounded wait turns a hang into the abort word.
+extern "C" int gp_pool_cs_apply_chain(void *x_hi, void *x_lo, void *p_hi, void *p_lo, int64_t ld, const int64_t *bu_off,
+                                      const int32_t *bu_row, const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv,
+                                      int32_t d, int32_t rows_per_block, int32_t applications, float *y_f32, int64_t ld_yf,
+                                      const float *out_scale, const int32_t *dep, uint32_t *flags, uint32_t epoch, void *stream_) {
+    GP_CHECK_ARG(x_hi && x_lo && p_hi && p_lo && bu_off && bu_row && bu_mask && wa_hi && wa_lo && y_f32 && dep && flags && nv > 0,
+                 "gp_pool_cs_apply_chain: null/empty argument");
+    GP_CHECK_ARG(d == CS_D, "gp_pool_cs_apply_chain: d=%d (kernel specialised for %d columns)", d, CS_D);
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_apply_chain: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    GP_CHECK_ARG(applications >= 2 && applications < 65536, "gp_pool_cs_apply_chain: applications=%d (2..65535; one: gp_pool_cs_apply)", applications);
+    GP_CHECK_ARG(ld % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0 && (uintptr_t)p_hi % 16 == 0 && (uintptr_t)p_lo % 16 == 0,
+                 "gp_pool_cs_apply_chain: plane rows must be 16-byte aligned");
+    GP_CHECK_ARG(x_hi != p_hi && x_lo != p_lo && x_hi != x_lo && p_hi != p_lo, "gp_pool_cs_apply_chain: the four planes must not alias");
+    GP_CHECK_ARG(ld_yf % 4 == 0 && (uintptr_t)y_f32 % 16 == 0, "gp_pool_cs_apply_chain: fp32 output rows must be 16-byte aligned");
+    hipStream_t s = gp_stream(stream_);
+    const int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
+    const int64_t per_xcd = (nb * (CS_D / CS_NC) + 7) / 8;
+    const int64_t grid = per_xcd * 8 * applications;
+    GP_CHECK_ARG(grid < (int64_t)INT32_MAX, "gp_pool_cs_apply_chain: %lld workgroups", (long long)grid);
+    CsChain ch;
+    ch.a_hi = static_cast<const _Float16 *>(x_hi);
+    ch.a_lo = static_cast<const _Float16 *>(x_lo);
+    ch.b_hi = static_cast<_Float16 *>(p_hi);
+    ch.b_lo = static_cast<_Float16 *>(p_lo);
+    ch.ld = ld;
+    ch.flags = flags;
+    ch.dep = dep;
+    ch.T = applications;
+    ch.base = epoch;
+    uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[0]);
+    GP_CHECK_ARG(!stamp || g_gp_debug_bytes[0] >= (size_t)grid * CS_NW * 10 * sizeof(uint64_t),
+                 "gp_pool_cs_apply_chain: the stamp buffer of gp_debug_ptr(0) holds %zu bytes, this launch writes %zu",
+                 g_gp_debug_bytes[0], (size_t)grid * CS_NW * 10 * sizeof(uint64_t));
+    if (stamp) {
+        GP_SMEM_ATTR(cs_chain_kernel<true>, CS_SMEM);
+        cs_chain_kernel<true><<<(unsigned)grid, 512, CS_SMEM, s>>>(ch, bu_off, bu_row, bu_mask, static_cast<const _Float16 *>(wa_hi),
+                                                                    static_cast<const _Float16 *>(wa_lo), nv, nb, y_f32, ld_yf, per_xcd,
+                                                                    out_scale, stamp, rows_per_block);
+    } else {
+        GP_SMEM_ATTR(cs_chain_kernel<false>, CS_SMEM);
+        cs_chain_kernel<false><<<(unsigned)grid, 512, CS_SMEM, s>>>(ch, bu_off, bu_row, bu_mask, static_cast<const _Float16 *>(wa_hi),
+                                                                     static_cast<const _Float16 *>(wa_lo), nv, nb, y_f32, ld_yf, per_xcd,
+                                                                     out_scale, nullptr, rows_per_block);
+    }
+    GP_CHECK_LAUNCH();
+    return GP_OK;
 }

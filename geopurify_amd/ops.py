@@ -509,6 +509,8 @@ class PoolCs:
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
         self.block_rows = block_rows
         self.dst = None            # i32 [nv, k]: fragment element of (row, neighbour) once the structure is built ahead
+        self.dep = self.flags = None   # the chained launch's dependency lists and flags (pool_cs_deps)
+        self.epoch = 0
         self.filled = False        # the weights are in the fragments
 
 
@@ -570,6 +572,55 @@ def pool_cs_apply(x_split, op, d, out_split=None, out_f32=None, out_scale=None, 
              op.nv, int(d), int(op.block_rows), _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
              _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _ptr(out_scale), _stream()), name)
     return out_f32 if out_f32 is not None else out_split
+
+
+def pool_cs_apply_half(x_split, op, d, half, out_split=None, out_f32=None, out_scale=None):
+    """One 256-column half (0 / 1) of pool_cs_apply: the halves are independent chains."""
+    lib = _lib.load()
+    xh, xl = x_split
+    yh, yl = out_split if out_split is not None else (None, None)
+    check(lib.gp_pool_cs_apply_half(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row), _ptr(op.bu_mask), _ptr(op.wa_hi),
+                                    _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows), int(half), _ptr(yh), _ptr(yl),
+                                    yh.stride(0) if yh is not None else 0, _ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+                                    _ptr(out_scale), _stream()), "gp_pool_cs_apply_half")
+
+
+def pool_cs_deps(op):
+    """Dependency lists + flags of the chained launch (pool_cs_apply_chain); needs the operator's structure (bu_row) only."""
+    lib = _lib.load()
+    dev = op.bu_row.device
+    nb = op.bu_off.numel() - 1
+    op.dep = torch.empty(nb * 64, dtype=torch.int32, device=dev)
+    scratch = torch.empty(nb, dtype=torch.int32, device=dev)
+    check(lib.gp_pool_cs_deps(_ptr(op.bu_off), _ptr(op.bu_row), op.nv, int(op.block_rows), _ptr(op.dep), _ptr(scratch), _stream()),
+          "gp_pool_cs_deps")
+    op.flags = torch.zeros(lib.gp_pool_cs_chain_flag_words(op.nv, int(op.block_rows)), dtype=torch.int32, device=dev)
+    op.epoch = 0
+    return op
+
+
+def pool_cs_apply_chain(x_split, pong, op, d, applications, out_f32, out_scale=None):
+    """All `applications` (>= 2) of the operator in ONE launch (gp_pool_cs_apply_chain): the same planes and bits as that many
+    pool_cs_apply calls ping-ponging between x_split and pong; x_split is rewritten.  op.flags[0] != 0 afterwards (read at the
+    caller's next synchronisation point: pool_cs_chain_check) means the launch gave up and the outputs are invalid."""
+    lib = _lib.load()
+    if getattr(op, "dep", None) is None:
+        pool_cs_deps(op)
+    xh, xl = x_split
+    ph, pl_ = pong
+    assert xh.stride(0) == xl.stride(0) == ph.stride(0) == pl_.stride(0)
+    check(lib.gp_pool_cs_apply_chain(_ptr(xh), _ptr(xl), _ptr(ph), _ptr(pl_), xh.stride(0), _ptr(op.bu_off), _ptr(op.bu_row),
+                                     _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo), op.nv, int(d), int(op.block_rows),
+                                     int(applications), _ptr(out_f32), out_f32.stride(0), _ptr(out_scale), _ptr(op.dep), _ptr(op.flags),
+                                     op.epoch & 0xFFFFFFFF, _stream()), "gp_pool_cs_apply_chain")
+    op.epoch += int(applications)
+    return out_f32
+
+
+def pool_cs_chain_check(op):
+    """Host side of the chained launch's contract: raise if the abort word is set (synchronises)."""
+    if getattr(op, "flags", None) is not None and int(op.flags[0].item()) != 0:
+        raise _lib.GeoPurifyHipError("gp_pool_cs_apply_chain: a workgroup waited 2 s for a dependency; the pooled features are invalid")
 
 
 def pool_mfma_apply_persistent(x_split, op, d, out_split=None, out_f32=None, out_scale=None, dynamic=True):

@@ -289,6 +289,30 @@ int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64_t ld_x, co
                             const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                             int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
                             const float *out_scale, void *stream);
+/* One 256-column half (0 or 1) of the same application; the halves are independent (two streams can each carry one).     */
+int gp_pool_cs_apply_half(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
+                          const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
+                          int32_t rows_per_block, int32_t half, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32,
+                          int64_t ld_yf, const float *out_scale, void *stream);
+/* ALL `applications` (2..65535) of the operator in ONE launch (the T = 19 torch.sparse.mm calls of                          */
+/* models/affinity_module.py:1575-1587 as one kernel): application t reads plane set (t even ? x : p) and writes the other   */
+/* one, the last one writes y_f32 (x out_scale[0]) only -- the sequence, planes and bits of `applications` calls of           */
+/* gp_pool_cs_apply ping-ponging between x and p; x_hi / x_lo are rewritten from application 1 on.  A row block's tile of     */
+/* application t starts when the row blocks of its dependency list have published application t - 1 (per-block flags,         */
+/* written-through stores, L1-bypassing gathers); workgroups wait only for workgroups with a smaller index.                   */
+/*   gp_pool_cs_deps: dep i32 [nblocks * 64] from the operator's structure (bu_off, bu_row), scratch i32 [nblocks].           */
+/*   flags u32 [gp_pool_cs_chain_flag_words()]: zeroed ONCE at allocation.  Word 0 is the ABORT word: set to 1 by the kernel   */
+/*     if a workgroup waited 2 s for a dependency (the launch drains without computing, outputs invalid); the caller reads it   */
+/*     at its next synchronisation point and treats non-zero as an error.                                                     */
+/*   epoch: kept by the caller per flags array, each call at least `applications` above the previous call's.                  */
+/* One flags array serves one launch at a time (do not share it between streams).                                             */
+int gp_pool_cs_deps(const int64_t *bu_off, const int32_t *bu_row, int64_t nv, int32_t rows_per_block, int32_t *dep,
+                    int32_t *scratch, void *stream);
+size_t gp_pool_cs_chain_flag_words(int64_t nv, int32_t rows_per_block);
+int gp_pool_cs_apply_chain(void *x_hi, void *x_lo, void *p_hi, void *p_lo, int64_t ld, const int64_t *bu_off,
+                           const int32_t *bu_row, const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv,
+                           int32_t d, int32_t rows_per_block, int32_t applications, float *y_f32, int64_t ld_yf,
+                           const float *out_scale, const int32_t *dep, uint32_t *flags, uint32_t epoch, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rows 5-7: 2D->3D lift (models/affinity_module.py:416-449, 495-646, 647-696).                   */
