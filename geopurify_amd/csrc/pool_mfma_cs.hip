@@ -75,19 +75,23 @@ __device__ __forceinline__ void cs_glds16(const void *g, void *l) {
 }
 // agent-visible accesses of the chained launch (cs_chain_kernel): sc1 stores are written through to memory, sc1 loads are never
 // served by a CU's L1 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility")
-__device__ __forceinline__ uint32_t cs_ld_sc1(const uint32_t *p) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+__device__ __forceinline__ uint32_t cs_ld_sc1(const uint32_t *p) {           // global_load_dword ... sc1 (the compiler counts it in vmcnt)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void cs_st_sc1(uint32_t *p, uint32_t v) {
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void cs_st_sc1(uint32_t *p, uint32_t v) {         // global_store_dword ... sc1
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 16-byte written-through store.  There is no compiler-visible form (agent-scope atomic stores stop at 8 bytes, which move at
+// 0.54-0.70 x the 16-byte rate), so it is inline asm -- and the hazard recogniser does not look inside inline asm: a store of more
+// than 64 bits reads its data registers AFTER issue, gfx950 needs two wait states before a VALU may overwrite them.  The first
+// build of this kernel had the next address computed into the first store's data registers in the very next instruction (28 % of
+// the hi rows came out as garbage, the lo rows -- second store, nothing behind it -- fine): the s_nop belongs to the store.
 template <typename V>
 __device__ __forceinline__ void cs_st16_sc1(void *p, V v) {
     static_assert(sizeof(V) == 16, "16-byte store");
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+
 template <int OFF>
 __device__ __forceinline__ void cs_tr(s16x4 &d, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
@@ -387,7 +391,6 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
                     v = cs_ld_sc1(fl + i0 + lane);
                 }
                 if (lane == 0) ab = cs_ld_sc1(ch.flags);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(ab)::"memory");
                 if (__builtin_amdgcn_readfirstlane(ab) != 0) return;                       // (all eight waves see it: the workgroup leaves)
                 if (__ballot((int32_t)(v - want) < 0) == 0ull) {
                     if (n < CS_DEP_CAP || (i0 += 64) >= nblocks) break;
