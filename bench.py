@@ -38,7 +38,13 @@ def parse():
     ap.add_argument("--config", default="S", choices=["P", "S", "M", "T", "V"],
                     help="S = BASELINE configs[1] (default); V = configs[2]: ScanNet-val scene SIZES (tests/golden/"
                          "scannet_val_point_counts.txt), a fixed subset of --val-scenes per GPU, sharded over the ranks")
-    ap.add_argument("--val-scenes", type=int, default=16, help="config V: scenes per GPU")
+    ap.add_argument("--val-scenes", type=int, default=None,
+                    help="config V: scenes per GPU.  Default: ceil(312 / N) for N > 1 GPUs -- BASELINE configs[2]'s 312 ScanNet-val scenes "
+                         "in total (run/validation.py:269-286 splits the whole list over the ranks) -- and a 16-scene stride subset at N = 1 "
+                         "(generating 312 synthetic scenes on one rank's host cores takes tens of minutes; --val-scenes 312 runs them all)")
+    ap.add_argument("--rank-timeout", type=float, default=float(os.environ.get("GP_BENCH_RANK_TIMEOUT", "2400")),
+                    help="--gpus N > 1 without a launcher: wall-clock limit (s) of the child launcher; on expiry its process group is "
+                         "killed, the ranks' last stderr lines are shown and bench.py exits non-zero")
     ap.add_argument("--shard-policy", default="lpt", choices=["lpt", "contiguous"], help="config V: scene -> rank assignment")
     ap.add_argument("--cpu-sample", default="full", choices=["full", "bounded"],
                     help="cpu_baseline: one whole scene of the workload through the oracle (measured, ~1 min at S) or the "
@@ -470,33 +476,77 @@ def val_scene_sizes(per_gpu, world):
     return [sizes[(i * len(sizes)) // n] for i in range(n)]
 
 
-def launch_ranks(n):
+VAL_SCENES_TOTAL = 312                                    # BASELINE configs[2]: the ScanNet-val list (dataset/scannet_val_metrics.tsv)
+
+
+def default_val_scenes(n_gpus):
+    """--val-scenes when not given: the whole 312-scene list split over N > 1 ranks, a 16-scene stride subset on one GPU."""
+    return 16 if n_gpus <= 1 else -(-VAL_SCENES_TOTAL // n_gpus)
+
+
+def launch_ranks(n, limit_s):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks HERE.  The parent never touches
     the GPU (no HIP call, no torch.cuda.is_available()): it starts `python -m torch.distributed.run --nproc-per-node N bench.py
-    <same arguments>` as a CHILD process (never an exec of itself), passes stderr through, relays rank 0's single JSON line
-    and exits non-zero if the launcher does or if the line does not say n_gpus == N.  One process per GPU, scenes sharded by
-    the split rule of run/validation.py:269-286, ONE all-reduce of the IoU counts (:441-450) over RCCL (backend "nccl")."""
+    <same arguments>` as a CHILD process (never an exec of itself), relays rank 0's single JSON line and exits non-zero if the
+    launcher does, if the line does not say n_gpus == N, or if the child is still running after limit_s seconds of wall clock
+    (a hung rank: a collective that never completes, a dead peer) -- its whole process group is then killed and the last stderr
+    lines of the ranks are repeated.  One process per GPU, scenes sharded by the split rule of run/validation.py:269-286, ONE
+    all-reduce of the IoU counts (:441-450) over RCCL (backend "nccl")."""
+    import collections
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    log(f"--gpus {n} without a launcher: starting {n} ranks (limit {limit_s:.0f} s): {' '.join(cmd)}")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    tail = collections.deque(maxlen=60)
+    out_lines = []
+
+    def pump_err():
+        for ln in p.stderr:
+            tail.append(ln.rstrip("\n"))
+            print(ln, end="", file=sys.stderr, flush=True)
+
+    def pump_out():
+        for ln in p.stdout:
+            out_lines.append(ln.rstrip("\n"))
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    try:
+        rc = p.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        log(f"the {n} ranks are still running after {limit_s:.0f} s: killing the launcher's process group")
+        try:
+            os.killpg(p.pid, signal.SIGKILL)             # (the child leads its own session: launcher + every rank, nothing else)
+        except ProcessLookupError:
+            pass
+        p.wait()
+        for t in threads:
+            t.join(5)
+        log("last stderr lines of the ranks:")
+        for ln in list(tail)[-30:]:
+            print("    " + ln, file=sys.stderr)
+        sys.exit(124)
+    for t in threads:
+        t.join(5)
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in out_lines:
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         else:
             print(ln, file=sys.stderr)
-    if p.returncode != 0:
-        log(f"the launcher exited with {p.returncode}")
-        sys.exit(p.returncode)
+    if rc != 0:
+        log(f"the launcher exited with {rc}")
+        sys.exit(rc)
     if line is None:
         log("no JSON line from rank 0")
         sys.exit(1)
@@ -511,8 +561,12 @@ def launch_ranks(n):
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        launch_ranks(args.gpus)                           # does not return
+        launch_ranks(args.gpus, args.rank_timeout)        # does not return
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("GP_BENCH_SELFTEST_HANG") in (str(rank), "all"):   # tests/test_host_logic.py: ranks that never come back
+        time.sleep(3600)
+    if args.val_scenes is None:
+        args.val_scenes = default_val_scenes(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:

@@ -359,6 +359,7 @@ class HotPath:
         self._taps = {}
         self.stats = {}
         self.stage_mark = None                          # optional callable(name): bench.py's per-stage HIP events (side pass only)
+        self.keep_lifted, self.last_lifted = False, None  # parity tests: evaluate_scene keeps the lifted features [N, D] it refined
 
     def _tap_tables(self, h, w):
         key = (h, w)
@@ -661,6 +662,8 @@ class HotPath:
             F, text, scale = self.lift_dense(batch, vlm)
         else:
             F, text, scale = self.lift_masks(batch, vlm)
+        if self.keep_lifted:                 # (parity tests compare the lift stage too; off by default: the tensor is 300 MB at S)
+            self.last_lifted = F
         return {"scene_features": self.refine(batch, F), "text_features": text, "logit_scale": scale}
 
     # ---- row 13 + caller tail --------------------------------------------------------------------

@@ -246,7 +246,12 @@ def fuse_views_top3(N, point_idx_views, f_views, logits_views, scene_coords, fai
                 for k, (a, b) in enumerate(vd):
                     pf[j, k] = a
                     pl[j, k] = b
-            out[ck] = _fuse_chunk(pf, pl, valid)
+            if return_debug:
+                out[ck], mc, mk = _fuse_chunk(pf, pl, valid, margins=True)
+                dbg.setdefault("class_margin", torch.full((N,), float("inf")))[ck] = mc
+                dbg.setdefault("cut_margin", torch.full((N,), float("inf")))[ck] = mk
+            else:
+                out[ck] = _fuse_chunk(pf, pl, valid)
     else:
         # vectorised: same math; slot k of point p = its k-th surviving view in ascending view order
         for pi in point_idx_views:
@@ -273,7 +278,12 @@ def fuse_views_top3(N, point_idx_views, f_views, logits_views, scene_coords, fai
                 pl[rr, ss] = lg[sel]
                 valid[rr, ss] = True
                 slot[pi[sel]] += 1
-            out[ck] = _fuse_chunk(pf, pl, valid)
+            if return_debug:
+                out[ck], mc, mk = _fuse_chunk(pf, pl, valid, margins=True)
+                dbg.setdefault("class_margin", torch.full((N,), float("inf")))[ck] = mc
+                dbg.setdefault("cut_margin", torch.full((N,), float("inf")))[ck] = mk
+            else:
+                out[ck] = _fuse_chunk(pf, pl, valid)
         del slot_of, M
     seen = counter != 0
     dbg["seen"] = seen
@@ -287,8 +297,10 @@ def fuse_views_top3(N, point_idx_views, f_views, logits_views, scene_coords, fai
     return out
 
 
-def _fuse_chunk(pf, pl, valid):
-    """affinity_module.py:672-683."""
+def _fuse_chunk(pf, pl, valid, margins=False):
+    """affinity_module.py:672-683.  margins=True also returns the two decision margins of every point (parity bookkeeping, not
+    part of the reference): consensus class (best minus second-best mean logit) and the top-3 cut (third minus fourth agreement
+    among the valid views; +inf with three views or fewer)."""
     Mc = pf.shape[1]
     K = min(Mc, 3)
     avg = pl.sum(1) / valid.sum(1, keepdim=True).clamp(min=1)
@@ -298,4 +310,17 @@ def _fuse_chunk(pf, pl, valid):
     top_s, top_i = torch.topk(agree, k=K, dim=1)
     top_f = torch.gather(pf, 1, top_i.unsqueeze(-1).expand(-1, -1, pf.shape[2]))
     w = F.softmax(top_s, dim=1)
-    return (top_f * w.unsqueeze(-1)).sum(1)
+    out = (top_f * w.unsqueeze(-1)).sum(1)
+    if not margins:
+        return out
+    if avg.shape[1] > 1:
+        a2 = avg.topk(2, dim=1).values
+        m_class = a2[:, 0] - a2[:, 1]
+    else:
+        m_class = torch.full((pf.shape[0],), float("inf"))
+    m_cut = torch.full((pf.shape[0],), float("inf"))
+    if Mc > 3:
+        s4 = agree.topk(4, dim=1).values
+        has4 = torch.isfinite(s4[:, 3])
+        m_cut[has4] = (s4[:, 2] - s4[:, 3])[has4]
+    return out, m_class, m_cut

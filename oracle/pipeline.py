@@ -47,8 +47,10 @@ def loader_math(scene, rigid, val_keep=10_000_000):
 
 
 def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=19, vectorised=True,
-                          dense_feat=None, timings=None, num_blocks=None, knn_impl="exact", lseg_feat=None):
-    """Returns dict(scene_features [N,D], text_features, logit_scale, + intermediates)."""
+                          dense_feat=None, timings=None, num_blocks=None, knn_impl="exact", lseg_feat=None, lifted=None):
+    """Returns dict(scene_features [N,D], text_features, logit_scale, + intermediates).
+    lifted: per-point features [N,D] to use INSTEAD of the oracle's own lift (rows 8-12 from a given lift: oracle/parity.py
+    re-derives the downstream stages from the product's lift when a decision inside fp32 rounding noise went the other way)."""
     cfg = scene.cfg
     t0 = time.perf_counter()
 
@@ -65,7 +67,11 @@ def evaluate_scene_oracle(scene, vlm, sd, rigid, K=96, sharpen=20.0, num_iters=1
     xyz32 = torch.from_numpy(scene.coords).float()
     text = torch.from_numpy(vlm["text_embed"])
     scale = float(vlm["logit_scale"])
-    if lseg_feat is not None:                            # LSeg path: (feat_lo [V,D,h,w], image_shape (H,W))
+    if lifted is not None:
+        Fp = torch.as_tensor(lifted).float().cpu()
+        if dense_feat is None and lseg_feat is None and len(ld["views"]):
+            text = F.normalize(text, dim=-1)
+    elif lseg_feat is not None:                            # LSeg path: (feat_lo [V,D,h,w], image_shape (H,W))
         feats = [torch.from_numpy(lseg_feat[0][v["src_view"]]) for v in ld["views"]]
         Fp, _ = lift.lift_lseg(feats, lseg_feat[1], [v["pt"] for v in ld["views"]], [v["x"] for v in ld["views"]],
                                [v["y"] for v in ld["views"]], xyz32)

@@ -458,9 +458,11 @@ def test_lift_masks_view_and_fuse(ops):
     assert torch.equal(seen.cpu(), dbg["seen"])
     if n_margin == 0:
         d = (out.cpu()[dbg["seen"]] - ref[dbg["seen"]]).abs().max(dim=1).values
-        # fused features are convex combinations of unit vectors; near-ties in the top-3 choice are
-        # the only legitimate source of a larger difference
-        assert (d < 1e-5).float().mean() > 0.995 and d.median() < 1e-6
+        # fused features are convex combinations of unit vectors; a row outside 1e-5 must hang on a consensus-class or top-3-cut
+        # decision whose ORACLE margin is inside the rounding noise of the logits (1e-4 on +-14): no blanket allowance
+        near = ((dbg["class_margin"] < 1e-4) | (dbg["cut_margin"] < 1e-4))[dbg["seen"]]
+        assert not ((d >= 1e-5) & ~near).any(), (int(((d >= 1e-5) & ~near).sum()), float(d.max()))
+        assert d.median() < 1e-6
     xyzd = dev(xyz)
     nn = ops.nn1(xyzd[seen].contiguous(), xyzd[~seen].contiguous())
     assert torch.equal(torch.where(seen)[0][nn].cpu(), dbg["fill_src"])

@@ -7,6 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import metric as o_metric  # noqa: E402
+from oracle import parity as o_parity  # noqa: E402
 from oracle import pipeline as o_pipe  # noqa: E402
 
 
@@ -40,12 +41,16 @@ def test_loader_math_bit_exact(env):
 
 
 def test_lift_stage(env):
+    """Rows 5-7: every lifted row within 1e-5 of the oracle's, except rows that hang on a decision (segment arg-max, the 0.5 test,
+    consensus class, top-3 cut) whose ORACLE margin is inside fp32 rounding noise (oracle/parity.py) -- expected: none."""
     hp, b, pl = env["hp"], env["batch"], env["pl"]
     F, text, scale = hp.lift_masks(b, pl.SyntheticVLM(env["vlm_np"], "cuda"))
     d = (F.cpu() - env["ref"]["lifted"]).abs().max(dim=1).values
-    # fused features are convex combinations of unit vectors: 1e-5 absolute; the rare larger
-    # differences are arg-max / top-3 decisions inside fp32 rounding noise of the oracle's own margins
-    assert (d < 1e-5).float().mean() > 0.995, (d < 1e-5).float().mean()
+    near = o_parity.lift_near_ties(env["ref"]["views"], env["vlm_np"], torch.from_numpy(env["scene"].coords).float(),
+                                   env["cfg"].mask_shape, F.shape[0])
+    bad = d > 1e-5
+    print(f"lift: {int(bad.sum())} rows outside 1e-5, {int(near.sum())} near-tie points")
+    assert not (bad & ~near).any(), (int((bad & ~near).sum()), float(d.max()))
     assert d.median() < 1e-6
 
 
@@ -110,17 +115,31 @@ def test_refine_with_a_state_prepared_ahead_on_another_stream(env, env512):
     assert (ahead.cpu() - ref["scene_features"]).abs().max() < 1e-4
 
 
+def _oracle_kwargs(env):
+    return dict(K=env["K"], num_iters=env["T"])
+
+
 def test_end_to_end_features_and_labels(env):
+    """The whole path against the oracle with NO blanket allowance (oracle/parity.py): lifted rows may differ only at decisions
+    inside fp32 rounding noise; pooled features within 1e-4 at EVERY point (of the oracle re-run from the device's lift if such a
+    decision went the other way); every class decision that differs must have an oracle top-2 margin below 1e-4."""
     hp, b, pl, cfg, ref = env["hp"], env["batch"], env["pl"], env["cfg"], env["ref"]
-    res = hp.evaluate_scene(b, pl.SyntheticVLM(env["vlm_np"], "cuda"))
-    d = (res["scene_features"].cpu() - ref["scene_features"]).abs().max(dim=1).values
-    assert (d < 1e-4).float().mean() > 0.995
+    hp.keep_lifted = True
+    try:
+        res = hp.evaluate_scene(b, pl.SyntheticVLM(env["vlm_np"], "cuda"))
+    finally:
+        hp.keep_lifted = False
+    info = o_parity.check_scene(ref, res["scene_features"], hp.last_lifted, env["scene"], env["vlm_np"], env["sd"], env["rigid"],
+                                _oracle_kwargs(env))
     counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device="cuda")
     pred, zero = hp.classify_and_count(res, b.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
-    rpred, (ri, ru, rt) = o_pipe.classify_and_count(ref, env["scene"].labels, cfg.num_classes, cfg.ignore_ids)
-    agree = (pred.cpu() == rpred).float().mean().item()
-    assert agree > 0.995, agree
+    mism, near = o_parity.check_labels(pred, info["target"])
+    print(f"end to end: lift mismatches {info['lift_mismatches']} (near ties {info['lift_near_ties']}), max |d| {info['max_diff']:.2e}, "
+          f"label mismatches {mism} (near ties {near})")
+    rpred, (ri, ru, rt) = o_pipe.classify_and_count(info["target"], env["scene"].labels, cfg.num_classes, cfg.ignore_ids)
     assert np.array_equal(counts[2].cpu().numpy(), rt)     # target histogram is input-only: exact
+    if mism == 0:                                          # no class near tie flipped: the IoU bookkeeping is exact
+        assert np.array_equal(counts[0].cpu().numpy(), ri) and np.array_equal(counts[1].cpu().numpy(), ru)
     assert not zero.any()
 
 
@@ -151,9 +170,11 @@ def test_reference_api_tuple_path(env):
     assert set(groups) == {"input", "middle", "output"} and len(groups["output"]) == 1
     tup = tuple(t.cpu() if torch.is_tensor(t) else t for t in env["batch"].as_tuple())
     assert len(tup) == 20
+    model._hot_path().keep_lifted = True
     bres = model.evaluate_scene(tup)
-    d = (bres["scene_features"].cpu() - ref["scene_features"]).abs().max(dim=1).values
-    assert (d < 1e-4).float().mean() > 0.995, (d < 1e-4).float().mean()          # vs the oracle, north-star tolerance
+    # vs the oracle, north-star tolerance at every point (oracle/parity.py: no blanket allowance)
+    o_parity.check_scene(ref, bres["scene_features"], model._hot_path().last_lifted, env["scene"], env["vlm_np"], env["sd"],
+                         env["rigid"], _oracle_kwargs(env))
     assert (bres["text_features"].cpu() - ref["text_features"]).abs().max() <= 1e-6   # normalised, as the reference returns them
     a = model.evaluate_scene(env["batch"])["scene_features"]
     assert torch.equal(a, bres["scene_features"])                                  # tuple path == SceneBatch path
@@ -192,6 +213,7 @@ def test_dataset_sampler_collate_drive_evaluate_scene():
                                    feature_dim=cfg.feat_dim, embed_dim=128, hidden_dim=128)
     model.affinity_student.load_state_dict(sd)
     model.K, model.num_pool_iters = 24, 3
+    model._hot_path().keep_lifted = True
     res = model.evaluate_scene(tup)
     # oracle on the tuple's own lists (the loader math itself is pinned elsewhere): lift -> mean -> student -> kNN -> pool
     xyz = tup[0]
@@ -213,7 +235,18 @@ def test_dataset_sampler_collate_drive_evaluate_scene():
     nbr = o_aff.knn_lattice(coords, 24)
     Y = o_aff.pool_sparse(X, nbr, o_aff.affinity_weights(E, nbr, 20.0), 3)[inv][:, :cfg.feat_dim]
     d = (res["scene_features"].cpu() - Y).abs().max(dim=1).values
-    assert (d < 1e-4).float().mean() > 0.995, (d < 1e-4).float().mean()
+    # lifted rows: only decisions inside fp32 rounding noise may differ (oracle/parity.py); with none flipped, every point within 1e-4
+    got_lift = model._hot_path().last_lifted.cpu()
+    bad = (got_lift - Fp).abs().max(dim=1).values > 1e-5
+    views = [{"src_view": int(tup[11][i, 0, 0, 0]), "pt": pts[i], "x": tup[12][view_of == i], "y": tup[13][view_of == i]} for i in range(V)]
+    near = o_parity.lift_near_ties(views, vlm_np, xyz, cfg.mask_shape, N)
+    assert not (bad & ~near).any(), int((bad & ~near).sum())
+    if bad.any():                                          # a near tie went the other way: the downstream oracle from the device's lift
+        X = torch.cat([o_aff.scatter_mean(got_lift, inv, coords.shape[0]), o_aff.scatter_mean(tup[19][:, :6], inv, coords.shape[0])], 1)
+        E = o_student.student_forward(X, coords, sd, num_blocks=4)
+        Y = o_aff.pool_sparse(X, nbr, o_aff.affinity_weights(E, nbr, 20.0), 3)[inv][:, :cfg.feat_dim]
+        d = (res["scene_features"].cpu() - Y).abs().max(dim=1).values
+    assert d.max() < 1e-4, (float(d.max()), int(bad.sum()))
 
 
 def test_dense_lift_config(env):

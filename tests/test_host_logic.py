@@ -283,3 +283,33 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--config", "T"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120, cwd=root)
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_rank_watchdog_and_config_v_default():
+    """(a) `bench.py --gpus N --config V` runs BASELINE configs[2]'s 312 scenes IN TOTAL unless --val-scenes is
+    given; (b) a rank that never comes back must not hang `python bench.py --gpus 2`: after --rank-timeout seconds the parent kills
+    the child launcher's process group, repeats the ranks' last stderr lines and exits non-zero (124), printing no JSON line."""
+    import importlib.util
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.default_val_scenes(1) == 16
+    for n in (2, 4, 8):
+        per = bench.default_val_scenes(n)
+        assert per == -(-312 // n) and len(bench.val_scene_sizes(per, n)) == 312      # the whole list, every scene once
+    assert sorted(bench.val_scene_sizes(39, 8)) == sorted(bench.val_scene_sizes(312, 1))
+    if torch.cuda.is_available():
+        return                                                                        # (the hang below is staged before the GPU assertion)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GP_BENCH_SELFTEST_HANG"] = "all"            # every rank sleeps instead of running (a lone sleeper is reaped by the launcher)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "T", "--no-cpu-baseline",
+                          "--rank-timeout", "45"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 124, (out.returncode, out.stderr[-2000:])
+    assert time.time() - t0 < 200
+    assert "still running after 45 s" in out.stderr and "last stderr lines of the ranks" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
