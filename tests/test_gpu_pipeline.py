@@ -139,7 +139,8 @@ def test_end_to_end_features_and_labels(env):
     rpred, (ri, ru, rt) = o_pipe.classify_and_count(info["target"], env["scene"].labels, cfg.num_classes, cfg.ignore_ids)
     assert np.array_equal(counts[2].cpu().numpy(), rt)     # target histogram is input-only: exact
     if mism == 0:                                          # no class near tie flipped: the IoU bookkeeping is exact
-        assert np.array_equal(counts[0].cpu().numpy(), ri) and np.array_equal(counts[1].cpu().numpy(), ru)
+        cn = counts.cpu().numpy()                          # rows: intersection, predicted area, target area
+        assert np.array_equal(cn[0], ri) and np.array_equal(cn[1] + cn[2] - cn[0], ru)
     assert not zero.any()
 
 
