@@ -50,7 +50,7 @@ def parse():
                     help="cpu_baseline: one whole scene of the workload through the oracle (measured, ~1 min at S) or the "
                          "bounded sub-sampled scene extrapolated per stage")
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
-    ap.add_argument("--pool-mode", default="auto", choices=["auto", "mfma_cs", "mfma_engine", "mfma", "mfma_persist", "tiles", "ell"])
+    ap.add_argument("--pool-mode", default=os.environ.get("GP_POOL_MODE", "auto"), choices=["auto", "mfma_cs", "mfma_chain", "mfma_engine", "mfma", "mfma_persist", "tiles", "ell"])
     ap.add_argument("--api", default="both", choices=["device", "both"],
                     help="both: after the headline run also time the DROP-IN call SonataXAffinityTrainer.evaluate_scene(20-tuple of "
                          "CPU tensors) (run/validation.py:408), reported as the extra object `api_tuple` -- never as `value`")
@@ -337,7 +337,7 @@ class PoolTimer:
 
     def wrap(self, ops):
         timer = self
-        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply", "pool_mfma_apply_persistent", "pool_cs_apply"):
+        for name in ("pool_ell", "pool_tiles_apply", "pool_mfma_apply", "pool_mfma_apply_persistent", "pool_cs_apply", "pool_cs_apply_chain"):
             orig = getattr(ops, name)
 
             def timed(*a, _orig=orig, _name=name, **k):
@@ -348,7 +348,10 @@ class PoolTimer:
                 e0.record(s)
                 r = _orig(*a, **k)
                 e1.record(s)
-                nv = int(a[1].nv) if hasattr(a[1], "nv") else int(a[1].shape[0])               # voxel rows of this launch
+                if _name == "pool_cs_apply_chain":            # (x_split, pong, op, d, applications, out): ONE launch = all applications
+                    nv = int(a[2].nv) * int(a[4])
+                else:
+                    nv = int(a[1].nv) if hasattr(a[1], "nv") else int(a[1].shape[0])           # voxel rows of this launch
                 timer.events.append((e0, e1, nv))
                 timer.kernel = _name
                 return r
@@ -852,7 +855,7 @@ def main():
             pool_timer.enabled = False
             alone.append(pool_timer.mean_ms())
         pool_ms_alone = float(np.median(alone))
-        pool_bytes = Nv * per_row
+        pool_bytes = Nv * per_row * (args.pool_iters if hp.stats["pool_kernel"] == "cs_chain_kernel" else 1)   # per LAUNCH
         # the access pattern's own ceiling: the SAME launches with the LDS fragment reads, the MFMAs and the
         # weight-fragment DMA switched off (tuning bits 0 and 3 of the kernel): every union row is still gathered into LDS through
         # the same ring at the same occupancy and every output row is still stored.  Results of these passes are garbage; every
@@ -921,7 +924,9 @@ def main():
                        "sharding": (f"{shard['policy']} assignment of {shard['scenes_total']} scenes to {world} rank(s), " if val_mode else
                                     f"1 scene per GPU x {world}, ") + "one int64 all-reduce of IoU counts",
                        "streams": len(streams), "schedule": "split" if split else "alternate"},
-            "roofline": {"kernel": hp.stats["pool_kernel"] + " (affinity pooling, one application of A)", "bound": "hbm",
+            "roofline": {"kernel": hp.stats["pool_kernel"] + (f" (affinity pooling, all {args.pool_iters} applications of A in one launch)"
+                                                              if hp.stats["pool_kernel"] == "cs_chain_kernel" else " (affinity pooling, one application of A)"),
+                         "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], int(round(tot_rows / n_launch))),
                          "algorithmic_bytes_per_launch": int(round(pool_bytes_mean)), "avg_launch_ms": round(pool_ms, 5),

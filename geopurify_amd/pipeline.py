@@ -359,6 +359,7 @@ class HotPath:
         self._taps = {}
         self.stats = {}
         self.stage_mark = None                          # optional callable(name): bench.py's per-stage HIP events (side pass only)
+        self._chain_ops = []                              # operators of chained pooling launches whose abort word is still unread
         self.keep_lifted, self.last_lifted = False, None  # parity tests: evaluate_scene keeps the lifted features [N, D] it refined
 
     def _tap_tables(self, h, w):
@@ -534,11 +535,14 @@ class HotPath:
         state = {"X": X, "rank": rank, "nbr_map": nbr_map, "pairs": pairs, "nbr": nbr, "Nv": Nv, "D": D, "pool": None,
                  "xs": st.split_input(X)}                   # the first layer's pre-split operand (per-row scales)
         mode = self._pool_mode(D)
-        if mode in ("mfma_cs", "mfma_engine"):
+        if mode in ("mfma_cs", "mfma_engine", "mfma_chain"):
             sc = ops.pow2_scale(X, D)
             state["pool"] = {"op": ops.pool_cs_plan(nbr, structure=self.pool_structure_ahead), "sc": sc,
                              "x_split": ops.split_f16(X, D, scale=sc[0:1]),
                              "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
+            if mode == "mfma_chain" and state["pool"]["op"].dst is not None:      # (the structure is built: the lists need bu_row only)
+                ops.pool_cs_deps(state["pool"]["op"])
+            self.pool_chain_check()                         # this host is synchronised here anyway: earlier scenes' abort words
             mark("pool plan+split")
         return state
 
@@ -577,7 +581,7 @@ class HotPath:
             mode = ("mfma_cs" if cs_ok else "mfma") if ((cs_ok or mfma_ok) and self.num_iters >= 3) else ("tiles" if tiles_ok else "ell")
         if mode in ("mfma", "mfma_persist") and not mfma_ok:
             raise ValueError(f"pool_mode='mfma' needs D == 512 and block_rows*K <= 16384 (D={D}, K={self.K})")
-        if mode in ("mfma_cs", "mfma_engine") and not cs_ok:
+        if mode in ("mfma_cs", "mfma_engine", "mfma_chain") and not cs_ok:
             raise ValueError(f"pool_mode='{mode}' needs D == 512 and K <= 96 (D={D}, K={self.K})")
         return mode
 
@@ -594,7 +598,7 @@ class HotPath:
             out.copy_(X[:, :D])
             self._pool_kernel = "none"
             return out
-        if mode in ("mfma_cs", "mfma_engine"):
+        if mode in ("mfma_cs", "mfma_engine", "mfma_chain"):
             # column-sliced matrix-core pooling (default): 128-row blocks x 256-column halves, union rows grouped by the 16-row
             # groups that use them, empty weight fragments skipped (pool_mfma_cs.hip).  "mfma_engine": the producer / consumer
             # form of the same operator (persistent, 128-column tiles) -- same bits, same speed on MI355X.
@@ -608,6 +612,15 @@ class HotPath:
             sp = [plan["x_split"], plan["pong"]]
             if self.stage_mark is not None:
                 self.stage_mark("pool operator fill")
+            if mode == "mfma_chain" and self.num_iters >= 2:
+                # all applications in ONE launch (gp_pool_cs_apply_chain: per-block flags instead of kernel boundaries; same planes,
+                # same bits).  The abort word of its contract is read at the next host synchronisation (pool_chain_check).
+                if op.dep is None:
+                    ops.pool_cs_deps(op)
+                ops.pool_cs_apply_chain(sp[0], sp[1], op, D, self.num_iters, out, out_scale=sc[1:2])
+                self._chain_ops.append(op)
+                self._pool_kernel = "cs_chain_kernel"
+                return out
             src = sp[0]
             for t in range(self.num_iters):
                 last = t == self.num_iters - 1
@@ -665,6 +678,12 @@ class HotPath:
         if self.keep_lifted:                 # (parity tests compare the lift stage too; off by default: the tensor is 300 MB at S)
             self.last_lifted = F
         return {"scene_features": self.refine(batch, F), "text_features": text, "logit_scale": scale}
+
+    def pool_chain_check(self):
+        """Host side of gp_pool_cs_apply_chain's contract: raise if a chained pooling launch gave up (synchronises on the words)."""
+        pending, self._chain_ops = self._chain_ops, []
+        for op in pending:
+            ops.pool_cs_chain_check(op)
 
     # ---- row 13 + caller tail --------------------------------------------------------------------
     def classify_and_count(self, result, labels, num_classes, ignore_ids, counts):

@@ -379,3 +379,67 @@ def test_config_p_full_size_properties():
     assert r["hp"].stats["pool_kernel"] == "pool_ell_kernel"
     # dense lift: a seen point's feature is the mean of its pixels' columns; every point has one (nearest-seen fill): no zero rows
     assert bool((r["F"].abs().sum(1) > 0).all())
+
+
+def test_pooling_chained_launch_full_size(big):
+    """gp_pool_cs_apply_chain (all T applications in ONE launch, per-block flags instead of kernel boundaries) at full size:
+    the planes and the fp32 output of T = 19 and T = 2 must be BIT-identical to T launches of the default kernel -- from NaN-poisoned
+    buffers, three times, and beside a second stream that streams copies through HBM (the hand-off under uneven load: every word is
+    compared) -- the dependency lists must equal numpy's symmetric closure of the union rows, and the abort word must stay 0."""
+    ops, nbr, w = big["ops"], big["nbr"], big["w"]
+    Nv, D = nbr.shape[0], 512
+    op = ops.pool_cs_build(nbr, w)
+    ops.pool_cs_deps(op)
+    off, row = op.bu_off.cpu().numpy(), op.bu_row.cpu().numpy()
+    nb = off.size - 1
+    src, dst = np.repeat(np.arange(nb), np.diff(off)), row // 128
+    e = np.unique(np.concatenate([src * nb + dst, dst * nb + src, np.arange(nb) * (nb + 1)]))
+    want = np.split(e % nb, np.cumsum(np.bincount(e // nb, minlength=nb))[:-1])
+    got = op.dep.view(-1, 64).cpu().numpy()
+    assert all(g[0] == len(wl) and (g[0] > 63 or set(g[1:g[0] + 1].tolist()) == set(wl.tolist())) for g, wl in zip(got, want))
+    X = torch.randn(Nv, 544, device="cuda")
+    sc = ops.pow2_scale(X, D)
+    x0 = ops.split_f16(X, D, scale=sc[0:1])
+
+    def launches(T):
+        sp = [tuple(t.clone() for t in x0), tuple(torch.full((Nv, D), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))]
+        out = torch.full((Nv, D), float("nan"), device="cuda")
+        src_ = sp[0]
+        for t in range(T):
+            last = t == T - 1
+            dst_ = None if last else sp[(t + 1) % 2]
+            ops.pool_cs_apply(src_, op, D, out_split=dst_, out_f32=out if last else None, out_scale=sc[1:2] if last else None)
+            src_ = dst_
+        return [out, *sp[0], *sp[1]]
+
+    def chain(T):
+        xs = tuple(t.clone() for t in x0)
+        pong = tuple(torch.full((Nv, D), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+        out = torch.full((Nv, D), float("nan"), device="cuda")
+        ops.pool_cs_apply_chain(xs, pong, op, D, T, out, out_scale=sc[1:2])
+        return [out, *xs, *pong]
+
+    side = torch.cuda.Stream()
+    big_a = torch.empty(128 << 20, dtype=torch.float32, device="cuda")
+    big_b = torch.empty_like(big_a)
+    for T in (2, 19):
+        ref = launches(T)
+        assert torch.isfinite(ref[0]).all()
+        for rep in range(3):
+            if rep == 2:
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        big_b.copy_(big_a)
+            got_t = chain(T)
+            torch.cuda.synchronize()
+            for a, b in zip(got_t, ref):
+                assert torch.equal(a, b)
+    ops.pool_cs_chain_check(op)                                 # abort word 0
+    assert op.epoch == 3 * (2 + 19)
+    # two chained applications == the fp32 ELL kernel twice
+    y1 = torch.empty(Nv, D, device="cuda")
+    y2 = torch.empty(Nv, D, device="cuda")
+    ops.pool_ell(X, nbr, w, D, y1)
+    ops.pool_ell(y1, nbr, w, D, y2)
+    assert (chain(2)[0] - y2).abs().max() < 2e-5

@@ -940,6 +940,57 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     assert keys == sorted(keys)
 
 
+@pytest.mark.parametrize("kind,rpb,T", [("lattice", 128, 4), ("lattice", 100, 3), ("random", 128, 4), ("random", 117, 2)])
+def test_pool_cs_chained_launch_small_and_overflowing_lists(ops, kind, rpb, T):
+    """gp_pool_cs_apply_chain on small operators: bit-identical to T launches of gp_pool_cs_apply for ragged block heights, and for
+    neighbour lists that are NOT local (random ids: every row block depends on more than 63 others, so every tile takes the
+    "wait for every block" path of its dependency list); dependency lists against numpy; epochs across repeated calls."""
+    rng = np.random.default_rng(5)
+    K, D = 96, 512
+    if kind == "lattice":
+        c = surface_voxels(rng, 9000)
+        ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+        Nv = len(c)
+        nbr = ops.knn_lattice(grid, cs, perm, K)
+    else:
+        Nv = 9100
+        nbr = torch.from_numpy(np.stack([rng.choice(Nv, K, replace=False) for _ in range(Nv)]).astype(np.int32)).cuda()
+    w = torch.softmax(torch.randn(Nv, K, device="cuda"), dim=1).contiguous()
+    op = ops.pool_cs_build(nbr, w, rows_per_block=rpb)
+    ops.pool_cs_deps(op)
+    off, row = op.bu_off.cpu().numpy(), op.bu_row.cpu().numpy()
+    nb = off.size - 1
+    src, dst = np.repeat(np.arange(nb), np.diff(off)), row // rpb
+    e = np.unique(np.concatenate([src * nb + dst, dst * nb + src, np.arange(nb) * (nb + 1)]))
+    want = np.split(e % nb, np.cumsum(np.bincount(e // nb, minlength=nb))[:-1])
+    got = op.dep.view(-1, 64).cpu().numpy()
+    for g, wl in zip(got, want):
+        assert (g[0] > 63 and len(wl) > 63) or (g[0] == len(wl) and set(g[1:g[0] + 1].tolist()) == set(wl.tolist()))
+    assert (got[:, 0] > 63).all() == (kind == "random")
+    X = torch.randn(Nv, 544, device="cuda")
+    x0 = ops.split_f16(X, D)
+    for rep in range(3):
+        sp = [tuple(t.clone() for t in x0), tuple(torch.full((Nv, D), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))]
+        ref = torch.full((Nv, D), float("nan"), device="cuda")
+        src_ = sp[0]
+        for t in range(T):
+            last = t == T - 1
+            dst_ = None if last else sp[(t + 1) % 2]
+            ops.pool_cs_apply(src_, op, D, out_split=dst_, out_f32=ref if last else None)
+            src_ = dst_
+        xs = tuple(t.clone() for t in x0)
+        pong = tuple(torch.full((Nv, D), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+        out = torch.full((Nv, D), float("nan"), device="cuda")
+        ops.pool_cs_apply_chain(xs, pong, op, D, T, out)
+        torch.cuda.synchronize()
+        for a, b in zip([out, *xs, *pong], [ref, *sp[0], *sp[1]]):
+            assert torch.equal(a, b)
+    ops.pool_cs_chain_check(op)
+    assert op.epoch == 3 * T
+    with pytest.raises(Exception, match="applications"):
+        ops.pool_cs_apply_chain(xs, pong, op, D, 1, out)
+
+
 @pytest.mark.parametrize("n_vox,rpb", [(2500, 128), (2531, 128), (2531, 100), (2500, 117)])
 def test_pool_cs_matches_ell_and_oracle(ops, n_vox, rpb):
     """Column-sliced matrix-core pooling (blocks of rpb <= 128 rows, union rows grouped by the 16-row groups that use them,

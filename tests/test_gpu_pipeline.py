@@ -75,7 +75,7 @@ def env512(env):
     return dict(cfg=cfg, sd=sd, ref=ref, K=K, T=T)
 
 
-@pytest.mark.parametrize("pool_mode,block_rows", [("auto", 64), ("mfma_cs", 64), ("mfma_engine", 64), ("mfma", 64), ("mfma", 128), ("mfma_persist", 64),
+@pytest.mark.parametrize("pool_mode,block_rows", [("auto", 64), ("mfma_cs", 64), ("mfma_chain", 64), ("mfma_engine", 64), ("mfma", 64), ("mfma", 128), ("mfma_persist", 64),
                                                    ("tiles", 64), ("ell", 64)])
 def test_refine_every_pooling_kernel_d512(env, env512, pool_mode, block_rows):
     """rows 8-12 at D = 512 through each pooling kernel (matrix-core, tiled, ELL): same oracle, same tolerance."""
@@ -87,7 +87,8 @@ def test_refine_every_pooling_kernel_d512(env, env512, pool_mode, block_rows):
     assert d < 1e-4, d                                    # north_star: pooled features within 1e-4 fp32
     # K = 32 on this tiny scene: row blocks may have fewer than 4 steps, in which case "mfma_persist" falls back to the
     # one-tile-per-workgroup kernel (the persistent kernel is covered at K = 96 by test_gpu_reference_golden / fullsize)
-    want = {"auto": ("cs_pool_kernel",), "mfma_cs": ("cs_pool_kernel",), "mfma_engine": ("cs_engine_kernel",), "mfma": ("pool_mfma_kernel",), "mfma_persist": ("pool_mfma_persist_kernel", "pool_mfma_kernel"),
+    hp.pool_chain_check()
+    want = {"auto": ("cs_pool_kernel",), "mfma_cs": ("cs_pool_kernel",), "mfma_chain": ("cs_chain_kernel",), "mfma_engine": ("cs_engine_kernel",), "mfma": ("pool_mfma_kernel",), "mfma_persist": ("pool_mfma_persist_kernel", "pool_mfma_kernel"),
             "tiles": ("pool_tiles_kernel",), "ell": ("pool_ell_kernel",)}
     assert hp.stats["pool_kernel"] in want[pool_mode]
 
