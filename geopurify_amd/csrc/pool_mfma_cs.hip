@@ -195,14 +195,19 @@ cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int rpb, int
 // pass 2: the block's union rows in (first group, last group, group set, id) order, one bit per (step, group) that says
 // whether the 16 x 32 weight fragment holds a non-zero, and the ELL weights scattered into MFMA fragment order:
 // wa[(step * 8 + group) * 64 + lane][8], lane = (k >> 3) * 16 + m  (k = union row within the step, m = row within the group).
-// WEIGHTS = false (gp_pool_cs_structure): everything that needs the neighbour lists only -- union rows, masks, zeroed fragments --
+// MODE 1 (gp_pool_cs_structure): everything that needs the neighbour lists only -- union rows, masks, zeroed fragments --
 // and, instead of the weights, dst[row * k + j] = the element index of (row, neighbour j) in the fragment arrays: whoever produces the
 // weights later (gp_affinity_softmax_scatter) stores them straight into fragment order.
-template <bool WEIGHTS>
+// MODE 2 (gp_pool_cs_structure_valid): union rows and masks as before; no fragment is touched; instead valid u32 [steps][128]
+// (bit p of valid[step][row] = union row 32 step + p is a neighbour of that row): gp_affinity_cs_fragments computes every
+// (row, union row) similarity of a fragment on the matrix cores, keeps the valid ones and writes WHOLE fragments.
+constexpr int CS_FILL_WEIGHTS = 0, CS_FILL_DST = 1, CS_FILL_VALID = 2;
+template <int MODE>
 __global__ void __launch_bounds__(1024)
 cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int rpb, const int64_t *__restrict__ bu_off,
                int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo,
-               int32_t *__restrict__ dst) {
+               int32_t *__restrict__ dst, uint32_t *__restrict__ valid) {
+    constexpr bool WEIGHTS = MODE == CS_FILL_WEIGHTS;
     extern __shared__ int s_mem[];                           // A[16384] | B[16384] | npos u16 [br*k]
     int *A = s_mem, *B = s_mem + CS_HS;
     unsigned short *npos = reinterpret_cast<unsigned short *>(s_mem + CS_HS + CS_MAXID);
@@ -255,6 +260,32 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
         s_mask[t] = m;
     }
     __syncthreads();
+    if constexpr (MODE == CS_FILL_VALID) {
+        // validity words: in LDS (A is free now: the order keys have been consumed) while the block's steps x 128 words fit it,
+        // else in global memory (zeroed by this workgroup first: the barrier orders its zero stores before its atomics, both
+        // through the same L2)
+        const int nsteps = Up / CS_KS;
+        const bool in_lds = nsteps * CS_BR <= CS_HS;
+        unsigned *sv = reinterpret_cast<unsigned *>(A);
+        uint32_t *gv = valid + ks0 * CS_BR;
+        __syncthreads();                                      // (every read of A above is done)
+        for (int i = tid; i < nsteps * CS_BR; i += 1024) { if (in_lds) sv[i] = 0u; else gv[i] = 0u; }
+        __syncthreads();
+        for (int t = tid; t < n; t += 1024) {
+            const int rl = t / k;
+            const int id = nb[t];
+            int lo = 0, hi = U - 1;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (B[mid] < id) lo = mid + 1; else hi = mid; }
+            const int p = npos[lo];
+            if (in_lds) atomicOr(&sv[(p / CS_KS) * CS_BR + rl], 1u << (p % CS_KS));
+            else atomicOr(&gv[(p / CS_KS) * CS_BR + rl], 1u << (p % CS_KS));
+        }
+        if (in_lds) {
+            __syncthreads();
+            for (int i = tid; i < nsteps * CS_BR; i += 1024) gv[i] = sv[i];
+        }
+        return;
+    }
     // zero the block's non-empty fragments (the only ones the apply kernel fetches), then scatter into them: the
     // barrier orders this workgroup's zero stores before its element stores (both through the same L2)
     for (int i = tid; i < (Up / CS_KS) * CS_NG * 64; i += 1024) {
@@ -681,6 +712,186 @@ cs_chain_kernel(CsChain ch, const int64_t *__restrict__ bu_off, const int32_t *_
                                      per_xcd, 0, out_scale, stamp, rpb, ch);
 }
 
+// ------------------------------------------------------------------------------------------------ affinity -> fragments
+// Row 11 on the matrix cores, fused with the operator fill (models/affinity_module.py:1559-1572: cosine similarity of the unit
+// embeddings, x sharpen, softmax over a row's K neighbours).  One 512-thread workgroup per row block; wave g owns the block's 16-row
+// group g.  The block's union rows are staged 32 at a time (the pooling kernel's steps) as f16 hi / lo planes of the embeddings x 2^10;
+// for a (step, group) fragment that is not empty the wave computes ALL 32 x 16 similarities of the step's union rows with its rows
+// (2 tiles x 4 K steps x {hi hi, hi lo, lo hi} v_mfma_f32_16x16x32_f16, its own rows' fragments held in registers), keeps the
+// entries whose validity bit is set (gp_pool_cs_structure_valid) in a per-row list in LDS (slot = entries of that row seen so far),
+// runs the softmax of each row over its list (the wave form's arithmetic: true row maximum, expf, fp32 sum) and writes every
+// non-empty fragment WHOLE -- zeros where there is no neighbour -- in the order the pooling kernel reads (weights x 2^10, hi + lo).
+// Against affinity_block_kernel: 0.33 GB gathered instead of 0.95, no dst table, no zeroing pass, fragments in 8-byte pieces instead
+// of 2-byte scatters, and the 12.3 M dot products are 15 us of matrix work.
+constexpr int AF_D = 128;                         // embedding width
+constexpr int AF_RB = AF_D * 2;                   // bytes per staged row and plane
+constexpr int AF_PLANE = CS_KS * AF_RB;           // 8 KiB
+constexpr int AF_STAGE = 2 * AF_PLANE;            // 16 KiB
+constexpr int AF_NST = 3;
+constexpr int AF_KMAX = 96;                       // neighbours per row (the list pitch is AF_KMAX + 1 floats)
+constexpr int AF_PITCH = AF_KMAX + 1;
+constexpr int AF_OFF_V = AF_NST * AF_STAGE;       // the steps' validity words: [stage][wave][64] u32
+constexpr int AF_OFF_P = AF_OFF_V + AF_NST * CS_NW * 256;
+constexpr size_t AF_SMEM = (size_t)AF_OFF_P + (size_t)CS_BR * AF_PITCH * sizeof(float);
+constexpr float AF_ESCALE = 1024.f;               // the embedding planes carry e x 2^10 (lo halves stay normal numbers)
+constexpr int AF_DMA = 3;                         // LDS-DMA instructions per wave and stage: rows hi, rows lo, validity words
+
+__global__ void __launch_bounds__(512, 2)
+affinity_cs_kernel(const _Float16 *__restrict__ e_hi, const _Float16 *__restrict__ e_lo, int64_t nv, float sharpen,
+                   const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
+                   const uint32_t *__restrict__ bu_valid, int64_t nblocks, int rpb, int64_t per_xcd,
+                   _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);                     // wave = 16-row group
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // XCD-contiguous: neighbouring blocks share halo rows in L2
+    if (b >= nblocks) return;
+    const int64_t ub0 = bu_off[b];
+    const int n = (int)((bu_off[b + 1] - ub0) / CS_KS);
+    const int64_t ks0 = ub0 / CS_KS;
+    const int m = lane & 15, q = lane >> 4;
+    float *plist = reinterpret_cast<float *>(smem_raw + AF_OFF_P) + (size_t)(g * 16 + m) * AF_PITCH;   // this lane's row's list
+    const uint32_t plist_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw + AF_OFF_P +
+                             (uint32_t)((g * 16 + m) * AF_PITCH * 4);
+    // ---- this wave's own rows as the B operand (row m of the group, 8 consecutive channels per lane and K step)
+    f16x8 bh[4], bl[4];
+    {
+        int64_t r = b * rpb + g * 16 + m;
+        r = r < nv ? r : nv - 1;                                               // (rows past the end have no valid bit)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bh[ks] = *reinterpret_cast<const f16x8 *>(e_hi + r * AF_D + ks * 32 + q * 8);
+            bl[ks] = *reinterpret_cast<const f16x8 *>(e_lo + r * AF_D + ks * 32 + q * 8);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]), "+v"(bl[0]), "+v"(bl[1]), "+v"(bl[2]), "+v"(bl[3]));
+    }
+    // ---- staging: wave g stages union rows 4 g .. 4 g + 3 of a step: one 1-KiB instruction per plane (lane -> row lane / 16, 16-byte
+    // piece lane % 16) and the step's validity words of ITS rows (64 words from its group's first: the 48 behind its 16 are other
+    // groups' -- fetched, never read; the array is padded by 64 words).  Physical piece p of row r holds logical piece p ^ (r & 15):
+    // the fragment reads of 16 consecutive rows at one logical piece then touch 16 different piece positions (a row is 256 bytes =
+    // all 64 banks).  The loop issues nothing but these LDS-DMA instructions, so `s_waitcnt vmcnt(AF_DMA)` means "the older stage
+    // has landed"; row ids and fragment masks come through the scalar cache.
+    const int srow_l = lane >> 4;
+    const int spiece = (lane & 15) ^ ((4 * g + srow_l) & 15);
+    const int32_t *idg = bu_row + ub0 + 4 * g;
+    const uint32_t *vgl = bu_valid + ks0 * CS_BR + g * 16 + lane;
+    auto issue = [&](int k, int slot) {
+        const i32x4 id4 = *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS);      // (wave-uniform address: a scalar load)
+        const int64_t id = srow_l == 0 ? id4.x : srow_l == 1 ? id4.y : srow_l == 2 ? id4.z : id4.w;
+        unsigned char *dst = smem_raw + slot * AF_STAGE + (4 * g) * AF_RB;
+        cs_glds16<0>(e_hi + id * AF_D + spiece * 8, dst);
+        cs_glds16<0>(e_lo + id * AF_D + spiece * 8, dst + AF_PLANE);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vgl + (int64_t)k * CS_BR),
+                                         (__attribute__((address_space(3))) void *)(smem_raw + AF_OFF_V + (slot * CS_NW + g) * 256), 4, 0, 0);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
+    // fragment read of tile t, K step ks: row i = 16 t + m, logical piece 4 ks + q
+    uint32_t rd[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int i = 16 * t + m;
+            rd[t][ks] = lds0 + (uint32_t)(i * AF_RB + (((4 * ks + q) ^ (i & 15)) << 4));
+        }
+    const uint32_t rdv = lds0 + AF_OFF_V + (uint32_t)(g * 256 + m * 4);
+    const uint32_t *mk = bu_mask + ks0;
+    if (n > 0) issue(0, 0);
+    if (n > 1) issue(1, 1);
+    int base = 0;
+    for (int s = 0; s < n; ++s) {
+        const int slot = s % AF_NST;
+        // the stage of step s has landed when at most the younger stage's AF_DMA instructions are outstanding (this wave's), and the
+        // barrier makes that true for every wave's rows; it also says every wave is done reading the slot that step s + 2 refills
+        if (s + 1 < n) cs_handover<AF_DMA>(); else cs_handover<0>();
+        if (s + 2 < n) issue(s + 2, (s + 2) % AF_NST);
+        const unsigned fm = mk[s];
+        if (!((fm >> g) & 1u)) continue;                                       // wave-uniform: this group has no neighbour in the step
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(rdv + (uint32_t)(slot * CS_NW * 256)) : "memory");
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const uint32_t so = (uint32_t)(slot * AF_STAGE);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                cs_rd128<0>(ah[ks], rd[t][ks] + so);
+                cs_rd128<AF_PLANE>(al[ks], rd[t][ks] + so);
+            }
+            cs_wait_a(ah, al);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh[ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl[ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh[ks], acc[t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));                        // (the validity word: read before the fragments)
+        // C layout: this lane holds union rows 16 t + 4 q + r of the step for its row m
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kb = 16 * t + 4 * q + r;
+                if ((v >> kb) & 1u) {
+                    const int sl = base + __popc(v & ((1u << kb) - 1u));
+                    // (inline asm: a compiler-visible LDS access inside the loop would wait for every LDS-DMA in flight)
+                    if (sl < AF_KMAX) asm volatile("ds_write_b32 %0, %1" ::"v"(plist_a + (uint32_t)(sl * 4)), "v"(acc[t][r]) : "memory");
+                }
+            }
+        base += __popc(v);
+    }
+    // ---- softmax of every row over its list (4 lanes q of a row share it: entries q, q + 4, ...)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the list stores above
+    gp_wave_sync();
+    const int cnt = base < AF_KMAX ? base : AF_KMAX;
+    const float lscale = sharpen / (AF_ESCALE * AF_ESCALE);
+    float mx = -INFINITY;
+    for (int j = q; j < cnt; j += 4) mx = fmaxf(mx, plist[j] * lscale);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    for (int j = q; j < cnt; j += 4) {
+        const float ex = expf(plist[j] * lscale - mx);
+        plist[j] = ex;
+        sum += ex;
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float rs = cnt > 0 ? GP_POOL_CS_WSCALE / sum : 0.f;
+    gp_wave_sync();
+    // ---- the fragments: lane (m, q) holds union rows 16 t + 4 q + r -> fragment lane (2 t + q / 2) * 16 + m, elements 4 (q & 1) + r
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    base = 0;
+    const uint32_t *vg = bu_valid + ks0 * CS_BR + g * 16 + m;
+    for (int s = 0; s < n; ++s) {
+        const unsigned fm = mk[s];
+        if (!((fm >> g) & 1u)) continue;
+        const uint32_t v = vg[(int64_t)s * CS_BR];                               // (no LDS-DMA in flight any more: plain loads)
+        _Float16 *fh = wa_hi + ((ks0 + s) * CS_NG + g) * 512, *fl = wa_lo + ((ks0 + s) * CS_NG + g) * 512;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f16x4 h, l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kb = 16 * t + 4 * q + r;
+                float wv_ = 0.f;
+                if ((v >> kb) & 1u) {
+                    const int sl = base + __popc(v & ((1u << kb) - 1u));
+                    if (sl < AF_KMAX) wv_ = plist[sl] * rs;
+                }
+                h[r] = (_Float16)wv_;
+                l[r] = (_Float16)(wv_ - (float)h[r]);
+            }
+            const int fo = ((2 * t + (q >> 1)) * 16 + m) * 8 + 4 * (q & 1);
+            *reinterpret_cast<f16x4 *>(fh + fo) = h;
+            *reinterpret_cast<f16x4 *>(fl + fo) = l;
+        }
+        base += __popc(v);
+    }
+}
+
 // ---- dependency lists of the chained launch: row block d is in list(b) iff a union row of b lies in d, or one of d lies in b
 __device__ __forceinline__ void cs_dep_bitmap(const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, int64_t b, int rpb,
                                               int words, unsigned *bm) {
@@ -1100,9 +1311,9 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
     size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
-    GP_SMEM_ATTR(cs_fill_kernel<true>, sm_max);
-    cs_fill_kernel<true><<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask, static_cast<_Float16 *>(wa_hi),
-                                                        static_cast<_Float16 *>(wa_lo), nullptr);
+    GP_SMEM_ATTR(cs_fill_kernel<CS_FILL_WEIGHTS>, sm_max);
+    cs_fill_kernel<CS_FILL_WEIGHTS><<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
+                                                                   static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), nullptr, nullptr);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -1123,9 +1334,9 @@ extern "C" int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, i
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
     size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
-    GP_SMEM_ATTR(cs_fill_kernel<false>, sm_max);
-    cs_fill_kernel<false><<<(unsigned)nb, 1024, sm, s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
-                                                         static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), dst);
+    GP_SMEM_ATTR(cs_fill_kernel<CS_FILL_DST>, sm_max);
+    cs_fill_kernel<CS_FILL_DST><<<(unsigned)nb, 1024, sm, s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
+                                                               static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), dst, nullptr);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -1227,6 +1438,52 @@ extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64
                                        const float *out_scale, void *stream_) {
     return cs_apply(x_hi, x_lo, ld_x, bu_off, bu_row, bu_mask, wa_hi, wa_lo, nv, d, rows_per_block, y_hi, y_lo, ld_y, y_f32, ld_yf,
                     out_scale, true, stream_);
+}
+
+// gp_pool_cs_structure for gp_affinity_cs_fragments: union rows, fragment masks and valid u32 [total_rows / 32 * 128 + 64] (bit p of
+// valid[step * 128 + row] = union row 32 step + p of the row's block is one of its neighbours; the last 64 words are padding that the
+// affinity kernel's 64-word fetches may touch).  No fragment is written: the affinity kernel writes every non-empty fragment whole.
+// The neighbour ids of a row must be distinct (a k-NN list is).
+extern "C" int gp_pool_cs_structure_valid(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
+                                          int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, uint32_t *bu_valid, void *stream_) {
+    GP_CHECK_ARG(nbr && bu_off && bu_row && bu_mask && bu_valid && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
+                 "gp_pool_cs_structure_valid: bad argument");
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_structure_valid: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_structure_valid: k=%d too large (128*k <= %d)", k, CS_MAXNK);
+    int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
+    hipStream_t s = gp_stream(stream_);
+    const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
+    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
+    GP_SMEM_ATTR(cs_fill_kernel<CS_FILL_VALID>, sm_max);
+    GP_CHECK_HIP(hipMemsetAsync(bu_valid + total_rows / CS_KS * CS_BR, 0, 64 * sizeof(uint32_t), s));
+    cs_fill_kernel<CS_FILL_VALID><<<(unsigned)nb, 1024, sm, s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask, nullptr, nullptr,
+                                                                 nullptr, bu_valid);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// Row 11 fused with the operator fill, on the matrix cores: from the unit embeddings as f16 hi / lo planes of e x 2^10
+// (gp_split_f16_scaled with scale 1024; d = 128, rows of 128 halves) and the operator's structure (gp_pool_cs_structure_valid) to the
+// weight fragments wa_hi / wa_lo = softmax_j(sharpen * <e_i, e_nbr(i,j)>) x 2^10 in the order gp_pool_cs_apply reads -- the cosine /
+// softmax / COO build of models/affinity_module.py:1559-1572 and the fill pass in one kernel.  k <= 96.  No [nv, k] weight matrix
+// is produced (gp_affinity_softmax does that).
+extern "C" int gp_affinity_cs_fragments(const void *e_hi, const void *e_lo, int64_t nv, int32_t d, int32_t k, float sharpen,
+                                        const int64_t *bu_off, const int32_t *bu_row, const uint32_t *bu_mask, const uint32_t *bu_valid,
+                                        int32_t rows_per_block, void *wa_hi, void *wa_lo, void *stream_) {
+    GP_CHECK_ARG(e_hi && e_lo && bu_off && bu_row && bu_mask && bu_valid && wa_hi && wa_lo && nv > 0, "gp_affinity_cs_fragments: null/empty argument");
+    GP_CHECK_ARG(d == AF_D, "gp_affinity_cs_fragments: d=%d (kernel specialised for %d-wide embeddings)", d, AF_D);
+    GP_CHECK_ARG(k > 0 && k <= AF_KMAX, "gp_affinity_cs_fragments: k=%d (1..%d)", k, AF_KMAX);
+    GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_affinity_cs_fragments: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
+    GP_CHECK_ARG((uintptr_t)e_hi % 16 == 0 && (uintptr_t)e_lo % 16 == 0, "gp_affinity_cs_fragments: embedding planes must be 16-byte aligned");
+    hipStream_t s = gp_stream(stream_);
+    const int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
+    const int64_t per_xcd = (nb + 7) / 8;
+    GP_SMEM_ATTR(affinity_cs_kernel, AF_SMEM);
+    affinity_cs_kernel<<<(unsigned)(per_xcd * 8), 512, AF_SMEM, s>>>(static_cast<const _Float16 *>(e_hi), static_cast<const _Float16 *>(e_lo), nv,
+                                                                     sharpen, bu_off, bu_row, bu_mask, bu_valid, nb, rows_per_block, per_xcd,
+                                                                     static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ the chained launch

@@ -403,6 +403,26 @@ def affinity_softmax(e, nbr, sharpen=20.0, d=None, into=None):
     return w
 
 
+_E_SCALE = {}
+
+
+def affinity_cs_fragments(e, sharpen, op):
+    """Row 11 + the operator fill in one matrix-core kernel (gp_affinity_cs_fragments): e fp32 [nv, 128] unit rows, op a PoolCs whose
+    structure was built with pool_cs_plan(structure="valid").  Completes op (no [nv, k] weight matrix is produced)."""
+    lib = _lib.load()
+    if op.valid is None:
+        raise ValueError("affinity_cs_fragments: the operator needs pool_cs_plan(structure='valid')")
+    key = str(e.device)
+    if key not in _E_SCALE:
+        _E_SCALE[key] = torch.tensor([1024.0], dtype=torch.float32, device=e.device)
+    eh, el = split_f16(e, 128, scale=_E_SCALE[key])
+    check(lib.gp_affinity_cs_fragments(_ptr(eh), _ptr(el), op.nv, 128, int(op.k), float(sharpen), _ptr(op.bu_off), _ptr(op.bu_row),
+                                       _ptr(op.bu_mask), _ptr(op.valid), int(op.block_rows), _ptr(op.wa_hi), _ptr(op.wa_lo), _stream()),
+          "gp_affinity_cs_fragments")
+    op.filled = True
+    return op
+
+
 def pool_ell(x, nbr, w, d, out):
     lib = _lib.load()
     nv, k = nbr.shape
@@ -509,6 +529,8 @@ class PoolCs:
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
         self.block_rows = block_rows
         self.dst = None            # i32 [nv, k]: fragment element of (row, neighbour) once the structure is built ahead
+        self.valid = None          # u32 validity words once the structure is built for affinity_cs_fragments; k: its list length
+        self.k = 0
         self.dep = self.flags = None   # the chained launch's dependency lists and flags (pool_cs_deps)
         self.epoch = 0
         self.filled = False        # the weights are in the fragments
@@ -535,6 +557,14 @@ def pool_cs_plan(nbr, rows_per_block=128, structure=False):
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
     op = PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb)
+    if structure == "valid":
+        # the structure for affinity_cs_fragments: validity bits instead of the dst table, no fragment zeroed (that kernel writes
+        # every non-empty fragment whole)
+        op.valid = torch.empty(total // 32 * 128 + 64, dtype=torch.int32, device=dev)
+        check(lib.gp_pool_cs_structure_valid(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(op.valid),
+                                             _stream()), "gp_pool_cs_structure_valid")
+        op.k = int(k)
+        return op
     if structure and total * 128 < 2 ** 31:
         # everything of the fill pass that needs the lists only, + where each (row, neighbour) weight goes: affinity_softmax(into=op)
         # then completes the operator

@@ -353,6 +353,8 @@ class HotPath:
         # weights in fragment order and no fill pass sits between the student and the pooling (GP_POOL_STRUCTURE_AHEAD=0: the
         # two-pass form of rounds 3-4, for A/B timing)
         self.pool_structure_ahead = os.environ.get("GP_POOL_STRUCTURE_AHEAD", "1") != "0"
+        # rows 11 + operator fill as one matrix-core kernel (GP_AFFINITY_MFMA=0: affinity_block_kernel + dst table, for A/B timing)
+        self.affinity_mfma = os.environ.get("GP_AFFINITY_MFMA", "1") != "0"
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
         self.device = torch.device(device)
@@ -537,10 +539,15 @@ class HotPath:
         mode = self._pool_mode(D)
         if mode in ("mfma_cs", "mfma_engine", "mfma_chain"):
             sc = ops.pow2_scale(X, D)
-            state["pool"] = {"op": ops.pool_cs_plan(nbr, structure=self.pool_structure_ahead), "sc": sc,
+            # "valid": the structure for the matrix-core affinity kernel (gp_affinity_cs_fragments: needs 128-wide embeddings and
+            # K <= 96); True: the dst table of rounds 3-4 (affinity_block_kernel scatters its weights); False: the two-pass build
+            how = self.pool_structure_ahead
+            if how and self.affinity_mfma and self.K <= 96 and self.student is not None and self.student.embed == 128:
+                how = "valid"
+            state["pool"] = {"op": ops.pool_cs_plan(nbr, structure=how), "sc": sc,
                              "x_split": ops.split_f16(X, D, scale=sc[0:1]),
                              "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
-            if mode == "mfma_chain" and state["pool"]["op"].dst is not None:      # (the structure is built: the lists need bu_row only)
+            if mode == "mfma_chain" and (state["pool"]["op"].dst is not None or state["pool"]["op"].valid is not None):   # (the lists need bu_row only)
                 ops.pool_cs_deps(state["pool"]["op"])
             self.pool_chain_check()                         # this host is synchronised here anyway: earlier scenes' abort words
             mark("pool plan+split")
@@ -561,8 +568,15 @@ class HotPath:
             after_student()
         # the operator's structure was built ahead: the affinity kernel writes its weights straight into fragment order
         op = p["pool"]["op"] if p["pool"] is not None else None
-        w = ops.affinity_softmax(E, nbr, self.sharpen, into=op if op is not None and op.dst is not None else None)
+        if op is not None and op.valid is not None:
+            # rows 11 + the operator fill on the matrix cores: similarities of every non-empty fragment, the valid ones through the
+            # row's softmax, fragments written whole (no [Nv, K] weight matrix exists on this path)
+            ops.affinity_cs_fragments(E, self.sharpen, op)
+            w = None
+        else:
+            w = ops.affinity_softmax(E, nbr, self.sharpen, into=op if op is not None and op.dst is not None else None)
         mark("affinity")
+        self._last_E = E
         self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12
         out = self._pool(X, nbr, w, Nv, D, plan=p["pool"])
         mark("pooling")
@@ -593,6 +607,8 @@ class HotPath:
         mode = self._pool_mode(D)
         R = self.pool_tile_rows
         tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
+        if w is None and (plan is None or not plan["op"].filled):
+            w = ops.affinity_softmax(self._last_E, nbr, self.sharpen)      # (isolated calls after a scene whose weights went straight into fragments)
         if self.num_iters == 0:
             out = torch.empty((Nv, D), dtype=torch.float32, device=dev)
             out.copy_(X[:, :D])

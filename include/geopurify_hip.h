@@ -279,6 +279,19 @@ int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, i
 int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
                          int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, int32_t *dst,
                          void *stream);
+/* The structure for gp_affinity_cs_fragments: union rows, fragment masks and valid u32 [total_rows / 32 * 128 + 64]: bit p of  */
+/* valid[step * 128 + row] = union row 32 step + p of the row's block is one of that row's neighbours (the last 64 words are     */
+/* padding).  No fragment is touched.  Needs the neighbour lists only; their ids must be distinct within a row (k-NN lists are).  */
+int gp_pool_cs_structure_valid(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
+                               int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, uint32_t *bu_valid, void *stream);
+/* Row 11 (models/affinity_module.py:1559-1572) fused with the operator fill, on the matrix cores: e_hi / e_lo = the unit          */
+/* embeddings x 2^10 as f16 planes [nv, 128] (gp_split_f16_scaled, scale 1024); every (row, union row) similarity of a non-empty   */
+/* fragment is computed as hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16, the valid ones go through the row's softmax           */
+/* (x sharpen), and every non-empty fragment of wa_hi / wa_lo is written whole (weights x 2^10, zeros elsewhere).  d = 128, k <= 96. */
+/* Produces no [nv, k] weight matrix (gp_affinity_softmax does).                                                                  */
+int gp_affinity_cs_fragments(const void *e_hi, const void *e_lo, int64_t nv, int32_t d, int32_t k, float sharpen,
+                             const int64_t *bu_off, const int32_t *bu_row, const uint32_t *bu_mask, const uint32_t *bu_valid,
+                             int32_t rows_per_block, void *wa_hi, void *wa_lo, void *stream);
 int gp_pool_cs_apply(const void *x_hi, const void *x_lo, int64_t ld_x, const int64_t *bu_off, const int32_t *bu_row,
                      const uint32_t *bu_mask, const void *wa_hi, const void *wa_lo, int64_t nv, int32_t d,
                      int32_t rows_per_block, void *y_hi, void *y_lo, int64_t ld_y, float *y_f32, int64_t ld_yf,
