@@ -25,6 +25,7 @@ extern "C" int gp_version(void) { return 100; }
 //      256 / 512 engine: no staged-row reads / no weight-fragment reads
 //   5  1-NN: 1 forces brute force          6  1-NN fine grid cells per axis (0 = 128, <= 256)
 //   7  1-NN: 2 brings back the fine-grid pass for near queries            9  64-row pooling: 1 forces one workgroup per CU
+//   8  matrix-core affinity (mask, tuning twin): 1 no fragment reads / MFMA, 2 no list stores, 4 no softmax, 8 no fragment pass, 16 no LDS-DMA
 //  10  persistent pooling: workgroups per XCD label (0 = CUs / 8, <= 64)   11  64-row pooling: 4 = column-sliced waves
 //  12  persistent pooling: 1 forces the static tile lists                  13  1-NN coarse grid cells per axis (0 = 32, <= 64)
 //  14  classify: 1 forces the kernel without the LDS-staged text matrix
@@ -41,7 +42,7 @@ const KnobRule k_rules[16] = {
     {0, 1, 0},           // 5
     {0, 256, 0},         // 6
     {0, 2, 0},           // 7
-    {0, -1, 0},          // 8: no such knob
+    {0, 0, 1u | 2u | 4u | 8u | 16u},                               // 8
     {0, 1, 0},           // 9
     {0, 64, 0},          // 10
     {0, 4, 0},           // 11 (0 or 4; the engine is gp_pool_cs_apply_engine, not a knob)

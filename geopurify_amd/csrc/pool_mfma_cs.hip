@@ -727,21 +727,27 @@ constexpr int AF_D = 128;                         // embedding width
 constexpr int AF_RB = AF_D * 2;                   // bytes per staged row and plane
 constexpr int AF_PLANE = CS_KS * AF_RB;           // 8 KiB
 constexpr int AF_STAGE = 2 * AF_PLANE;            // 16 KiB
-constexpr int AF_NST = 3;
+constexpr int AF_NST = 4;                         // ring depth (3, 4 and 6 stages measure the same: the ring is not what a step waits for)
+constexpr int AF_KEEP = 24;                       // steps whose validity words stay in LDS for the fragment pass (longer blocks re-load them)
 constexpr int AF_KMAX = 96;                       // neighbours per row (the list pitch is AF_KMAX + 1 floats)
 constexpr int AF_PITCH = AF_KMAX + 1;
 constexpr int AF_OFF_V = AF_NST * AF_STAGE;       // the steps' validity words: [stage][wave][64] u32
-constexpr int AF_OFF_P = AF_OFF_V + AF_NST * CS_NW * 256;
+constexpr int AF_OFF_K = AF_OFF_V + AF_NST * CS_NW * 256;                  // kept validity words: [AF_KEEP][128] u32
+constexpr int AF_OFF_P = AF_OFF_K + AF_KEEP * CS_BR * 4;
 constexpr size_t AF_SMEM = (size_t)AF_OFF_P + (size_t)CS_BR * AF_PITCH * sizeof(float);
 constexpr float AF_ESCALE = 1024.f;               // the embedding planes carry e x 2^10 (lo halves stay normal numbers)
 constexpr int AF_DMA = 3;                         // LDS-DMA instructions per wave and stage: rows hi, rows lo, validity words
 
+// (TUNE: the bits of knob 8 are honoured -- 1 no fragment reads / MFMA, 2 no list stores, 4 no softmax, 8 no fragment pass, 16 no
+// LDS-DMA; the product instantiation compiles them out)
+template <bool TUNE>
 __global__ void __launch_bounds__(512, 2)
 affinity_cs_kernel(const _Float16 *__restrict__ e_hi, const _Float16 *__restrict__ e_lo, int64_t nv, float sharpen,
                    const int64_t *__restrict__ bu_off, const int32_t *__restrict__ bu_row, const uint32_t *__restrict__ bu_mask,
                    const uint32_t *__restrict__ bu_valid, int64_t nblocks, int rpb, int64_t per_xcd,
-                   _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo) {
+                   _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo, int tune_) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tune = TUNE ? tune_ : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);                     // wave = 16-row group
     const int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // XCD-contiguous: neighbouring blocks share halo rows in L2
@@ -771,12 +777,18 @@ affinity_cs_kernel(const _Float16 *__restrict__ e_hi, const _Float16 *__restrict
     // the fragment reads of 16 consecutive rows at one logical piece then touch 16 different piece positions (a row is 256 bytes =
     // all 64 banks).  The loop issues nothing but these LDS-DMA instructions, so `s_waitcnt vmcnt(AF_DMA)` means "the older stage
     // has landed"; row ids and fragment masks come through the scalar cache.
+    // MFMA tile t takes the step's union rows 8 a + 4 t + c (a, c = 0 .. 3) as its rows 4 a + c: a lane's C registers of the two tiles
+    // are then 8 CONSECUTIVE union rows (8 q .. 8 q + 7) for its row m -- exactly one 16-byte piece of the weight fragment the pooling
+    // kernel reads (fragment lane q * 16 + m = this lane), so the fragments leave in 1-KiB stores.  Swizzle key of a staged row:
+    // 4 (row / 8) + row % 4 -- the 16 rows of either tile have 16 different keys.
     const int srow_l = lane >> 4;
-    const int spiece = (lane & 15) ^ ((4 * g + srow_l) & 15);
+    const int srow_k = (((4 * g + srow_l) >> 3) << 2) | ((4 * g + srow_l) & 3);
+    const int spiece = (lane & 15) ^ srow_k;
     const int32_t *idg = bu_row + ub0 + 4 * g;
     const uint32_t *vgl = bu_valid + ks0 * CS_BR + g * 16 + lane;
-    auto issue = [&](int k, int slot) {
-        const i32x4 id4 = *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS);      // (wave-uniform address: a scalar load)
+    auto load_ids = [&](int k) { return *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS); };   // (wave-uniform address: a scalar load)
+    auto issue = [&](i32x4 id4, int k, int slot) {
+        if (tune & 16) return;
         const int64_t id = srow_l == 0 ? id4.x : srow_l == 1 ? id4.y : srow_l == 2 ? id4.z : id4.w;
         unsigned char *dst = smem_raw + slot * AF_STAGE + (4 * g) * AF_RB;
         cs_glds16<0>(e_hi + id * AF_D + spiece * 8, dst);
@@ -785,67 +797,105 @@ affinity_cs_kernel(const _Float16 *__restrict__ e_hi, const _Float16 *__restrict
                                          (__attribute__((address_space(3))) void *)(smem_raw + AF_OFF_V + (slot * CS_NW + g) * 256), 4, 0, 0);
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
-    // fragment read of tile t, K step ks: row i = 16 t + m, logical piece 4 ks + q
+    // fragment read of tile t, K step ks: staged row 8 (m / 4) + 4 t + m % 4 (key m), logical piece 4 ks + q
     uint32_t rd[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int i = 16 * t + m;
-            rd[t][ks] = lds0 + (uint32_t)(i * AF_RB + (((4 * ks + q) ^ (i & 15)) << 4));
+            const int i = 8 * (m >> 2) + 4 * t + (m & 3);
+            rd[t][ks] = lds0 + (uint32_t)(i * AF_RB + (((4 * ks + q) ^ m) << 4));
         }
     const uint32_t rdv = lds0 + AF_OFF_V + (uint32_t)(g * 256 + m * 4);
     const uint32_t *mk = bu_mask + ks0;
-    if (n > 0) issue(0, 0);
-    if (n > 1) issue(1, 1);
+#pragma unroll
+    for (int j = 0; j < AF_NST - 1; ++j)
+        if (j < n) issue(load_ids(j), j, j);
+    // the scalars of a step (row ids of the stage it issues, its fragment mask) are loaded one step ahead and waited for at the END
+    // of the step before: a scalar load's round trip right behind the barrier was most of a step (round 5, first version: 50 us per block)
+    i32x4 idn = load_ids(AF_NST - 1 < n ? AF_NST - 1 : n - 1);
+    unsigned fm = mk[0];
     int base = 0;
+    unsigned live = 0;                                                         // bit s: step s < AF_KEEP has a fragment of this group
+    const uint32_t keep_a = lds0 + AF_OFF_K + (uint32_t)((g * 16 + m) * 4);
     for (int s = 0; s < n; ++s) {
         const int slot = s % AF_NST;
-        // the stage of step s has landed when at most the younger stage's AF_DMA instructions are outstanding (this wave's), and the
-        // barrier makes that true for every wave's rows; it also says every wave is done reading the slot that step s + 2 refills
-        if (s + 1 < n) cs_handover<AF_DMA>(); else cs_handover<0>();
-        if (s + 2 < n) issue(s + 2, (s + 2) % AF_NST);
-        const unsigned fm = mk[s];
-        if (!((fm >> g) & 1u)) continue;                                       // wave-uniform: this group has no neighbour in the step
-        uint32_t v;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(rdv + (uint32_t)(slot * CS_NW * 256)) : "memory");
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        const uint32_t so = (uint32_t)(slot * AF_STAGE);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f16x8 ah[4], al[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                cs_rd128<0>(ah[ks], rd[t][ks] + so);
-                cs_rd128<AF_PLANE>(al[ks], rd[t][ks] + so);
-            }
-            cs_wait_a(ah, al);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh[ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl[ks], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh[ks], acc[t], 0, 0, 0);
-            }
+        // the stage of step s has landed when at most the YOUNGER stages' instructions are outstanding (this wave's; AF_NST - 2 stages
+        // while the block lasts, fewer at its end), and the barrier makes that true for every wave's rows; it also says every wave
+        // is done reading the slot that step s + AF_NST - 1 refills
+        {
+            const int younger = (tune & 16) ? 0 : n - 1 - s < AF_NST - 2 ? n - 1 - s : AF_NST - 2;
+            static_assert(AF_NST == 4, "the hand-over below lists the waits of a four-stage ring");
+            if (younger == 2) cs_handover<2 * AF_DMA>();
+            else if (younger == 1) cs_handover<1 * AF_DMA>();
+            else cs_handover<0>();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));                        // (the validity word: read before the fragments)
-        // C layout: this lane holds union rows 16 t + 4 q + r of the step for its row m
+        if (s + AF_NST - 1 < n) issue(idn, s + AF_NST - 1, (s + AF_NST - 1) % AF_NST);
+        const int kn = s + AF_NST < n ? s + AF_NST : n - 1;
+        const i32x4 idn2 = load_ids(kn);
+        const unsigned fmn = mk[s + 1 < n ? s + 1 : n - 1];
+        if ((fm >> g) & 1u) {                                                  // wave-uniform: this group has a neighbour in the step
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(rdv + (uint32_t)(slot * CS_NW * 256)) : "memory");
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const uint32_t so = (uint32_t)(slot * AF_STAGE);
+            if (!(tune & 1)) {
+                f16x8 ah0[4], al0[4], ah1[4], al1[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kb = 16 * t + 4 * q + r;
-                if ((v >> kb) & 1u) {
-                    const int sl = base + __popc(v & ((1u << kb) - 1u));
-                    // (inline asm: a compiler-visible LDS access inside the loop would wait for every LDS-DMA in flight)
-                    if (sl < AF_KMAX) asm volatile("ds_write_b32 %0, %1" ::"v"(plist_a + (uint32_t)(sl * 4)), "v"(acc[t][r]) : "memory");
+                for (int ks = 0; ks < 4; ++ks) {
+                    cs_rd128<0>(ah0[ks], rd[0][ks] + so);
+                    cs_rd128<AF_PLANE>(al0[ks], rd[0][ks] + so);
+                    cs_rd128<0>(ah1[ks], rd[1][ks] + so);
+                    cs_rd128<AF_PLANE>(al1[ks], rd[1][ks] + so);
                 }
+                cs_wait_a(ah0, al0);
+                cs_wait_a(ah1, al1);
+                // four independent chains (two tiles x {hi hi, cross terms}): no MFMA waits for the one before it, and the cross terms
+                // (2^-11 of the main term) are summed among themselves -- added one by one to the 2^20-sized main sum, each of the
+                // twelve additions rounded at THAT size (cosine error 2e-7, weights 1.2e-6 from the fp64 softmax); now four do
+                f32x4 cr[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[ks], bh[ks], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[ks], bh[ks], acc[1], 0, 0, 0);
+                    cr[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0[ks], bl[ks], cr[0], 0, 0, 0);
+                    cr[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1[ks], bl[ks], cr[1], 0, 0, 0);
+                    cr[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0[ks], bh[ks], cr[0], 0, 0, 0);
+                    cr[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1[ks], bh[ks], cr[1], 0, 0, 0);
+                }
+                acc[0] += cr[0];
+                acc[1] += cr[1];
             }
-        base += __popc(v);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));                    // (the validity word: read before the fragments)
+            if (tune & 16) v = 0xFFFFFFFFu;
+            if (s < AF_KEEP) {                                                 // kept for the fragment pass (q == 0 lanes: one word per row)
+                if (q == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(keep_a + (uint32_t)(s * CS_BR * 4)), "v"(v) : "memory");
+                live |= 1u << s;
+            }
+            // C layout: this lane holds union rows 8 q + 4 t + r of the step for its row m
+            if (!(tune & 2)) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kb = 8 * q + 4 * t + r;
+                        if ((v >> kb) & 1u) {
+                            const int sl = base + __popc(v & ((1u << kb) - 1u));
+                            // (inline asm: a compiler-visible LDS access inside the loop would wait for every LDS-DMA in flight)
+                            if (sl < AF_KMAX) asm volatile("ds_write_b32 %0, %1" ::"v"(plist_a + (uint32_t)(sl * 4)), "v"(acc[t][r]) : "memory");
+                        }
+                    }
+            }
+            base += __popc(v);
+        }
+        asm volatile("" ::"s"(idn2.x), "s"(idn2.y), "s"(idn2.z), "s"(idn2.w), "s"(fmn));    // (the scalar loads are waited for HERE)
+        idn = idn2;
+        fm = fmn;
     }
     // ---- softmax of every row over its list (4 lanes q of a row share it: entries q, q + 4, ...)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the list stores above
     gp_wave_sync();
-    const int cnt = base < AF_KMAX ? base : AF_KMAX;
+    const int cnt = (tune & 4) ? 0 : base < AF_KMAX ? base : AF_KMAX;
     const float lscale = sharpen / (AF_ESCALE * AF_ESCALE);
     float mx = -INFINITY;
     for (int j = q; j < cnt; j += 4) mx = fmaxf(mx, plist[j] * lscale);
@@ -861,34 +911,46 @@ affinity_cs_kernel(const _Float16 *__restrict__ e_hi, const _Float16 *__restrict
     sum += __shfl_xor(sum, 32, 64);
     const float rs = cnt > 0 ? GP_POOL_CS_WSCALE / sum : 0.f;
     gp_wave_sync();
-    // ---- the fragments: lane (m, q) holds union rows 16 t + 4 q + r -> fragment lane (2 t + q / 2) * 16 + m, elements 4 (q & 1) + r
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    // ---- the fragments
     base = 0;
-    const uint32_t *vg = bu_valid + ks0 * CS_BR + g * 16 + m;
-    for (int s = 0; s < n; ++s) {
-        const unsigned fm = mk[s];
-        if (!((fm >> g) & 1u)) continue;
-        const uint32_t v = vg[(int64_t)s * CS_BR];                               // (no LDS-DMA in flight any more: plain loads)
+    if (tune & 8) return;
+    const uint32_t *keep = reinterpret_cast<const uint32_t *>(smem_raw + AF_OFF_K) + g * 16 + m;
+    auto emit = [&](int s, uint32_t v) {
         _Float16 *fh = wa_hi + ((ks0 + s) * CS_NG + g) * 512, *fl = wa_lo + ((ks0 + s) * CS_NG + g) * 512;
+        f16x8 h, l;                                              // union rows 8 q .. 8 q + 7 of row m = fragment lane q * 16 + m = this lane
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f16x4 h, l;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kb = 16 * t + 4 * q + r;
-                float wv_ = 0.f;
-                if ((v >> kb) & 1u) {
-                    const int sl = base + __popc(v & ((1u << kb) - 1u));
-                    if (sl < AF_KMAX) wv_ = plist[sl] * rs;
-                }
-                h[r] = (_Float16)wv_;
-                l[r] = (_Float16)(wv_ - (float)h[r]);
+        for (int e = 0; e < 8; ++e) {
+            const int kb = 8 * q + e;
+            float wv_ = 0.f;
+            if ((v >> kb) & 1u) {
+                const int sl = base + __popc(v & ((1u << kb) - 1u));
+                if (sl < AF_KMAX) wv_ = plist[sl] * rs;
             }
-            const int fo = ((2 * t + (q >> 1)) * 16 + m) * 8 + 4 * (q & 1);
-            *reinterpret_cast<f16x4 *>(fh + fo) = h;
-            *reinterpret_cast<f16x4 *>(fl + fo) = l;
+            h[e] = (_Float16)wv_;
+            l[e] = (_Float16)(wv_ - (float)h[e]);
         }
+        *reinterpret_cast<f16x8 *>(fh + lane * 8) = h;
+        *reinterpret_cast<f16x8 *>(fl + lane * 8) = l;
         base += __popc(v);
+    };
+    // steps below AF_KEEP: the fragment's step from the bit set, its validity word from LDS -- no memory round trip in this loop
+    while (live) {
+        const int s = __builtin_ctz(live);
+        live &= live - 1;
+        emit(s, keep[s * CS_BR]);
+    }
+    // longer blocks: the rest with the words re-loaded, eight steps at a time
+    const uint32_t *vg = bu_valid + ks0 * CS_BR + g * 16 + m;
+    for (int s0 = AF_KEEP; s0 < n; s0 += 8) {
+        uint32_t v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = (s0 + j < n && ((mk[s0 + j] >> g) & 1u)) ? vg[(int64_t)(s0 + j) * CS_BR] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = s0 + j;
+            if (s >= n || !((mk[s] >> g) & 1u)) continue;
+            emit(s, v8[j]);
+        }
     }
 }
 
@@ -1478,10 +1540,18 @@ extern "C" int gp_affinity_cs_fragments(const void *e_hi, const void *e_lo, int6
     hipStream_t s = gp_stream(stream_);
     const int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     const int64_t per_xcd = (nb + 7) / 8;
-    GP_SMEM_ATTR(affinity_cs_kernel, AF_SMEM);
-    affinity_cs_kernel<<<(unsigned)(per_xcd * 8), 512, AF_SMEM, s>>>(static_cast<const _Float16 *>(e_hi), static_cast<const _Float16 *>(e_lo), nv,
-                                                                     sharpen, bu_off, bu_row, bu_mask, bu_valid, nb, rows_per_block, per_xcd,
-                                                                     static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo));
+    const int tune = g_gp_knobs[8];                       // tuning bits: only ever handed to the tuning twin
+    if (tune != 0) {
+        GP_SMEM_ATTR(affinity_cs_kernel<true>, AF_SMEM);
+        affinity_cs_kernel<true><<<(unsigned)(per_xcd * 8), 512, AF_SMEM, s>>>(static_cast<const _Float16 *>(e_hi), static_cast<const _Float16 *>(e_lo),
+                                                                               nv, sharpen, bu_off, bu_row, bu_mask, bu_valid, nb, rows_per_block,
+                                                                               per_xcd, static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), tune);
+    } else {
+        GP_SMEM_ATTR(affinity_cs_kernel<false>, AF_SMEM);
+        affinity_cs_kernel<false><<<(unsigned)(per_xcd * 8), 512, AF_SMEM, s>>>(static_cast<const _Float16 *>(e_hi), static_cast<const _Float16 *>(e_lo),
+                                                                                nv, sharpen, bu_off, bu_row, bu_mask, bu_valid, nb, rows_per_block,
+                                                                                per_xcd, static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), 0);
+    }
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

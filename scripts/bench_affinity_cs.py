@@ -75,3 +75,14 @@ for rnd in range(2):
     t_new = timeit(lambda: ops.affinity_cs_fragments(E, 20.0, op_b))
     print(f"structure (count + fill, incl. one host sync): dst table {t_old_s:.3f} ms, validity words {t_new_s:.3f} ms;   "
           f"affinity: block kernel + scatter {t_old:.3f} ms, matrix cores -> fragments (incl. the split of E) {t_new:.3f} ms", flush=True)
+
+from geopurify_amd import _lib
+lib = _lib.load()
+for bits, what in ((0, "everything"), (1, "no fragment reads / MFMA"), (2, "no list stores"), (4, "no softmax"), (8, "no fragment pass"), (16, "no LDS-DMA"),
+                   (1 | 2 | 4 | 8, "ring only"), (1 | 2 | 4 | 8 | 16, "skeleton")):
+    lib.gp_debug_set(8, bits)
+    t = timeit(lambda: ops.affinity_cs_fragments(E, 20.0, op_b))
+    print(f"tuning twin, {what:28s} {t:.3f} ms (incl. the split of E)", flush=True)
+lib.gp_debug_set(8, 0)
+t = timeit(lambda: ops.split_f16(E, 128, scale=torch.tensor([1024.0], device="cuda")))
+print(f"the split of E alone (incl. a host->device scalar copy): {t:.3f} ms")

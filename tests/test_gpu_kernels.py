@@ -940,6 +940,48 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     assert keys == sorted(keys)
 
 
+@pytest.mark.parametrize("n_vox,rpb,K", [(2531, 128, 96), (2500, 100, 96), (1900, 128, 20), (300, 128, 96), (4000, 117, 64)])
+def test_affinity_cs_fragments_vs_fp64_and_the_block_kernel(ops, n_vox, rpb, K):
+    """gp_pool_cs_structure_valid + gp_affinity_cs_fragments (rows 11 + operator fill on the matrix cores) on small operators: ragged
+    block heights, K below 96, a single block; weights read back from the fragments against an fp64 softmax (2e-6) and against
+    affinity_block_kernel's (4e-6: both carry fp32 rounding); the validity words against the neighbour lists; an application of the
+    operator equal to the ELL kernel's with those weights (1e-5)."""
+    rng = np.random.default_rng(21)
+    c = surface_voxels(rng, n_vox)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv = len(c)
+    K = min(K, Nv)
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    E = F.normalize(torch.randn(8, 128)[torch.from_numpy((c[:, 0] // 6) % 8)] + 0.6 * torch.randn(Nv, 128), dim=1).cuda().contiguous()
+    op = ops.pool_cs_plan(nbr, rows_per_block=rpb, structure="valid")
+    ops.affinity_cs_fragments(E, 20.0, op)
+    ref_op = ops.pool_cs_plan(nbr, rows_per_block=rpb, structure=True)
+    w_blk = ops.affinity_softmax(E, nbr, 20.0, into=ref_op)
+    assert torch.equal(ref_op.bu_row, op.bu_row) and torch.equal(ref_op.bu_mask, op.bu_mask)
+    # validity words == the dst table's (step, row, bit) set
+    steps = op.total // 32
+    el = ref_op.dst.long()                                                  # element = ((step * 8 + group) * 64 + lane) * 8 + e
+    st, grp, ln, e8 = el // 4096, (el // 512) % 8, (el // 8) % 64, el % 8
+    krow = (ln // 16) * 8 + e8
+    rl = grp * 16 + ln % 16
+    want = torch.zeros(steps * 128, dtype=torch.int64, device="cuda")
+    want.index_put_(((st * 128 + rl).flatten(),), torch.bitwise_left_shift(torch.ones_like(krow), krow).flatten(), accumulate=True)
+    got = op.valid[:steps * 128].long() & 0xFFFFFFFF
+    assert torch.equal(got, want)
+    frag = (op.wa_hi.float() + op.wa_lo.float()) / 1024.0
+    w = frag[el]
+    Ed = E.double()
+    wref = torch.softmax(20.0 * (Ed[:, None, :] * Ed[nbr.long()]).sum(-1), dim=1)
+    assert (w.double() - wref).abs().max().item() < 2e-6
+    assert (w - w_blk).abs().max().item() < 4e-6
+    X = torch.randn(Nv, 544, device="cuda")
+    y_ell = torch.empty(Nv, 512, device="cuda")
+    ops.pool_ell(X, nbr, w.contiguous(), 512, y_ell)
+    y_cs = torch.empty(Nv, 512, device="cuda")
+    ops.pool_cs_apply(ops.split_f16(X, 512), op, 512, out_f32=y_cs)
+    assert (y_cs - y_ell).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("kind,rpb,T", [("lattice", 128, 4), ("lattice", 100, 3), ("random", 128, 4), ("random", 117, 2)])
 def test_pool_cs_chained_launch_small_and_overflowing_lists(ops, kind, rpb, T):
     """gp_pool_cs_apply_chain on small operators: bit-identical to T launches of gp_pool_cs_apply for ragged block heights, and for
