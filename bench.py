@@ -231,8 +231,26 @@ def training_step_rate(batch, dev, sd, steps=6):
         o = one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # roofline of the step's matrix work: every fp32-class product is three f16 MFMAs, so the ISSUED rate is 3 x
+    # the algorithmic one; priced over the WHOLE step (sampler, BatchNorm sweeps, top-k, AdamW included), i.e. a lower bound of what
+    # the matrix kernels themselves reach -- their own durations are in profiles/r05_train_kernel_stats.csv
+    P = int((o["nbr_map"] >= 0).sum().item())
+    nvs, cin0, hid, emb, A, Dt = int(o["num_voxels"]), tr.cin_pad, 512, 128, 4096, 1088
+    n_mid = sum(1 for k in sd if k.endswith(".conv1.kernel") or k.endswith(".conv2.kernel"))
+    fwd = 2.0 * P * cin0 * hid + n_mid * 2.0 * P * hid * hid + 2.0 * nvs * hid * emb
+    dgrad = n_mid * 2.0 * P * hid * hid + 2.0 * nvs * hid * emb              # (the input layer's data gradient is not needed)
+    wgrad = fwd                                                              # dW[k] = X[in_k]^T dY[out_k]: the same products, reduced over the pairs
+    sim = 2.0 * A * N * Dt                                                   # anchors x points teacher similarity (the sampler's GEMM)
+    flop = fwd + dgrad + wgrad + sim
+    issued = 3.0 * flop / dt / 1e12
+    roof = {"bound": "mfma", "achieved": round(issued, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / MFMA_F16_PEAK_TFLOPS, 4),
+            "algorithmic_tflops": round(flop / dt / 1e12, 1),
+            "gflop_per_step": {"forward (gp_sparse_conv_f16x3 + head)": round(fwd / 1e9, 1), "data gradients (the same operator, transposed weights)": round(dgrad / 1e9, 1),
+                               "weight gradients (wgrad_kernel)": round(wgrad / 1e9, 1), "teacher similarity (anchors x points)": round(sim / 1e9, 1)},
+            "pairs": P, "note": "issued = 3 x algorithmic f16 flops (hi hi + hi lo + lo hi) / the whole step's time"}
     return {"value": round(1.0 / dt, 3), "unit": "optimizer steps/s (1 scene per step)", "ms_per_step": round(dt * 1e3, 2),
-            "sampled_voxels": int(o["num_voxels"]), "loss": round(float(o["loss"]), 4), "data": "synthetic teacher + lifted features"}
+            "sampled_voxels": int(o["num_voxels"]), "loss": round(float(o["loss"]), 4), "data": "synthetic teacher + lifted features",
+            "roofline_train": roof}
 
 
 def api_tuple_rate(batches, vlms, sd, cfg, pool_iters, dev, steps=4):

@@ -315,7 +315,7 @@ class StudentTrainer:
         if optimize:
             self.optimizer_step(grads)
         return {"loss": loss, "grads": grads, "num_voxels": Nvs, "num_samples": int(all_idx.shape[0]), "positive": positive,
-                "negative": negative, "neighbors": nbrs, "perm": perm, "uniq_vox": uniq_vox, "embeddings": E}
+                "negative": negative, "neighbors": nbrs, "perm": perm, "uniq_vox": uniq_vox, "embeddings": E, "nbr_map": nbr_map}
 
 
 class _LossWithGradients(torch.autograd.Function):
