@@ -42,5 +42,8 @@ utils = SimpleNamespace(batched_coordinates=_batched_coordinates)
 class MinkowskiSyncBatchNorm:
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):
-        """Identity: the student's BatchNorm layers here are plain per-rank modules (see compat/README.md, deviation)."""
+        """Returns the module unchanged: nothing needs converting.  BatchNorm in training mode is computed by the HIP training step
+        (geopurify_amd/training.py), which synchronises the batch statistics over the ranks by itself whenever torch.distributed is
+        initialised with more than one rank (StudentTrainer(sync_bn=True): fp64 column sums all-reduced, sharding.sync_batch_stats) --
+        what the reference obtains from this call (run/train.py:212-213)."""
         return module
