@@ -65,10 +65,10 @@ SIGNATURES = {
     "gp_pool_mfma_apply_persistent": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64,
                                                 _P, c_int64, c_int64, _P, _P, _P]),
     "gp_pool_cs_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "gp_pool_cs_count": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
-    "gp_pool_cs_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
-    "gp_pool_cs_structure": (c_int32, [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P]),
-    "gp_pool_cs_structure_valid": (c_int32, [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P]),
+    "gp_pool_cs_count": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+    "gp_pool_cs_fill": (c_int32, [_P, _P, c_int64, c_int32, c_int32, _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
+    "gp_pool_cs_structure": (c_int32, [_P, c_int64, c_int32, c_int32, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gp_pool_cs_structure_valid": (c_int32, [_P, c_int64, c_int32, c_int32, _P, c_int64, c_int32, _P, _P, _P, _P]),
     "gp_affinity_cs_fragments": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "gp_pool_cs_apply": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),
     "gp_pool_cs_apply_engine": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, _P]),

@@ -136,9 +136,11 @@ __device__ __forceinline__ void cs_bitonic(int *a, int n_pow2, int tid, int nthr
         }
 }
 
-// distinct neighbour ids of the rows of block b -> dense[0 .. U) (unsorted), through an LDS hash table: a small table
-// first (unions of lattice neighbourhoods are a few hundred ids), the full-size one if it overflows
-__device__ int cs_union(const int32_t *__restrict__ nbr, int n, int *keys, int *dense) {
+// distinct neighbour ids of the rows of block b -> dense[0 .. U) (unsorted), through an LDS hash table of `cap` slots (a power of two
+// >= 2048; `dense` holds cap entries too): a 2048-slot table first (unions of lattice neighbourhoods are a few hundred ids), all
+// `cap` slots if that overflows.  Returns -1 if the union does not fit cap / 2 ids (the caller sized cap from the largest union, or
+// runs the block again with the full-size table).
+__device__ int cs_union(const int32_t *__restrict__ nbr, int n, int *keys, int *dense, int cap) {
     __shared__ int s_wcnt[16];
     __shared__ int s_base, s_new, s_over;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -156,15 +158,16 @@ __device__ int cs_union(const int32_t *__restrict__ nbr, int n, int *keys, int *
                 if (old == -1) { atomicAdd(&s_new, 1); break; }
                 if (old == id) break;
                 h = (h + 1) & (hs - 1);
-                if (++probes > 256 && hs < CS_HS) { s_over = 1; break; }   // (the full table always has a free slot)
+                if (++probes > (hs < cap ? 256 : hs)) { s_over = 1; break; }   // (a table with a free slot ends the probe sequence)
             }
         }
         __syncthreads();
-        const bool redo = hs < CS_HS && (s_over || s_new > 1024);          // block-uniform
+        const bool over = s_over || (hs < cap && s_new > hs / 2);          // block-uniform (the last table may fill up to its last slot)
         __syncthreads();
-        if (!redo) break;
-        hs = CS_HS;
-        shift = 18;
+        if (!over) break;
+        if (hs >= cap) return -1;
+        hs = cap;
+        shift = 32 - (31 - __clz(cap));
     }
     for (int i0 = 0; i0 < hs; i0 += 1024) {                                // compact the occupied slots
         const int key = keys[i0 + tid];
@@ -181,15 +184,23 @@ __device__ int cs_union(const int32_t *__restrict__ nbr, int n, int *keys, int *
     return s_base;
 }
 
-// pass 1: padded union size of every block (a multiple of 32 union rows, at least one step)
+// pass 1: padded union size of every block (a multiple of 32 union rows, at least one step).  Launched twice: with a 2048-slot table
+// (16 KiB of LDS: several workgroups per CU, and room beside a convolution tile) for every block -- a union above 1024 ids marks the
+// block (bu_n = -1) -- then with the full-size table (128 KiB) for the marked blocks only.  stats[0] = the largest union (atomicMax).
 __global__ void __launch_bounds__(1024)
-cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int rpb, int64_t *__restrict__ padded_cnt, int32_t *__restrict__ bu_n) {
+cs_count_kernel(const int32_t *__restrict__ nbr, int64_t nv, int k, int rpb, int64_t *__restrict__ padded_cnt, int32_t *__restrict__ bu_n,
+                int cap, int second, unsigned long long *__restrict__ stats) {
     extern __shared__ int s_mem[];
-    int *keys = s_mem, *dense = s_mem + CS_HS;
+    int *keys = s_mem, *dense = s_mem + cap;
     const int64_t b = blockIdx.x, r0 = b * rpb;
+    if (second && bu_n[b] >= 0) return;
     const int rows = (int)((nv - r0) < rpb ? (nv - r0) : rpb);
-    const int U = cs_union(nbr + r0 * k, rows * k, keys, dense);
-    if (threadIdx.x == 0) { padded_cnt[b] = (int64_t)((U + CS_KS - 1) / CS_KS) * CS_KS; bu_n[b] = U; }
+    const int U = cs_union(nbr + r0 * k, rows * k, keys, dense, cap);
+    if (threadIdx.x == 0) {
+        padded_cnt[b] = U < 0 ? 0 : (int64_t)((U + CS_KS - 1) / CS_KS) * CS_KS;
+        bu_n[b] = U;
+        if (U > 0 && stats) atomicMax(stats, (unsigned long long)U);
+    }
 }
 
 // pass 2: the block's union rows in (first group, last group, group set, id) order, one bit per (step, group) that says
@@ -206,17 +217,17 @@ template <int MODE>
 __global__ void __launch_bounds__(1024)
 cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int64_t nv, int k, int rpb, const int64_t *__restrict__ bu_off,
                int32_t *__restrict__ bu_row, uint32_t *__restrict__ bu_mask, _Float16 *__restrict__ wa_hi, _Float16 *__restrict__ wa_lo,
-               int32_t *__restrict__ dst, uint32_t *__restrict__ valid) {
+               int32_t *__restrict__ dst, uint32_t *__restrict__ valid, int cap) {
     constexpr bool WEIGHTS = MODE == CS_FILL_WEIGHTS;
-    extern __shared__ int s_mem[];                           // A[16384] | B[16384] | npos u16 [br*k]
-    int *A = s_mem, *B = s_mem + CS_HS;
-    unsigned short *npos = reinterpret_cast<unsigned short *>(s_mem + CS_HS + CS_MAXID);
+    extern __shared__ int s_mem[];                           // A[cap] | B[cap] | npos u16 [br*k]   (cap: a power of two >= 2 x the largest union)
+    int *A = s_mem, *B = s_mem + cap;
+    unsigned short *npos = reinterpret_cast<unsigned short *>(s_mem + 2 * cap);
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x, r0 = b * rpb;
     const int rows = (int)((nv - r0) < rpb ? (nv - r0) : rpb);
     const int n = rows * k;
     const int32_t *nb = nbr + r0 * k;
-    const int U = cs_union(nb, n, A, B);
+    const int U = cs_union(nb, n, A, B, cap);                  // (>= 0: the host sized cap from the largest union of pass 1)
     int np2 = 1;
     while (np2 < U) np2 <<= 1;
     for (int i = U + tid; i < np2; i += 1024) B[i] = INT32_MAX;
@@ -265,7 +276,7 @@ cs_fill_kernel(const int32_t *__restrict__ nbr, const float *__restrict__ w, int
         // else in global memory (zeroed by this workgroup first: the barrier orders its zero stores before its atomics, both
         // through the same L2)
         const int nsteps = Up / CS_KS;
-        const bool in_lds = nsteps * CS_BR <= CS_HS;
+        const bool in_lds = nsteps * CS_BR <= cap;
         unsigned *sv = reinterpret_cast<unsigned *>(A);
         uint32_t *gv = valid + ks0 * CS_BR;
         __syncthreads();                                      // (every read of A above is done)
@@ -1341,7 +1352,7 @@ extern "C" size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block)
 // pass 1: bu_off i64 [nblocks+1] (padded union rows before each block; multiples of 32), bu_n i32 [nblocks];
 // nblocks = ceil(nv / rows_per_block)
 extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, int64_t *bu_off, int32_t *bu_n,
-                                void *workspace, size_t workspace_bytes, void *stream_) {
+                                int64_t *max_union, void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(nbr && bu_off && bu_n && workspace && nv > 0 && k > 0, "gp_pool_cs_count: null/empty argument");
     GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_count: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
     GP_CHECK_ARG((int64_t)CS_BR * k <= CS_MAXNK, "gp_pool_cs_count: k=%d too large (128*k <= %d)", k, CS_MAXNK);
@@ -1353,18 +1364,33 @@ extern "C" int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32
     if (!cv.ok()) { gp_set_error("gp_pool_cs_count: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(cnt + nb, 0, sizeof(int64_t), s));
-    size_t sm = (size_t)(CS_HS + cs_np2((int64_t)CS_BR * k)) * sizeof(int);
-    GP_SMEM_ATTR(cs_count_kernel, (CS_HS + CS_MAXID) * sizeof(int));
-    cs_count_kernel<<<(unsigned)nb, 1024, sm, s>>>(nbr, nv, k, rows_per_block, cnt, bu_n);
+    if (max_union) GP_CHECK_HIP(hipMemsetAsync(max_union, 0, sizeof(int64_t), s));
+    // every block with the 2048-slot table (16 KiB), then the blocks it marked (a union above 1024 ids) with the full-size one
+    const int cap_big = CS_HS > cs_np2((int64_t)CS_BR * k) ? CS_HS : cs_np2((int64_t)CS_BR * k);
+    GP_SMEM_ATTR(cs_count_kernel, (size_t)2 * CS_HS * sizeof(int));
+    cs_count_kernel<<<(unsigned)nb, 1024, (size_t)2 * 2048 * sizeof(int), s>>>(nbr, nv, k, rows_per_block, cnt, bu_n, 2048, 0,
+                                                                              reinterpret_cast<unsigned long long *>(max_union));
+    cs_count_kernel<<<(unsigned)nb, 1024, (size_t)2 * cap_big * sizeof(int), s>>>(nbr, nv, k, rows_per_block, cnt, bu_n, cap_big, 1,
+                                                                                 reinterpret_cast<unsigned long long *>(max_union));
     GP_CHECK_HIP(rocprim::exclusive_scan(tmp, tb, cnt, bu_off, (int64_t)0, (size_t)(nb + 1), rocprim::plus<int64_t>(), s));
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
 
+// LDS of the fill kernels: two tables of `cap` ints (cap = a power of two >= 2 x the largest union, 2048 .. 16384; max_union = 0:
+// not known, the full size) + the position table
+static int cs_fill_cap(int32_t max_union) {
+    if (max_union <= 0) return CS_HS;
+    int cap = cs_np2(2 * (int64_t)max_union);
+    return cap < 2048 ? 2048 : cap > CS_HS ? CS_HS : cap;
+}
+static size_t cs_fill_smem(int cap, int32_t k) { return (size_t)2 * cap * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short); }
+
 // pass 2: bu_row i32 [total], bu_mask u32 [total/32], wa_hi / wa_lo f16 [total/32 * 8 * 512] (only the fragments whose
 // mask bit is set are defined -- and read)
 extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
-                               int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream_) {
+                               int64_t total_rows, int32_t max_union, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo,
+                               void *stream_) {
     GP_CHECK_ARG(nbr && w && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
                  "gp_pool_cs_fill: bad argument");
     GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_fill: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
@@ -1372,10 +1398,11 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
     int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
-    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
+    const int cap = cs_fill_cap(max_union);
     GP_SMEM_ATTR(cs_fill_kernel<CS_FILL_WEIGHTS>, sm_max);
-    cs_fill_kernel<CS_FILL_WEIGHTS><<<(unsigned)nb, 1024, sm, s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
-                                                                   static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), nullptr, nullptr);
+    cs_fill_kernel<CS_FILL_WEIGHTS><<<(unsigned)nb, 1024, cs_fill_smem(cap, k), s>>>(nbr, w, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
+                                                                                    static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo),
+                                                                                    nullptr, nullptr, cap);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -1384,8 +1411,8 @@ extern "C" int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, i
 // wa_hi / wa_lo that (row, neighbour j) owns.  gp_affinity_softmax_scatter then writes the weights in place; a scheduler runs this
 // before the student's embeddings exist (it needs the kNN lists only).
 extern "C" int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
-                                    int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, int32_t *dst,
-                                    void *stream_) {
+                                    int64_t total_rows, int32_t max_union, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo,
+                                    int32_t *dst, void *stream_) {
     GP_CHECK_ARG(nbr && dst && bu_off && bu_row && bu_mask && wa_hi && wa_lo && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
                  "gp_pool_cs_structure: bad argument");
     GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_structure: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
@@ -1395,10 +1422,11 @@ extern "C" int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, i
     int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
-    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
+    const int cap = cs_fill_cap(max_union);
     GP_SMEM_ATTR(cs_fill_kernel<CS_FILL_DST>, sm_max);
-    cs_fill_kernel<CS_FILL_DST><<<(unsigned)nb, 1024, sm, s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
-                                                               static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), dst, nullptr);
+    cs_fill_kernel<CS_FILL_DST><<<(unsigned)nb, 1024, cs_fill_smem(cap, k), s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask,
+                                                                                static_cast<_Float16 *>(wa_hi), static_cast<_Float16 *>(wa_lo), dst,
+                                                                                nullptr, cap);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -1507,7 +1535,8 @@ extern "C" int gp_pool_cs_apply_engine(const void *x_hi, const void *x_lo, int64
 // affinity kernel's 64-word fetches may touch).  No fragment is written: the affinity kernel writes every non-empty fragment whole.
 // The neighbour ids of a row must be distinct (a k-NN list is).
 extern "C" int gp_pool_cs_structure_valid(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
-                                          int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, uint32_t *bu_valid, void *stream_) {
+                                          int64_t total_rows, int32_t max_union, int32_t *bu_row, uint32_t *bu_mask, uint32_t *bu_valid,
+                                          void *stream_) {
     GP_CHECK_ARG(nbr && bu_off && bu_row && bu_mask && bu_valid && nv > 0 && total_rows > 0 && total_rows % CS_KS == 0,
                  "gp_pool_cs_structure_valid: bad argument");
     GP_CHECK_ARG(cs_rpb_ok(rows_per_block), "gp_pool_cs_structure_valid: rows_per_block=%d (16..%d)", rows_per_block, CS_BR);
@@ -1515,11 +1544,11 @@ extern "C" int gp_pool_cs_structure_valid(const int32_t *nbr, int64_t nv, int32_
     int64_t nb = (nv + rows_per_block - 1) / rows_per_block;
     hipStream_t s = gp_stream(stream_);
     const size_t sm_max = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_MAXNK * sizeof(unsigned short);
-    size_t sm = (size_t)(CS_HS + CS_MAXID) * sizeof(int) + (size_t)CS_BR * k * sizeof(unsigned short);
+    const int cap = cs_fill_cap(max_union);
     GP_SMEM_ATTR(cs_fill_kernel<CS_FILL_VALID>, sm_max);
     GP_CHECK_HIP(hipMemsetAsync(bu_valid + total_rows / CS_KS * CS_BR, 0, 64 * sizeof(uint32_t), s));
-    cs_fill_kernel<CS_FILL_VALID><<<(unsigned)nb, 1024, sm, s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask, nullptr, nullptr,
-                                                                 nullptr, bu_valid);
+    cs_fill_kernel<CS_FILL_VALID><<<(unsigned)nb, 1024, cs_fill_smem(cap, k), s>>>(nbr, nullptr, nv, k, rows_per_block, bu_off, bu_row, bu_mask, nullptr,
+                                                                                  nullptr, nullptr, bu_valid, cap);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -529,6 +529,7 @@ class PoolCs:
         self.wa_hi, self.wa_lo, self.nv, self.total = wa_hi, wa_lo, nv, total
         self.block_rows = block_rows
         self.dst = None            # i32 [nv, k]: fragment element of (row, neighbour) once the structure is built ahead
+        self.max_union = 0         # largest block union (pass 1): sizes the LDS tables of the fill passes (0 = not known)
         self.valid = None          # u32 validity words once the structure is built for affinity_cs_fragments; k: its list length
         self.k = 0
         self.dep = self.flags = None   # the chained launch's dependency lists and flags (pool_cs_deps)
@@ -547,29 +548,31 @@ def pool_cs_plan(nbr, rows_per_block=128, structure=False):
     rpb = int(rows_per_block)
     nb = (nv + rpb - 1) // rpb
     ws = _ws(lib.gp_pool_cs_workspace_bytes(nv, rpb), dev)
-    bu_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+    bu_off = torch.empty(nb + 2, dtype=torch.int64, device=dev)[:nb + 1]                       # (+ one slot behind it: the largest union)
     bu_n = torch.empty(nb, dtype=torch.int32, device=dev)
-    check(lib.gp_pool_cs_count(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), _ptr(bu_n), _ptr(ws), ws.numel(), _stream()),
+    tail = bu_off.as_strided((2,), (1,), bu_off.storage_offset() + nb)                        # [total, largest union]: ONE read-back
+    check(lib.gp_pool_cs_count(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), _ptr(bu_n), tail[1:].data_ptr(), _ptr(ws), ws.numel(), _stream()),
           "gp_pool_cs_count")
-    total = int(bu_off[nb].item())                                                            # the one host sync
+    total, max_union = (int(v) for v in tail.tolist())                                        # the one host sync
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)
     wa_lo = torch.empty_like(wa_hi)
     op = PoolCs(bu_off, bu_n, bu_row, bu_mask, wa_hi, wa_lo, nv, total, block_rows=rpb)
+    op.max_union = max_union                                   # sizes the LDS tables of the fill passes
     if structure == "valid":
         # the structure for affinity_cs_fragments: validity bits instead of the dst table, no fragment zeroed (that kernel writes
         # every non-empty fragment whole)
         op.valid = torch.empty(total // 32 * 128 + 64, dtype=torch.int32, device=dev)
-        check(lib.gp_pool_cs_structure_valid(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(op.valid),
-                                             _stream()), "gp_pool_cs_structure_valid")
+        check(lib.gp_pool_cs_structure_valid(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), total, max_union, _ptr(bu_row), _ptr(bu_mask),
+                                             _ptr(op.valid), _stream()), "gp_pool_cs_structure_valid")
         op.k = int(k)
         return op
     if structure and total * 128 < 2 ** 31:
         # everything of the fill pass that needs the lists only, + where each (row, neighbour) weight goes: affinity_softmax(into=op)
         # then completes the operator
         op.dst = torch.empty((nv, k), dtype=torch.int32, device=dev)
-        check(lib.gp_pool_cs_structure(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), total, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
+        check(lib.gp_pool_cs_structure(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), total, max_union, _ptr(bu_row), _ptr(bu_mask), _ptr(wa_hi),
                                        _ptr(wa_lo), _ptr(op.dst), _stream()), "gp_pool_cs_structure")
     return op
 
@@ -578,7 +581,7 @@ def pool_cs_fill(op, nbr, w):
     """Second half: union rows, fragment masks and the weights in fragment order (no host sync)."""
     lib = _lib.load()
     nv, k = nbr.shape
-    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), int(op.block_rows), _ptr(op.bu_off), op.total, _ptr(op.bu_row),
+    check(lib.gp_pool_cs_fill(_ptr(nbr), _ptr(w), nv, int(k), int(op.block_rows), _ptr(op.bu_off), op.total, int(op.max_union), _ptr(op.bu_row),
                               _ptr(op.bu_mask), _ptr(op.wa_hi), _ptr(op.wa_lo), _stream()), "gp_pool_cs_fill")
     op.filled = True
     return op

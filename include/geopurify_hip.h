@@ -269,21 +269,25 @@ int gp_pool_mfma_apply_persistent(const void *x_hi, const void *x_lo, int64_t ld
 /* models/affinity_module.py:1575-1589.  gp_pool_cs_count needs the neighbour lists only: a scheduler can run it (and the  */
 /* host read-back of bu_off[nblocks] that sizes the arrays) before the affinity weights exist.                            */
 size_t gp_pool_cs_workspace_bytes(int64_t nv, int32_t rows_per_block);
+/* max_union (device i64, may be NULL): receives the largest block union.  The fill passes take it (max_union argument, 0 = not   */
+/* known) to size their LDS tables -- 56 KiB instead of 152 KiB per workgroup on a ScanNet-shaped scene -- together with the      */
+/* host read-back of bu_off[nblocks].                                                                                           */
 int gp_pool_cs_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, int64_t *bu_off, int32_t *bu_n,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     int64_t *max_union, void *workspace, size_t workspace_bytes, void *stream);
 int gp_pool_cs_fill(const int32_t *nbr, const float *w, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
-                    int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream);
+                    int64_t total_rows, int32_t max_union, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, void *stream);
 /* gp_pool_cs_fill without the weights: bu_row, bu_mask, zeroed fragments and dst i32 [nv, k] = the element of wa_hi / wa_lo that  */
 /* (row, neighbour j) owns; gp_affinity_softmax_scatter completes the operator.  Needs the neighbour lists only (a scheduler runs */
 /* it ahead, like gp_pool_cs_count).  total_rows * 128 must fit 32 bits (else: gp_pool_cs_fill).                               */
 int gp_pool_cs_structure(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
-                         int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo, int32_t *dst,
-                         void *stream);
+                         int64_t total_rows, int32_t max_union, int32_t *bu_row, uint32_t *bu_mask, void *wa_hi, void *wa_lo,
+                         int32_t *dst, void *stream);
 /* The structure for gp_affinity_cs_fragments: union rows, fragment masks and valid u32 [total_rows / 32 * 128 + 64]: bit p of  */
 /* valid[step * 128 + row] = union row 32 step + p of the row's block is one of that row's neighbours (the last 64 words are     */
 /* padding).  No fragment is touched.  Needs the neighbour lists only; their ids must be distinct within a row (k-NN lists are).  */
 int gp_pool_cs_structure_valid(const int32_t *nbr, int64_t nv, int32_t k, int32_t rows_per_block, const int64_t *bu_off,
-                               int64_t total_rows, int32_t *bu_row, uint32_t *bu_mask, uint32_t *bu_valid, void *stream);
+                               int64_t total_rows, int32_t max_union, int32_t *bu_row, uint32_t *bu_mask, uint32_t *bu_valid,
+                               void *stream);
 /* Row 11 (models/affinity_module.py:1559-1572) fused with the operator fill, on the matrix cores: e_hi / e_lo = the unit          */
 /* embeddings x 2^10 as f16 planes [nv, 128] (gp_split_f16_scaled, scale 1024); every (row, union row) similarity of a non-empty   */
 /* fragment is computed as hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16, the valid ones go through the row's softmax           */
