@@ -158,14 +158,20 @@ __global__ void lift_masks_kernel(const float *__restrict__ mt /*[h*w, Q]*/, int
 
 // ---- the same for ALL views of a scene: entries e = (view, point, pixel) in view-major order (gp_views_visible_lists); the masks
 // of view v are mt + v * h*w*Q, its scores scores + v * Q.  Entries of dropped views get -1.
-__global__ void transpose_views_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst) {
+// (order: the queries of view blockIdx.z by descending score, lv_sort_scores_kernel -- row r of the transposed copy is query order[r])
+__global__ void transpose_views_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst,
+                                       const int32_t *__restrict__ order) {
     __shared__ float tile[64][65];
     const int64_t vo = (int64_t)blockIdx.z * rows * cols;
+    const int32_t *ord = order + (int64_t)blockIdx.z * rows;
     int bx = blockIdx.x * 64, by = blockIdx.y * 64;
     int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __shared__ int s_ord[64];                                  // (one load per tile row instead of a dependent load in front of every read)
+    if (threadIdx.x < 64) s_ord[threadIdx.x] = by + threadIdx.x < rows ? ord[by + threadIdx.x] : 0;
+    __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         int row = by + r, col = bx + tx;
-        tile[r][tx] = (row < rows && col < cols) ? src[vo + (int64_t)row * cols + col] : 0.f;
+        tile[r][tx] = (row < rows && col < cols) ? src[vo + (int64_t)s_ord[r] * cols + col] : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -173,15 +179,113 @@ __global__ void transpose_views_kernel(const float *__restrict__ src, int rows, 
         if (orow < cols && ocol < rows) dst[vo + (int64_t)orow * rows + ocol] = tile[tx][r];
     }
 }
+// the queries of every view by (score descending, index ascending): order i32 [V, Q] (rank -> query), sscore f32 [V, Q].  One
+// workgroup per view, bitonic sort of 64-bit keys in LDS (Q <= 1024).
+__global__ void __launch_bounds__(256) lv_sort_scores_kernel(const float *__restrict__ scores, int Q, int32_t *__restrict__ order,
+                                                             float *__restrict__ sscore) {
+    __shared__ unsigned long long key[1024];
+    const int v = blockIdx.x;
+    int np2 = 1;
+    while (np2 < Q) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += 256) {
+        unsigned long long k = ~0ull;
+        if (i < Q) {
+            unsigned u = __float_as_uint(scores[(int64_t)v * Q + i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                     // monotone in the float's value
+            k = ((unsigned long long)(~u) << 32) | (unsigned)i;                // ascending key = descending score, then ascending index
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = key[i], y = key[ixj];
+                    if ((x > y) == ((i & kk) == 0)) { key[i] = y; key[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < Q; i += 256) {
+        const int qo = (int)(key[i] & 0xFFFFFFFFull);
+        order[(int64_t)v * Q + i] = qo;
+        sscore[(int64_t)v * Q + i] = scores[(int64_t)v * Q + qo];
+    }
+}
+// One wave per entry on the score-ordered copy.  The candidates of a pixel are the Q products score_q x sigmoid(logit_q) <= score_q:
+// with the queries in descending score order, a pass of 64 can be skipped -- with every pass behind it -- as soon as its LARGEST
+// score is strictly below the best product found so far (nothing in it can win or tie).  The decision is the one of
+// lift_masks_point (largest product, then smallest query index; the same arithmetic per candidate), reached after 1.1 passes
+// instead of 4 on the S scene's synthetic masks (92 % of the pixels stop after the first 64 queries).
+__device__ __forceinline__ void lift_masks_point_sorted(const float *__restrict__ mt /*[h*w, Q] in rank order*/, int Q, int h, int w,
+                                                        const float *__restrict__ sscore, const int32_t *__restrict__ order,
+                                                        const int32_t *__restrict__ tx0, const float *__restrict__ twx,
+                                                        const int32_t *__restrict__ ty0, const float *__restrict__ twy, int out_h, int out_w,
+                                                        int row, int col, int lane, int &seg_out) {
+    bool inb = (unsigned)row < (unsigned)out_h && (unsigned)col < (unsigned)out_w;
+    float best = -1.f, best_logit = 0.f;
+    int best_q = -1;
+    if (inb) {
+        int x0 = tx0[col], y0 = ty0[row];
+        float wx[4], wy[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { wx[t] = twx[col * 4 + t]; wy[t] = twy[row * 4 + t]; }
+        for (int q0 = 0; q0 < Q; q0 += 64) {
+            if (q0 > 0) {                                                     // wave-uniform: can the rest still matter?
+                float wb = best;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wb = fmaxf(wb, __shfl_xor(wb, o, 64));
+                if (sscore[q0] < wb) break;
+            }
+            const int q = q0 + lane;
+            if (q < Q) {
+                float sc = sscore[q];
+                float hr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int yy = min(y0 + j, h - 1);
+                    const float *r = mt + ((int64_t)yy * w) * Q + q;
+                    float t = __fmul_rn(r[(int64_t)min(x0, w - 1) * Q], wx[0]);
+#pragma unroll
+                    for (int a = 1; a < 4; ++a) t = fmaf(r[(int64_t)min(x0 + a, w - 1) * Q], wx[a], t);
+                    hr[j] = t;
+                }
+                float v = __fmul_rn(hr[0], wy[0]);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) v = fmaf(hr[j], wy[j], v);
+                if (sc > 0.f) {
+                    float sg = 1.f / (1.f + expf(-v));
+                    float pr = __fmul_rn(sc, sg);
+                    const int qo = order[q];
+                    if (pr > best || (pr == best && qo < best_q)) { best = pr; best_q = qo; best_logit = v; }
+                }
+            }
+        }
+    }
+    // wave arg-max: larger value, then smaller (original) query index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oq = __shfl_xor(best_q, o, 64);
+        float ol = __shfl_xor(best_logit, o, 64);
+        bool take = (oq >= 0) && (best_q < 0 || ob > best || (ob == best && oq < best_q));
+        if (take) { best = ob; best_q = oq; best_logit = ol; }
+    }
+    float sg = 1.f / (1.f + expf(-best_logit));
+    seg_out = (best_q >= 0 && sg >= 0.5f) ? best_q : -1;
+}
 // Measured and left out (round 4): the entries of a view come in POINT order, scattered over the image, and the kernel fetches 4.6 GB
 // from beyond L2 per S scene for 0.39 GB of transposed logits (PMC: 53 % L2 hits); with the entries radix-sorted by (view, 8 x 8 pixel
 // tile) it takes 524 instead of 545 us and the sort costs 80 us: the wave's 16 taps x Q multiply-adds and their dependent loads
 // bound it, not the bytes.  Four consecutive queries per lane with 16-byte loads (Q = 200: one pass of 16 loads on 50 lanes instead of
 // four passes of 16 dword loads, the last with 8 live lanes; same bits) is SLOWER: 733 us -- the four passes keep four times as many
-// loads in flight.
-__global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, Q]*/, int Q, int h, int w,
-                                        const float *__restrict__ scores /*[V,Q]*/, const int32_t *__restrict__ tx0,
-                                        const float *__restrict__ twx, const int32_t *__restrict__ ty0,
+// loads in flight.  Round 5: a tile-major form (bins of 16 low-resolution cells staged in LDS from the [Q, h, w] layout): 1.9 ms
+// (profiles/r05_lift_tile_major.log); what pays is doing less of the work: the score order above.
+__global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, Q] in rank order*/, int Q, int h, int w,
+                                        const float *__restrict__ sscore /*[V,Q]*/, const int32_t *__restrict__ order /*[V,Q]*/,
+                                        const int32_t *__restrict__ tx0, const float *__restrict__ twx, const int32_t *__restrict__ ty0,
                                         const float *__restrict__ twy, int out_h, int out_w,
                                         const int64_t *__restrict__ ent_x, const int64_t *__restrict__ ent_y,
                                         const int32_t *__restrict__ ent_view, const uint8_t *__restrict__ keep, int64_t total,
@@ -191,10 +295,9 @@ __global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, 
     int lane = gp_lane();
     const int v = ent_view[e];
     int sg = -1;
-    float lg;
     if (keep[v])                                                 // wave-uniform
-        lift_masks_point(mt + (int64_t)v * h * w * Q, Q, h, w, scores + (int64_t)v * Q, tx0, twx, ty0, twy, out_h, out_w,
-                         (int)ent_x[e], (int)ent_y[e], lane, sg, lg);
+        lift_masks_point_sorted(mt + (int64_t)v * h * w * Q, Q, h, w, sscore + (int64_t)v * Q, order + (int64_t)v * Q, tx0, twx, ty0, twy,
+                                out_h, out_w, (int)ent_x[e], (int)ent_y[e], lane, sg);
     if (lane == 0) seg[e] = sg;
 }
 
@@ -570,11 +673,14 @@ static size_t lv_scan64_tmp(int64_t n) {
 struct LvWork {
     float *mt; int32_t *cov, *rs, *rent, *qent; float *rxyz; double *part_d; int32_t *part_i; unsigned long long *vmask; int4 *tab;
     int64_t *cnt; char *tmp; size_t tmp_bytes;
+    int32_t *order; float *sscore;                       // the queries of every view by descending score
 };
 static size_t lv_carve(void *ws, size_t bytes, int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n, int64_t fill_cap,
                        LvWork &k) {
     GpCarver cv(ws, bytes);
     k.mt = cv.take<float>((size_t)nsrc * q * h * w);
+    k.order = cv.take<int32_t>((size_t)nsrc * q);
+    k.sscore = cv.take<float>((size_t)nsrc * q);
     k.cov = cv.take<int32_t>(total + 1);
     k.rs = cv.take<int32_t>(total + 1);
     k.rent = cv.take<int32_t>(total);
@@ -613,6 +719,7 @@ extern "C" int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_
                      keep && seg && pv_start && pv_view && pv_seg && workspace,
                  "gp_lift_masks_views: null argument");
     GP_CHECK_ARG(q > 0 && h > 0 && w > 0 && n > 0 && total > 0, "gp_lift_masks_views: empty shape");
+    GP_CHECK_ARG(q <= 1024, "gp_lift_masks_views: %d queries (the score sort holds 1024)", q);
     GP_CHECK_ARG(nviews > 0 && nviews <= 128 && nviews <= nsrc, "gp_lift_masks_views: %d views (1..128, <= %d mask sets)", nviews, nsrc);
     GP_CHECK_ARG(total < (int64_t)INT32_MAX, "gp_lift_masks_views: too many entries");
     GP_CHECK_ARG(fill_cap >= 0 && fill_cap <= total, "gp_lift_masks_views: fill_cap=%lld outside 0..total", (long long)fill_cap);
@@ -624,9 +731,10 @@ extern "C" int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_
     }
     hipStream_t s = gp_stream(stream_);
     const int hw = h * w;
-    transpose_views_kernel<<<dim3((hw + 63) / 64, (q + 63) / 64, nviews), 256, 0, s>>>(pred_masks, q, hw, k.mt);
-    lift_masks_views_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, s>>>(k.mt, q, h, w, scores, tap_x0, tap_wx, tap_y0, tap_wy,
-                                                                               out_h, out_w, ent_x, ent_y, ent_view, keep, total, seg);
+    lv_sort_scores_kernel<<<nviews, 256, 0, s>>>(scores, q, k.order, k.sscore);
+    transpose_views_kernel<<<dim3((hw + 63) / 64, (q + 63) / 64, nviews), 256, 0, s>>>(pred_masks, q, hw, k.mt, k.order);
+    lift_masks_views_kernel<<<(unsigned)((total * 64 + 255) / 256), 256, 0, s>>>(k.mt, q, h, w, k.sscore, k.order, tap_x0, tap_wx, tap_y0,
+                                                                               tap_wy, out_h, out_w, ent_x, ent_y, ent_view, keep, total, seg);
     // in-view fill
     const unsigned eb = (unsigned)((total + 1 + 255) / 256);
     fill_flags_kernel<<<eb, 256, 0, s>>>(seg, total, k.cov);
