@@ -3,7 +3,7 @@
 # profile (kernel stats + PMC passes).  usage: scripts/final_round.sh <tag>  -> gpurun_out/<tag>/...
 set -e
 R=$GRAFT_REPO_ROOT
-T=${1:-r04}
+T=${1:-r05}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
