@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgeopurify_hip.so")
+LIB_PATH = os.environ.get("GP_LIB") or os.path.join(_HERE, "libgeopurify_hip.so")      # (GP_LIB: another build of the library, for same-box A/B runs)
 
 _P = c_void_p  # every device pointer travels as void*
 
