@@ -20,15 +20,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int EH_ROWS = 128, EH_COLS = 128, EH_KC = 64, EH_PITCH = EH_KC + 8, EH_NT = 256;
+constexpr int EH_EP = EH_COLS + 8;                  // halfs per row of the epilogue's plane image (272 bytes)
 struct EhSmem {
     _Float16 b_hi[2][EH_COLS][EH_PITCH];
     _Float16 b_lo[2][EH_COLS][EH_PITCH];
 };
+static_assert(sizeof(EhSmem) >= 4 * 2 * 32 * EH_EP * sizeof(_Float16), "the epilogue's plane images of the four waves reuse the weight buffers");
 
 __global__ void __launch_bounds__(EH_NT)
 embed_head_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x, const float *__restrict__ x_row_inv,
                   const _Float16 *__restrict__ w_hi /*[128][cin]*/, const _Float16 *__restrict__ w_lo, int64_t nv, int cin, float out_scale,
-                  int normalize, float *__restrict__ y, int64_t ld_y) {
+                  int normalize, float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ e_hi, _Float16 *__restrict__ e_lo,
+                  float plane_scale) {
     __shared__ EhSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fq = lane >> 4;
@@ -131,29 +134,59 @@ embed_head_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = v[j] / nrm;
             }
-            if (row < nv) {
+            if (row < nv && y) {
                 float *dst = y + row * ld_y + fl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dst[j * 16] = v[j];
             }
+            if (e_hi) {
+                // the row as f16 hi / lo planes of v x plane_scale (what gp_affinity_cs_fragments stages by LDS-DMA): through a wave-private
+                // LDS image (the weight buffers are free: the loop's last barrier is behind every read of them), 272-byte row pitch so that
+                // the four row groups of a store instruction fall on different banks, then 16-byte pieces to global memory
+                _Float16 *st = reinterpret_cast<_Float16 *>(&sm) + wv * (2 * 32 * EH_EP);
+                const int lrow = i * 16 + fq * 4 + r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float sv = v[j] * plane_scale;
+                    const _Float16 h = (_Float16)sv;
+                    st[lrow * EH_EP + j * 16 + fl] = h;
+                    st[32 * EH_EP + lrow * EH_EP + j * 16 + fl] = (_Float16)(sv - (float)h);
+                }
+            }
         }
+    if (e_hi) {
+        gp_wave_sync();
+        const _Float16 *st = reinterpret_cast<const _Float16 *>(&sm) + wv * (2 * 32 * EH_EP);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int id = lane + 64 * t, lrow = id >> 4, piece = id & 15;
+            const int64_t row = r0 + lrow;
+            if (row < nv) {
+                *reinterpret_cast<f16x8 *>(e_hi + row * EH_COLS + piece * 8) = *reinterpret_cast<const f16x8 *>(st + lrow * EH_EP + piece * 8);
+                *reinterpret_cast<f16x8 *>(e_lo + row * EH_COLS + piece * 8) = *reinterpret_cast<const f16x8 *>(st + 32 * EH_EP + lrow * EH_EP + piece * 8);
+            }
+        }
+    }
 }
 }  // namespace
 
 extern "C" int gp_embed_head_f16x3(const void *x_hi, const void *x_lo, int64_t ld_x, const float *x_row_inv_scale, const void *w_hi,
                                    const void *w_lo, int64_t nv, int32_t cin, int32_t cout, float out_scale, int32_t l2_normalize,
-                                   float *y, int64_t ld_y, void *stream_) {
-    GP_CHECK_ARG(x_hi && x_lo && w_hi && w_lo && y && nv > 0, "gp_embed_head_f16x3: null/empty argument");
+                                   float *y, int64_t ld_y, void *e_hi, void *e_lo, float plane_scale, void *stream_) {
+    GP_CHECK_ARG(x_hi && x_lo && w_hi && w_lo && (y || e_hi) && nv > 0, "gp_embed_head_f16x3: null/empty argument");
+    GP_CHECK_ARG((e_hi != nullptr) == (e_lo != nullptr) && (!e_hi || ((uintptr_t)e_hi % 16 == 0 && (uintptr_t)e_lo % 16 == 0 && plane_scale > 0.f)),
+                 "gp_embed_head_f16x3: the output planes come as a 16-byte aligned pair with a positive scale");
     GP_CHECK_ARG(cout == EH_COLS, "gp_embed_head_f16x3: cout=%d, this kernel writes %d embedding channels", cout, EH_COLS);
     GP_CHECK_ARG(cin > 0 && cin % EH_KC == 0, "gp_embed_head_f16x3: cin=%d must be a multiple of %d", cin, EH_KC);
     GP_CHECK_ARG(ld_x % 8 == 0 && ld_x >= cin && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0,
                  "gp_embed_head_f16x3: pre-split rows must be 16-byte aligned and hold cin channels");
-    GP_CHECK_ARG((uintptr_t)w_hi % 16 == 0 && (uintptr_t)w_lo % 16 == 0 && ld_y >= cout, "gp_embed_head_f16x3: bad weight / output layout");
+    GP_CHECK_ARG((uintptr_t)w_hi % 16 == 0 && (uintptr_t)w_lo % 16 == 0 && (!y || ld_y >= cout), "gp_embed_head_f16x3: bad weight / output layout");
     GP_CHECK_ARG(out_scale > 0.f, "gp_embed_head_f16x3: out_scale must be the positive inverse of the weights' pre-scale");
     const int64_t blocks = (nv + EH_ROWS - 1) / EH_ROWS;
     embed_head_kernel<<<(unsigned)blocks, EH_NT, 0, gp_stream(stream_)>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, x_row_inv_scale, static_cast<const _Float16 *>(w_hi),
-        static_cast<const _Float16 *>(w_lo), nv, cin, out_scale, l2_normalize, y, ld_y);
+        static_cast<const _Float16 *>(w_lo), nv, cin, out_scale, l2_normalize, y, ld_y, static_cast<_Float16 *>(e_hi), static_cast<_Float16 *>(e_lo),
+        plane_scale);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

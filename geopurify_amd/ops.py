@@ -354,10 +354,12 @@ def l2norm_rows_(x, d=None):
     return x
 
 
-def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=True, out=None):
+def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=True, out=None, planes=False, want_f32=True):
     """The student's 1x1x1 output layer on pre-split rows, fused with F.normalize (affinity_module.py:66,71,1547).
     x_split = (hi, lo) f16 [nv, >=cin]; w_hi / w_lo f16 [1, cout, cin] or [cout, cin] (conv_weights_split of the [1, cin, cout]
-    kernel with a power-of-two pre-scale whose inverse is out_scale)."""
+    kernel with a power-of-two pre-scale whose inverse is out_scale).
+    planes=True: also returns the rows x 2^10 as f16 (hi, lo) planes -- the operand of affinity_cs_fragments -- written by the same
+    epilogue; want_f32=False then skips the fp32 rows.  Returns out, or (out_or_None, (e_hi, e_lo))."""
     lib = _lib.load()
     hi, lo = x_split
     cout, cin = w_hi.shape[-2:]
@@ -365,11 +367,16 @@ def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=T
     _chk(hi, torch.float16, "x_hi"), _chk(lo, torch.float16, "x_lo")
     if hi.stride(0) != lo.stride(0) or hi.shape[1] < cin:
         raise ValueError("embed_head_f16x3: the hi / lo planes must share a row stride and hold cin channels")
-    if out is None:
+    if out is None and (want_f32 or not planes):
         out = torch.empty((nv, cout), dtype=torch.float32, device=hi.device)
+    eh = el = None
+    if planes:
+        eh = torch.empty((nv, cout), dtype=torch.float16, device=hi.device)
+        el = torch.empty((nv, cout), dtype=torch.float16, device=hi.device)
     check(lib.gp_embed_head_f16x3(_ptr(hi), _ptr(lo), hi.stride(0), _ptr(x_row_inv), _ptr(w_hi), _ptr(w_lo), nv, int(cin), int(cout),
-                                  float(out_scale), int(bool(normalize)), _ptr(out), out.stride(0), _stream()), "gp_embed_head_f16x3")
-    return out
+                                  float(out_scale), int(bool(normalize)), _ptr(out), out.stride(0) if out is not None else 0, _ptr(eh), _ptr(el),
+                                  AFFINITY_PLANE_SCALE, _stream()), "gp_embed_head_f16x3")
+    return (out, (eh, el)) if planes else out
 
 
 def knn_lattice(grid, coords_sorted, ids, k):
@@ -404,18 +411,23 @@ def affinity_softmax(e, nbr, sharpen=20.0, d=None, into=None):
 
 
 _E_SCALE = {}
+AFFINITY_PLANE_SCALE = 1024.0      # the embedding planes of affinity_cs_fragments carry e x 2^10 (lo halves stay normal numbers)
 
 
-def affinity_cs_fragments(e, sharpen, op):
-    """Row 11 + the operator fill in one matrix-core kernel (gp_affinity_cs_fragments): e fp32 [nv, 128] unit rows, op a PoolCs whose
-    structure was built with pool_cs_plan(structure="valid").  Completes op (no [nv, k] weight matrix is produced)."""
+def affinity_cs_fragments(e, sharpen, op, planes=None):
+    """Row 11 + the operator fill in one matrix-core kernel (gp_affinity_cs_fragments): e fp32 [nv, 128] unit rows -- or planes = their
+    (hi, lo) f16 planes x 2^10 as embed_head_f16x3(planes=True) writes them -- and op a PoolCs whose structure was built with
+    pool_cs_plan(structure="valid").  Completes op (no [nv, k] weight matrix is produced)."""
     lib = _lib.load()
     if op.valid is None:
         raise ValueError("affinity_cs_fragments: the operator needs pool_cs_plan(structure='valid')")
-    key = str(e.device)
-    if key not in _E_SCALE:
-        _E_SCALE[key] = torch.tensor([1024.0], dtype=torch.float32, device=e.device)
-    eh, el = split_f16(e, 128, scale=_E_SCALE[key])
+    if planes is not None:
+        eh, el = planes
+    else:
+        key = str(e.device)
+        if key not in _E_SCALE:
+            _E_SCALE[key] = torch.tensor([AFFINITY_PLANE_SCALE], dtype=torch.float32, device=e.device)
+        eh, el = split_f16(e, 128, scale=_E_SCALE[key])
     check(lib.gp_affinity_cs_fragments(_ptr(eh), _ptr(el), op.nv, 128, int(op.k), float(sharpen), _ptr(op.bu_off), _ptr(op.bu_row),
                                        _ptr(op.bu_mask), _ptr(op.valid), int(op.block_rows), _ptr(op.wa_hi), _ptr(op.wa_lo), _stream()),
           "gp_affinity_cs_fragments")

@@ -116,10 +116,12 @@ class StudentWeights:
         means only, so a scheduler can run it ahead (HotPath.prepare)."""
         return ops.split_f16(x, self.cin_pad, per_row=True) if self.fast else None
 
-    def forward(self, x, nbr_map, pairs=None, x_split=None, mark=None):
+    def forward(self, x, nbr_map, pairs=None, x_split=None, mark=None, planes=False):
         """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed].
         On the f16x3 path every layer also emits its output pre-split (hi/lo f16) so that the next
-        layer stages both operands by LDS-DMA.  x_split: split_input(x) when it was made ahead."""
+        layer stages both operands by LDS-DMA.  x_split: split_input(x) when it was made ahead.
+        planes=True (only with the fused output layer): returns the embeddings x 2^10 as f16 (hi, lo) planes INSTEAD -- the operand
+        of the matrix-core affinity kernel, written by the output layer's epilogue (no fp32 rows, no split pass)."""
         ctx = {"nbr_map": nbr_map, "pairs": pairs}
         fast = self.fast
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
@@ -135,9 +137,14 @@ class StudentWeights:
         if mark is not None:
             mark("student convolutions")                  # (stage marks of bench.py's per-stage pass)
         if fast and self.head is not None and hs is not None:
+            if planes:
+                return ops.embed_head_f16x3(hs[:2], self.head[0], self.head[1], self.head[2], x_row_inv=hs[2], normalize=True,
+                                            planes=True, want_f32=False)[1]
             return ops.embed_head_f16x3(hs[:2], self.head[0], self.head[1], self.head[2], x_row_inv=hs[2], normalize=True)
-        e = ops.sparse_conv(h, None, self.w_out)
-        return ops.l2norm_rows_(e)
+        e = ops.l2norm_rows_(ops.sparse_conv(h, None, self.w_out))
+        if planes:
+            return ops.split_f16(e, self.embed, scale=torch.tensor([ops.AFFINITY_PLANE_SCALE], dtype=torch.float32, device=e.device))
+        return e
 
     def flops(self, num_pairs, nv):
         per_pair = self.cin * self.hidden + 2 * self.num_blocks * self.hidden * self.hidden
@@ -562,16 +569,17 @@ class HotPath:
         p = prepared if prepared is not None else self.prepare(batch, F)
         X, rank, nbr, Nv, D = p["X"], p["rank"], p["nbr"], p["Nv"], p["D"]
         mark = self.stage_mark if self.stage_mark is not None else (lambda name: None)
-        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"), mark=self.stage_mark)
+        # the operator's structure was built ahead: the affinity kernel writes its weights straight into fragment order
+        op = p["pool"]["op"] if p["pool"] is not None else None
+        mfma_aff = op is not None and op.valid is not None
+        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"), mark=self.stage_mark, planes=mfma_aff)
         mark("embed head" if self.stage_mark is not None else "student")
         if after_student is not None:
             after_student()
-        # the operator's structure was built ahead: the affinity kernel writes its weights straight into fragment order
-        op = p["pool"]["op"] if p["pool"] is not None else None
-        if op is not None and op.valid is not None:
+        if mfma_aff:
             # rows 11 + the operator fill on the matrix cores: similarities of every non-empty fragment, the valid ones through the
-            # row's softmax, fragments written whole (no [Nv, K] weight matrix exists on this path)
-            ops.affinity_cs_fragments(E, self.sharpen, op)
+            # row's softmax, fragments written whole (no [Nv, K] weight matrix exists on this path); E = the embeddings as planes x 2^10
+            ops.affinity_cs_fragments(None, self.sharpen, op, planes=E)
             w = None
         else:
             w = ops.affinity_softmax(E, nbr, self.sharpen, into=op if op is not None and op.dst is not None else None)
@@ -608,7 +616,11 @@ class HotPath:
         R = self.pool_tile_rows
         tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
         if w is None and (plan is None or not plan["op"].filled):
-            w = ops.affinity_softmax(self._last_E, nbr, self.sharpen)      # (isolated calls after a scene whose weights went straight into fragments)
+            # (isolated calls after a scene whose weights went straight into fragments: the [Nv, K] weights from the embedding planes)
+            E = self._last_E
+            if isinstance(E, tuple):
+                E = (E[0].float() + E[1].float()) / ops.AFFINITY_PLANE_SCALE
+            w = ops.affinity_softmax(E.contiguous(), nbr, self.sharpen)
         if self.num_iters == 0:
             out = torch.empty((Nv, D), dtype=torch.float32, device=dev)
             out.copy_(X[:, :D])

@@ -180,9 +180,11 @@ int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
 /* y[r, :] = out_scale * x_row_inv_scale[r] * sum_c (x_hi + x_lo)[r, c] * (w_hi + w_lo)[:, c]   (three exact f16 products per  */
 /* element, fp32 accumulation, fixed order).  w_hi / w_lo f16 [cout, cin] from gp_conv_weights_split(kv = 1, scale 2^k),       */
 /* out_scale = 2^-k; x_row_inv_scale nullable (unscaled planes).  cout = 128, cin a multiple of 64.                            */
+/* e_hi / e_lo (nullable pair, f16 [nv, 128]): also / instead (y may then be NULL) the rows x plane_scale as hi + lo planes --   */
+/* the operand of gp_affinity_cs_fragments (plane_scale 1024), written by the same epilogue instead of a separate split pass.    */
 int gp_embed_head_f16x3(const void *x_hi, const void *x_lo, int64_t ld_x, const float *x_row_inv_scale, const void *w_hi,
                         const void *w_lo, int64_t nv, int32_t cin, int32_t cout, float out_scale, int32_t l2_normalize,
-                        float *y, int64_t ld_y, void *stream);
+                        float *y, int64_t ld_y, void *e_hi, void *e_lo, float plane_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row 10: faiss.IndexFlatL2.search(K+1) on integer voxel coordinates, self dropped              */

@@ -763,6 +763,14 @@ def test_embed_head_f16x3_matches_fp64_and_the_fp32_kernel(ops):
     assert rel[torch.arange(nv) != 17].max() < 4e-6, rel.max()
     # bitwise repeatable, and independent of how many rows share a launch (rows 0..1279 alone = the same bits)
     assert torch.equal(ops.embed_head_f16x3(xs[:2], hi, lo, 1.0 / p2, x_row_inv=xs[2]), e)
+    # round 5: the same rows x 2^10 as f16 hi / lo planes from the same epilogue (the matrix-core affinity kernel's operand): the fp32
+    # rows beside them are unchanged, the planes are the split of exactly those rows, with or without the fp32 output
+    e2, (ph, plo) = ops.embed_head_f16x3(xs[:2], hi, lo, 1.0 / p2, x_row_inv=xs[2], planes=True)
+    assert torch.equal(e2, e)
+    sv = e * 1024.0
+    assert torch.equal(ph, sv.half()) and torch.equal(plo, (sv - sv.half().float()).half())
+    none, (ph2, plo2) = ops.embed_head_f16x3(xs[:2], hi, lo, 1.0 / p2, x_row_inv=xs[2], planes=True, want_f32=False)
+    assert none is None and torch.equal(ph2, ph) and torch.equal(plo2, plo)
     part = ops.embed_head_f16x3((xs[0][:1280], xs[1][:1280]), hi, lo, 1.0 / p2, x_row_inv=xs[2][:1280])
     assert torch.equal(part, e[:1280])
     with pytest.raises(GeoPurifyHipError, match="embedding channels"):
