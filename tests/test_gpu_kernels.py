@@ -1041,6 +1041,51 @@ def test_pool_cs_chained_launch_small_and_overflowing_lists(ops, kind, rpb, T):
         ops.pool_cs_apply_chain(xs, pong, op, D, 1, out)
 
 
+def test_pool_cs_chained_launch_gives_up_instead_of_hanging(ops):
+    """gp_pool_cs_apply_chain's contract for a dependency that never comes: the wait is bounded (2 s of the constant clock), the workgroup
+    sets the abort word and leaves, every later poll sees it -- the grid drains -- and the host side of the contract
+    (pool_cs_chain_check) raises.  Staged by pointing one row block's list at a flag nobody publishes (the header word in front of
+    the flags: index -1)."""
+    import time
+    rng = np.random.default_rng(9)
+    c = surface_voxels(rng, 3000)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, K, D = len(c), 32, 512
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    w = torch.softmax(torch.randn(Nv, K, device="cuda"), dim=1).contiguous()
+    op = ops.pool_cs_build(nbr, w)
+    ops.pool_cs_deps(op)
+    dep = op.dep.view(-1, 64)
+    n0 = int(dep[3, 0])
+    assert 1 <= n0 < 63
+    dep[3, 1] = -1                                                   # row block 3 waits for a flag that stays 0
+    xs = ops.split_f16(torch.randn(Nv, 544, device="cuda"), D)
+    pong = tuple(torch.empty((Nv, D), dtype=torch.float16, device="cuda") for _ in range(2))
+    out = torch.empty(Nv, D, device="cuda")
+    t0 = time.time()
+    ops.pool_cs_apply_chain(xs, pong, op, D, 3, out)
+    torch.cuda.synchronize()
+    took = time.time() - t0
+    assert 1.5 < took < 30, took                                     # one bounded wait, not one per dependent tile
+    with pytest.raises(Exception, match="waited 2 s"):
+        ops.pool_cs_chain_check(op)
+    # the operator is usable again once the caller has dealt with it: lists repaired, abort word cleared
+    ops.pool_cs_deps(op)
+    ref = torch.empty(Nv, D, device="cuda")
+    sp = [tuple(t.clone() for t in xs), tuple(torch.empty_like(t) for t in pong)]
+    x_keep = tuple(t.clone() for t in xs)
+    src = sp[0]
+    for t in range(3):
+        last = t == 2
+        dst = None if last else sp[(t + 1) % 2]
+        ops.pool_cs_apply(src, op, D, out_split=dst, out_f32=ref if last else None)
+        src = dst
+    ops.pool_cs_apply_chain(tuple(t.clone() for t in x_keep), pong, op, D, 3, out)
+    torch.cuda.synchronize()
+    ops.pool_cs_chain_check(op)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("n_vox,rpb", [(2500, 128), (2531, 128), (2531, 100), (2500, 117)])
 def test_pool_cs_matches_ell_and_oracle(ops, n_vox, rpb):
     """Column-sliced matrix-core pooling (blocks of rpb <= 128 rows, union rows grouped by the 16-row groups that use them,
