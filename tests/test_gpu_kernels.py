@@ -948,6 +948,32 @@ def _cs_dense_block(op, b, K, nbc, wc, Nv):
     assert keys == sorted(keys)
 
 
+def test_affinity_cs_fragments_on_non_local_neighbour_lists(ops):
+    """The same kernels on neighbour lists that are NOT local (random distinct ids: a block's union is ~10 000 rows = hundreds of steps):
+    the builder's validity words go through global atomics (they do not fit its LDS buffer), the affinity kernel's fragment pass
+    re-loads the words of the steps beyond the 24 it keeps in LDS, and the operator builder runs its second, full-size count pass."""
+    rng = np.random.default_rng(77)
+    Nv, K = 2200, 96
+    nbr = torch.from_numpy(np.stack([rng.choice(Nv, K, replace=False) for _ in range(Nv)]).astype(np.int32)).cuda()
+    E = F.normalize(torch.randn(Nv, 128), dim=1).cuda().contiguous()
+    op = ops.pool_cs_plan(nbr, structure="valid")
+    assert op.max_union > 1024 and int((op.bu_off[1:] - op.bu_off[:-1]).max()) // 32 > 24
+    ops.affinity_cs_fragments(E, 20.0, op)
+    ref_op = ops.pool_cs_plan(nbr, structure=True)
+    w_blk = ops.affinity_softmax(E, nbr, 20.0, into=ref_op)
+    assert torch.equal(ref_op.bu_row, op.bu_row) and torch.equal(ref_op.bu_mask, op.bu_mask)
+    frag = (op.wa_hi.float() + op.wa_lo.float()) / 1024.0
+    w = frag[ref_op.dst.long()]
+    Ed = E.double()
+    wref = torch.softmax(20.0 * (Ed[:, None, :] * Ed[nbr.long()]).sum(-1), dim=1)
+    assert (w.double() - wref).abs().max().item() < 2e-6 and (w - w_blk).abs().max().item() < 4e-6
+    X = torch.randn(Nv, 544, device="cuda")
+    y_ell, y_cs = torch.empty(Nv, 512, device="cuda"), torch.empty(Nv, 512, device="cuda")
+    ops.pool_ell(X, nbr, w.contiguous(), 512, y_ell)
+    ops.pool_cs_apply(ops.split_f16(X, 512), op, 512, out_f32=y_cs)
+    assert (y_cs - y_ell).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("n_vox,rpb,K", [(2531, 128, 96), (2500, 100, 96), (1900, 128, 20), (300, 128, 96), (4000, 117, 64)])
 def test_affinity_cs_fragments_vs_fp64_and_the_block_kernel(ops, n_vox, rpb, K):
     """gp_pool_cs_structure_valid + gp_affinity_cs_fragments (rows 11 + operator fill on the matrix cores) on small operators: ragged
