@@ -108,14 +108,14 @@ def conv_roofline(timer):
 
 def conv_ceilings(hp, dev):
     """What bounds a 512->512 layer (VERDICT r3 next 4 ii): ONE layer of the last scene, alone on the GPU, on random pre-split rows:
-      layer_ms             the product kernels (conv_phase1_dma_kernel per chunk + conv_phase2_kernel per chunk)
+      layer_ms             the product kernels (conv_phase1_dma_kernel per chunk + conv_phase2_q24_kernel per chunk)
       no_mfma_ms           the same launches with the MFMAs compiled out of the loop's body (conv_phase1_tuning_kernel, knob 3 = 2):
                            operand gathers into LDS, the partial-row round trip and phase 2 -- the layer's DATA-MOVEMENT ceiling
       zero_operand_ms      the product kernels on all-zero rows and weights: the same instruction stream, the same cycles, at the
                            clock the chip holds when the matrix pipes toggle nothing (MI355X_MICROARCH.md "DVFS give-back")
       mfma_floor_ms        3 x the layer's flops at the dense f16 peak (2.5 PFLOP/s).
     Algorithmic bytes per layer: gathered operand rows P x 2 KiB x 2 column tiles, weight tiles (P / 256) x 2 x 512 KiB, partial
-    rows P x 2 KiB written and read, output rows (fp32 where kept + hi/lo planes); the memory-side bytes per LAYER are in
+    rows P x 1.5 KiB (24-bit block floating point, round 5; 2 KiB as fp32 before) written and read, output rows (fp32 where kept + hi/lo planes); the memory-side bytes per LAYER are in
     profiles/r04_conv_pmc_summary.json."""
     from geopurify_amd import _lib, ops
     st = hp.student
@@ -158,7 +158,7 @@ def conv_ceilings(hp, dev):
     P = float(pairs.num_pairs)
     flop = 2.0 * P * c * c
     alg = {"gathered_rows": P * c * 4 * (c // 256), "weight_tiles": np.ceil(P / 256) * (c // 256) * 256 * c * 4,
-           "partial_rows_written_and_read": 2 * P * c * 4, "output_planes": nv * c * 4}
+           "partial_rows_written_and_read": 2 * P * (c * 3 + c // 128), "output_planes": nv * c * 4}   # 24-bit block floating point
     return {"layer_ms": round(full, 4), "no_mfma_ms": round(nomfma, 4), "zero_operand_ms": round(zero, 4),
             "mfma_floor_ms": round(3 * flop / (MFMA_F16_PEAK_TFLOPS * 1e12) * 1e3, 4), "pairs": int(P), "chunks": int(pairs.num_chunks),
             "algorithmic_bytes_per_layer": {k: int(v) for k, v in alg.items()},

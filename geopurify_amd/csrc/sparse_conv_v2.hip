@@ -393,7 +393,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                      const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
                      const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
                      float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base,
-                     const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp) {
+                     const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp, int64_t q_e_off) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0, st_dma = 0, st_wait = 0;
@@ -426,7 +426,11 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         int row = (issuer ? wv : 0) * RPW + t * 16 + lrow;
         int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];              // clamped, unconditional: both loads overlap
         ga_hi[t] = x_hi + (int64_t)in_row * ld_xh + q;
-        gb_hi[t] = w_hi + ((int64_t)k * cout + n0 + row) * cin + q;
+        // LDS row j * 16 + f of a wave's 128 weight rows (column tile j, MFMA column f) holds OUTPUT COLUMN f * 8 + j: a lane's eight
+        // accumulators of a row are then eight consecutive columns of the partial row (one 16-byte and one 8-byte store per row in
+        // the 24-bit format below), and the permutation costs nothing: it is the source address of the LDS-DMA
+        const int wcol = (row & 128) | ((row & 15) << 3) | ((row >> 4) & 7);
+        gb_hi[t] = w_hi + ((int64_t)k * cout + n0 + wcol) * cin + q;
     }
     auto issue = [&](int c0, int buf) {
         if (!issuer) return;
@@ -511,59 +515,83 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         }
     };
     if (ablate & 8) { stamp_out(); return; }
-    // ---- epilogue: accumulators straight to the partial buffer (per instruction 4 rows x 64-byte runs, merged in L2).
-    //      Staging the tile through LDS for 512-byte runs made every slice's LDS reads wait for the previous slice's
-    //      stores (one vector-memory counter): 4 store round trips per tile, a third of the kernel's time.
-    if (!(ablate & 32)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < nrt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int grow = wm * 64 + i * 16 + fq * 4 + r;
-                    if (grow < cnt) {
-                        float *prow = P + (int64_t)(base - pair_base + grow) * cout + n0 + wn * 128 + fl;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) prow[j * 16] = acc[i][j][r] * rinv[i][r];
-                    }
-                }
-            }
-        }
-        stamp_out();
-        return;
-    }
-    // (ablate bit 5: the former LDS-staged epilogue, kept for A/B timing)
-    constexpr int EP = 132;                                  // floats per staged row (16-byte aligned, bank-skewed)
-    float *st = reinterpret_cast<float *>(smem_raw) + wv * (16 * EP);
+    // ---- epilogue: accumulators straight to the partial buffer (no LDS staging: that made every slice's LDS reads wait for the
+    //      previous slice's stores -- one vector-memory counter -- 4 store round trips per tile, a third of the kernel's time).
+    // PARTIAL ROWS ARE STORED AS 24-BIT BLOCK FLOATING POINT (round 5): per pair row and 128-column quarter (= what one wave owns) an
+    // exponent byte E and per element u = rint(v * 2^(148 - E)) + 2^22 in three bytes, |v * 2^(148 - E)| < 2^22 for every element of
+    // the quarter -- 3 + 1/128 bytes instead of 4 per element of the round trip phase 1 -> Infinity Cache -> phase 2 (2 x 2.0 GB per
+    // 512 -> 512 layer in fp32).  Encoding costs ONE fused multiply-add per element: t = fma(acc, s, 1.5 * 2^23) lies in [2^23, 2^24),
+    // where floats are the integers, so the hardware's round-to-nearest-even IS the quantisation and the three low bytes of t's bit
+    // pattern ARE u; eight elements = 24 bytes per lane, packed by six byte permutes.  The rounding is <= 2^-23 of the quarter's
+    // largest magnitude per partial row -- half of what the NEXT rounding on the path already is (phase 2 splits the summed row into
+    // f16 hi + lo at 2^-22 of the row's maximum).  E = 255 marks a quarter with an Inf or a NaN activation row (phase 2 writes NaN).
+    unsigned char *pb = reinterpret_cast<unsigned char *>(P);
+    const bool as_f32 = TUNE && (ablate & 32);               // tuning twin: the fp32 rows of rounds 1-4 (host pairs them with conv_phase2_kernel)
+    typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 24-byte lane records: 8-byte aligned
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i < nrt) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int r = 0; r < 4; ++r) {
+                const int grow = wm * 64 + i * 16 + fq * 4 + r;
+                const float sc = rinv[i][r];
+                const int64_t prow = base - pair_base + grow;
+                const int col = n0 + wn * 128 + fl * 8;
+                if (as_f32) {
+                    if (grow < cnt) {
+                        float *dst = P + prow * cout + col;
+                        *reinterpret_cast<float4 *>(dst) = make_float4(acc[i][0][r] * sc, acc[i][1][r] * sc, acc[i][2][r] * sc, acc[i][3][r] * sc);
+                        *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[i][4][r] * sc, acc[i][5][r] * sc, acc[i][6][r] * sc, acc[i][7][r] * sc);
+                    }
+                    continue;
+                }
+                // the quarter's largest magnitude: 8 accumulators, then the 16 lanes that share fq (DPP: two quad permutes, two row
+                // rotations -- no LDS round trip); a NaN row (NaN x anything: every column of the row is NaN) enters as +Inf
+                float m = fmaxf(fmaxf(fabsf(acc[i][0][r]), fabsf(acc[i][1][r])), fabsf(acc[i][2][r]));
+                m = fmaxf(fmaxf(m, fabsf(acc[i][3][r])), fabsf(acc[i][4][r]));
+                m = fmaxf(fmaxf(m, fabsf(acc[i][5][r])), fabsf(acc[i][6][r]));
+                m = fmaxf(m, fabsf(acc[i][7][r]));
+                m = (acc[i][0][r] != acc[i][0][r]) ? __uint_as_float(0x7f800000u) : m;
+                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0xb1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x4e, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x124, 0xf, 0xf, true)));   // row_ror:4
+                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x128, 0xf, 0xf, true)));   // row_ror:8
+                m *= sc;                                                     // (a power of two: the stored values are acc * sc)
+                // + 1 in the last place: a maximum with an all-ones mantissa would round up to 2^22 -- it takes the next exponent
+                unsigned E = (__float_as_uint(m) + 1u) >> 23;
+                E = E < 40u ? 40u : E;
+                // 2^(148 - E) * sc, kept finite (the clamp only acts when the quarter is all but zero: everything then rounds to 0)
+                const float s = fminf(__uint_as_float((275u - E) << 23) * sc, 0x1p126f);
+                unsigned t[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * EP + j * 16 + fl] = acc[i][j][r] * rinv[i][r];
-            gp_wave_sync();
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                int idx = t * 64 + lane;
-                int row = idx >> 5, c4 = idx & 31;
-                int grow = wm * 64 + i * 16 + row;
+                for (int j = 0; j < 8; ++j) t[j] = __float_as_uint(fmaf(acc[i][j][r], s, 12582912.f));
                 if (grow < cnt) {
-                    float4 v = *reinterpret_cast<const float4 *>(st + row * EP + c4 * 4);
-                    *reinterpret_cast<float4 *>(P + (int64_t)(base - pair_base + grow) * cout + n0 + wn * 128 + c4 * 4) = v;
+                    u32x4_a8 h;
+                    u32x2 l;
+                    h[0] = __builtin_amdgcn_perm(t[1], t[0], 0x04020100u);
+                    h[1] = __builtin_amdgcn_perm(t[2], t[1], 0x05040201u);
+                    h[2] = __builtin_amdgcn_perm(t[3], t[2], 0x06050402u);
+                    h[3] = __builtin_amdgcn_perm(t[5], t[4], 0x04020100u);
+                    l[0] = __builtin_amdgcn_perm(t[6], t[5], 0x05040201u);
+                    l[1] = __builtin_amdgcn_perm(t[7], t[6], 0x06050402u);
+                    unsigned char *dst = pb + ((unsigned)prow * (unsigned)cout + (unsigned)col) * 3u;     // (below 4 GiB: checked on the host)
+                    *reinterpret_cast<u32x4_a8 *>(dst) = h;
+                    *reinterpret_cast<u32x2 *>(dst + 16) = l;
+                    if (fl == 0) (pb + q_e_off)[(unsigned)prow * (unsigned)(cout >> 7) + (unsigned)(col >> 7)] = (unsigned char)E;
                 }
             }
-            gp_wave_sync();
         }
     }
+    stamp_out();
 }
 
 #define P1_PARAMS const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh, const int32_t *__restrict__ pair_in, \
                   const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg,  \
                   int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, \
                   int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base, const float *__restrict__ x_inv_scale,           \
-                  uint64_t *__restrict__ stamp
-#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp
+                  uint64_t *__restrict__ stamp, int64_t q_e_off
+#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp, q_e_off
 // the product kernel (tuning bits compiled out) and its twin with the bits of knob 3 live, under its own name in a trace
 // (bench.py's data-movement ceiling of the convolution and scripts/bench_conv.py's ablations launch the twin)
 __global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
@@ -719,6 +747,153 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         }
     }
     }   // rows of this wave
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 2 over 24-bit block-floating partial rows (the format of conv_phase1_dma_body's epilogue): a lane owns EIGHT consecutive
+// columns (c = lane * 8 + 512 it) = 24 bytes of a partial row (one 16-byte and one 8-byte load) plus the quarter's exponent byte
+// (one address per 16 lanes); an element is (u - 2^22) * 2^(E - 148), exact in fp32, and the sum runs in ASCENDING offset order as
+// before (bitwise reproducible).
+template <int NL>
+__device__ __forceinline__ void conv_gather_sum_q24(const unsigned char *__restrict__ pb, int64_t e_off, int mypos, int kv,
+                                                    int cout, int c, bool act, int pair_base, float (&a)[8]) {
+    typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    unsigned long long m = __ballot(mypos >= 0) & ((kv >= 64) ? ~0ull : ((1ull << kv) - 1ull));
+    const int nq = cout >> 7;
+    const unsigned char *pb_e = pb + e_off;
+    while (m) {
+        int kk[NL];
+        u32x4_a8 th[NL];
+        u32x2 tl[NL];
+        unsigned te[NL];
+        int cntv = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            if (m) { kk[i] = __builtin_ctzll(m); m &= m - 1; ++cntv; } else kk[i] = -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < cntv) {
+                // 32-bit byte offsets from uniform bases (the host checks that a chunk's rows stay below 4 GiB): one address register
+                // per load instead of two
+                const unsigned pos = (unsigned)(__shfl(mypos, kk[i], 64) - pair_base);
+                if (act) {
+                    const unsigned o = (pos * (unsigned)cout + (unsigned)c) * 3u;
+                    th[i] = *reinterpret_cast<const u32x4_a8 *>(pb + o);
+                    tl[i] = *reinterpret_cast<const u32x2 *>(pb + o + 16u);
+                    te[i] = pb_e[pos * (unsigned)nq + ((unsigned)c >> 7)];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < cntv && act) {
+                const float s = te[i] == 255u ? __uint_as_float(0x7fc00000u) : __uint_as_float((te[i] - 21u) << 23);   // 2^(E - 148)
+                const unsigned d[6] = {th[i][0], th[i][1], th[i][2], th[i][3], tl[i][0], tl[i][1]};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned u0 = __builtin_amdgcn_perm(0u, d[g * 3], 0x0c020100u);
+                    const unsigned u1 = __builtin_amdgcn_perm(d[g * 3 + 1], d[g * 3], 0x0c050403u);
+                    const unsigned u2 = __builtin_amdgcn_perm(d[g * 3 + 2], d[g * 3 + 1], 0x0c040302u);
+                    const unsigned u3 = __builtin_amdgcn_perm(0u, d[g * 3 + 2], 0x0c030201u);
+                    a[g * 4 + 0] = fmaf((float)u0 - 4194304.f, s, a[g * 4 + 0]);
+                    a[g * 4 + 1] = fmaf((float)u1 - 4194304.f, s, a[g * 4 + 1]);
+                    a[g * 4 + 2] = fmaf((float)u2 - 4194304.f, s, a[g * 4 + 2]);
+                    a[g * 4 + 3] = fmaf((float)u3 - 4194304.f, s, a[g * 4 + 3]);
+                }
+            }
+    }
+}
+
+template <bool WIDE /* cout > 512: a second register set for columns 512 .. */>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, const int32_t *__restrict__ pair_pos, int64_t nv,
+                       int kv, int cout, const float *__restrict__ scale, const float *__restrict__ shift,
+                       const float *__restrict__ residual, int64_t ld_res, int relu, float *__restrict__ y, int64_t ld_y,
+                       _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_yh, int64_t row_begin, int64_t row_count,
+                       int pair_base, float *__restrict__ y_inv_scale) {
+    // the row walk of conv_phase2_kernel: rows w, w + W, ... per wave, the next row's 27 positions loaded under this row's gathers
+    const int lane = gp_lane();
+    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t row_end = (row_begin + row_count < nv) ? row_begin + row_count : nv;
+    int64_t u = row_begin + wave0;
+    if (u >= row_end) return;
+    const bool rowscale = y_inv_scale && y_hi && cout <= 1024;
+    int mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    for (; u < row_end; u += n_waves) {
+        const int mypos = mypos_next;
+        if (u + n_waves < row_end) mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u + n_waves] : -1;
+        float av[WIDE ? 2 : 1][8];
+        float amax = 0.f;
+        // columns [0, 512) and [512, 1024) with static register sets (the row-scaled split needs the whole row before its first store);
+        // wider rows (no row scale: checked on the host) continue in the loop below
+        auto block = [&](int c0, float (&a)[8]) {
+            const int c = c0 + lane * 8;
+            const bool act = c < cout;
+            conv_gather_sum_q24<WIDE ? 4 : GS_NL>(pb, e_off, mypos, kv, cout, c, act, pair_base, a);   // (the wide form: fewer loads in flight, no spills)
+            if (!act) return;
+            float scv[8], shv[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c + h * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                scv[h * 4] = sc.x; scv[h * 4 + 1] = sc.y; scv[h * 4 + 2] = sc.z; scv[h * 4 + 3] = sc.w;
+                shv[h * 4] = sh.x; shv[h * 4 + 1] = sh.y; shv[h * 4 + 2] = sh.z; shv[h * 4 + 3] = sh.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = a[j] * scv[j] + shv[j];
+            if (residual) {
+                const float4 r0 = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
+                const float4 r1 = *reinterpret_cast<const float4 *>(residual + u * ld_res + c + 4);
+                a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j], 0.f);
+            }
+            if (y) {                                         // fp32 copy only where a later layer reads it (residual, linear)
+                *reinterpret_cast<float4 *>(y + u * ld_y + c) = make_float4(a[0], a[1], a[2], a[3]);
+                *reinterpret_cast<float4 *>(y + u * ld_y + c + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(a[j]));
+        };
+        auto split_store = [&](int c0, const float (&a)[8], float s) {
+            const int c = c0 + lane * 8;
+            if (c >= cout) return;
+            f16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = a[j] * s;
+                h[j] = (_Float16)v;
+                l[j] = (_Float16)(v - (float)h[j]);
+            }
+            *reinterpret_cast<f16x8 *>(y_hi + u * ld_yh + c) = h;
+            *reinterpret_cast<f16x8 *>(y_lo + u * ld_yh + c) = l;
+        };
+        block(0, av[0]);
+        if (!rowscale && y_hi) split_store(0, av[0], 1.f);
+        if constexpr (WIDE) {
+            block(512, av[1]);
+            if (!rowscale && y_hi) split_store(512, av[1], 1.f);
+        }
+        if (rowscale) {
+            // pre-split output with a per-row power of two: hi + lo = y * 2^e, the row's largest magnitude in [2^13, 2^14) (see
+            // conv_phase2_kernel); the next layer's phase 1 multiplies its partial rows by y_inv_scale[row] = 2^-e (exact)
+            amax = gp_wave_max(amax);
+            const float s = gp_pow2_for(amax);
+            if (lane == 0) y_inv_scale[u] = 1.f / s;
+            split_store(0, av[0], s);
+            if constexpr (WIDE) split_store(512, av[1], s);
+        } else if constexpr (WIDE) {
+            for (int c0 = 1024; c0 < cout; c0 += 512) {
+                block(c0, av[0]);
+                if (y_hi) split_store(c0, av[0], 1.f);
+            }
+        }
+    }
 }
 
 // fp32 rows -> hi/lo f16 rows with a power-of-two pre-scale: global (device scalar `scale`, from gp_pow2_scale) or per row
@@ -986,13 +1161,22 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         int pair_base = chunked ? chunk_pair_off_host[c] : 0;
         int64_t row_begin = chunked ? chunk_row_off_host[c] : 0;
         int64_t row_count = chunked ? chunk_row_off_host[c + 1] - row_begin : nv;
+        // the LDS-DMA path keeps the chunk's partial rows as 24-bit block floating point inside `partial` (sized for fp32 rows by
+        // the caller): three bytes per element, then one exponent byte per (row, 128 columns)
+        const int64_t chunk_pairs = chunked ? (int64_t)chunk_pair_off_host[c + 1] - pair_base : num_pairs;
+        const int64_t q_e_off = (chunk_pairs * cout * 3 + 15) & ~(int64_t)15;
+        const bool dma_path = x_hi && !(g_conv_ablate & 16);
+        const bool q24 = dma_path && !(g_conv_ablate & 32);   // tuning bit 5: the fp32 partial rows of rounds 1-4, same kernels otherwise
+        GP_CHECK_ARG(!q24 || chunk_pairs * cout * 3 + 32 < ((int64_t)1 << 32),
+                     "gp_sparse_conv_f16x3: %lld pairs x %d columns in one chunk: the 24-bit partial rows must stay below 4 GiB (use chunks)",
+                     (long long)chunk_pairs, cout);
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
             const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
-                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp
-            if (x_hi && !(g_conv_ablate & 16)) {
+                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off
+            if (dma_path) {
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
                              g_gp_debug_bytes[1], (size_t)nblocks * 10 * sizeof(uint64_t));
@@ -1011,10 +1195,20 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
 #undef P1_ARGS
         }
         // one resident round: 6 workgroups of 4 waves per CU (80 registers per lane); GP_CONV_P2_WG_PER_CU for the sweep
-        const int64_t p2_full = (row_count * 64 + 255) / 256, p2_res = (int64_t)gp_cu_count() * p2_wg_per_cu;
-        conv_phase2_kernel<<<(unsigned)((p2_res > 0 && p2_res < p2_full) ? p2_res : p2_full), 256, 0, s>>>(
-            partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
-            static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale);
+        const int64_t p2_full = (row_count * 64 + 255) / 256;
+        int64_t p2_res = (int64_t)gp_cu_count() * p2_wg_per_cu;
+        // (the 24-bit kernel: 4 waves per SIMD at 128 registers -- 4 workgroups per CU are one resident round)
+        if (q24 && p2_wg_per_cu == 6) p2_res = (int64_t)gp_cu_count() * 4;
+        const unsigned p2_grid = (unsigned)((p2_res > 0 && p2_res < p2_full) ? p2_res : p2_full);
+#define P2Q_ARGS reinterpret_cast<const unsigned char *>(partial), q_e_off, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, \
+                 relu, y, ld_y, static_cast<_Float16 *>(y_hi), static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale
+        if (q24 && cout > 512) conv_phase2_q24_kernel<true><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
+        else if (q24) conv_phase2_q24_kernel<false><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
+#undef P2Q_ARGS
+        else
+            conv_phase2_kernel<<<p2_grid, 256, 0, s>>>(
+                partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
+                static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale);
     }
     GP_CHECK_LAUNCH();
     return GP_OK;
