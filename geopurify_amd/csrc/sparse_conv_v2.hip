@@ -527,7 +527,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     // f16 hi + lo at 2^-22 of the row's maximum).  E = 255 marks a quarter with an Inf or a NaN activation row (phase 2 writes NaN).
     unsigned char *pb = reinterpret_cast<unsigned char *>(P);
     const bool as_f32 = TUNE && (ablate & 32);               // tuning twin: the fp32 rows of rounds 1-4 (host pairs them with conv_phase2_kernel)
-    typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 24-byte lane records: 8-byte aligned
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -546,28 +546,35 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                     }
                     continue;
                 }
-                // the quarter's largest magnitude: 8 accumulators, then the 16 lanes that share fq (DPP: two quad permutes, two row
-                // rotations -- no LDS round trip); a NaN row (NaN x anything: every column of the row is NaN) enters as +Inf
+                // the quarter's largest magnitude: 8 accumulators, then the 16 lanes that share fq -- as BIT PATTERNS (non-negative floats
+                // order like unsigned integers), so that each step is one v_max_u32 with a DPP operand (two quad permutes, two row
+                // rotations; no LDS round trip, no canonicalising moves); a NaN row (NaN x anything: every column of the row is NaN)
+                // enters as +Inf
                 float m = fmaxf(fmaxf(fabsf(acc[i][0][r]), fabsf(acc[i][1][r])), fabsf(acc[i][2][r]));
                 m = fmaxf(fmaxf(m, fabsf(acc[i][3][r])), fabsf(acc[i][4][r]));
                 m = fmaxf(fmaxf(m, fabsf(acc[i][5][r])), fabsf(acc[i][6][r]));
                 m = fmaxf(m, fabsf(acc[i][7][r]));
-                m = (acc[i][0][r] != acc[i][0][r]) ? __uint_as_float(0x7f800000u) : m;
-                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0xb1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
-                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x4e, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
-                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x124, 0xf, 0xf, true)));   // row_ror:4
-                m = fmaxf(m, __uint_as_float(__builtin_amdgcn_mov_dpp((int)__float_as_uint(m), 0x128, 0xf, 0xf, true)));   // row_ror:8
-                m *= sc;                                                     // (a power of two: the stored values are acc * sc)
-                // + 1 in the last place: a maximum with an all-ones mantissa would round up to 2^22 -- it takes the next exponent
-                unsigned E = (__float_as_uint(m) + 1u) >> 23;
-                E = E < 40u ? 40u : E;
-                // 2^(148 - E) * sc, kept finite (the clamp only acts when the quarter is all but zero: everything then rounds to 0)
-                const float s = fminf(__uint_as_float((275u - E) << 23) * sc, 0x1p126f);
+                unsigned mi = (acc[i][0][r] != acc[i][0][r]) ? 0x7f800000u : __float_as_uint(m);
+                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0xb1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0x4e, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0x124, 0xf, 0xf, true));    // row_ror:4
+                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0x128, 0xf, 0xf, true));    // row_ror:8
+                // exponent field of the raw maximum; + 1 in the last place first: a maximum with an all-ones mantissa would round up
+                // to 2^22 -- it takes the next exponent.  The accumulators are multiplied by 2^(148 - Em) (field 275 - Em, kept a
+                // finite float: below 2^-106 everything rounds to 0 anyway); the STORED exponent carries the row's 2^e(sc) as well:
+                // decoded value = (u - 2^22) 2^(E - 148) = acc * sc.  E outside [22, 254]: the value is below 2^-104 (kept, scaled
+                // wrongly by a power of two: it is nothing) or beyond fp32 (E = 255: phase 2 writes NaN where fp32 had Inf)
+                const unsigned Em = (mi + 1u) >> 23;
+                const unsigned fld = 275u - Em;
+                const float s = __uint_as_float((fld > 254u ? 254u : fld) << 23);
+                int Es = (int)Em + ((int)(__float_as_uint(sc) >> 23) - 127);
+                Es = Es < 22 ? 22 : Es;
+                const unsigned E = (Em == 255u || Es > 254) ? 255u : (unsigned)Es;
                 unsigned t[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t[j] = __float_as_uint(fmaf(acc[i][j][r], s, 12582912.f));
                 if (grow < cnt) {
-                    u32x4_a8 h;
+                    u32x4 h;
                     u32x2 l;
                     h[0] = __builtin_amdgcn_perm(t[1], t[0], 0x04020100u);
                     h[1] = __builtin_amdgcn_perm(t[2], t[1], 0x05040201u);
@@ -575,9 +582,11 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                     h[3] = __builtin_amdgcn_perm(t[5], t[4], 0x04020100u);
                     l[0] = __builtin_amdgcn_perm(t[6], t[5], 0x05040201u);
                     l[1] = __builtin_amdgcn_perm(t[7], t[6], 0x06050402u);
-                    unsigned char *dst = pb + ((unsigned)prow * (unsigned)cout + (unsigned)col) * 3u;     // (below 4 GiB: checked on the host)
-                    *reinterpret_cast<u32x4_a8 *>(dst) = h;
-                    *reinterpret_cast<u32x2 *>(dst + 16) = l;
+                    // a quarter's 384 bytes: the 16 lanes' first 16 bytes (elements 0-4 and a third of 5), then their last 8 --
+                    // every store naturally aligned, 256- and 128-byte runs (below 4 GiB: checked on the host)
+                    unsigned char *dst = pb + ((unsigned)prow * (unsigned)cout + (unsigned)(col & ~127)) * 3u;
+                    *reinterpret_cast<u32x4 *>(dst + fl * 16) = h;
+                    *reinterpret_cast<u32x2 *>(dst + 256 + fl * 8) = l;
                     if (fl == 0) (pb + q_e_off)[(unsigned)prow * (unsigned)(cout >> 7) + (unsigned)(col >> 7)] = (unsigned char)E;
                 }
             }
@@ -751,13 +760,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 
 // ------------------------------------------------------------------------------------------------
 // phase 2 over 24-bit block-floating partial rows (the format of conv_phase1_dma_body's epilogue): a lane owns EIGHT consecutive
-// columns (c = lane * 8 + 512 it) = 24 bytes of a partial row (one 16-byte and one 8-byte load) plus the quarter's exponent byte
-// (one address per 16 lanes); an element is (u - 2^22) * 2^(E - 148), exact in fp32, and the sum runs in ASCENDING offset order as
+// columns (c = lane * 8 + 512 it) = 24 bytes of a partial row (a quarter's 384 bytes hold its 16 lanes' first 16 bytes, then their
+// last 8: one aligned 16-byte and one 8-byte load) plus the quarter's exponent byte (one address per 16 lanes); an element is (u - 2^22) * 2^(E - 148), exact in fp32, and the sum runs in ASCENDING offset order as
 // before (bitwise reproducible).
 template <int NL>
 __device__ __forceinline__ void conv_gather_sum_q24(const unsigned char *__restrict__ pb, int64_t e_off, int mypos, int kv,
                                                     int cout, int c, bool act, int pair_base, float (&a)[8]) {
-    typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
@@ -766,7 +775,7 @@ __device__ __forceinline__ void conv_gather_sum_q24(const unsigned char *__restr
     const unsigned char *pb_e = pb + e_off;
     while (m) {
         int kk[NL];
-        u32x4_a8 th[NL];
+        u32x4 th[NL];
         u32x2 tl[NL];
         unsigned te[NL];
         int cntv = 0;
@@ -781,9 +790,9 @@ __device__ __forceinline__ void conv_gather_sum_q24(const unsigned char *__restr
                 // per load instead of two
                 const unsigned pos = (unsigned)(__shfl(mypos, kk[i], 64) - pair_base);
                 if (act) {
-                    const unsigned o = (pos * (unsigned)cout + (unsigned)c) * 3u;
-                    th[i] = *reinterpret_cast<const u32x4_a8 *>(pb + o);
-                    tl[i] = *reinterpret_cast<const u32x2 *>(pb + o + 16u);
+                    const unsigned o = (pos * (unsigned)cout + ((unsigned)c & ~127u)) * 3u, f = ((unsigned)c >> 3) & 15u;   // quarter, lane in it
+                    th[i] = *reinterpret_cast<const u32x4 *>(pb + o + f * 16u);
+                    tl[i] = *reinterpret_cast<const u32x2 *>(pb + o + 256u + f * 8u);
                     te[i] = pb_e[pos * (unsigned)nq + ((unsigned)c >> 7)];
                 }
             }

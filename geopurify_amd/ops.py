@@ -224,7 +224,9 @@ class ConvPairs:
         return cp
 
 
-# phase-1 tiles per chunk launch of the balanced chunking: None = two rounds of one-tile workgroups = 2 x the CU count (512 on MI355X)
+# phase-1 tiles per chunk launch of the balanced chunking: None = three rounds of one-tile workgroups less 16 = 3 x the CU count - 16
+# (752 on MI355X).  Rounds 3-4, fp32 partial rows: two rounds (512; 768 was slower -- 200 MB of partial rows per chunk).  Round 5, 24-bit
+# partial rows (150 MB per 768 tiles): 752 / 768 beat 512 by 1.1 % of the scene, 640 (2.5 rounds) loses 4 %, 1024 is 0.5 % behind 768
 CONV_TARGET_TILES = int(os.environ["GP_CONV_TARGET_TILES"]) if os.environ.get("GP_CONV_TARGET_TILES") else None
 
 
@@ -232,7 +234,7 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
     """nbr_map i32 [27,nv] -> ConvPairs.  Pairs are ordered chunk-major and phase 1 / phase 2 run chunk by chunk, so the partial
     buffer only holds one chunk.  chunk_rows:
       "balanced" (default): chunk heights chosen on the device from the kernel map (gp_conv_chunk_plan) so that every chunk's
-          phase-1 launch is at most 2 x CUs tiles = two full rounds of workgroups (col_tiles = cout / 256 column tiles
+          phase-1 launch is at most 3 x CUs - 16 tiles = three rounds of workgroups (col_tiles = cout / 256 column tiles
           per row tile); two host syncs (the plan, the pair bounds);
       an int: equal heights.  Round 4 on the S scene (profiles/r04_conv_launch_groups.log), per 512->512 layer: 8192 rows (17
           launches, 128 MB of partial rows -- inside the Infinity Cache) 1.87 ms, 16384 rows (250 MB) 1.96 ms, 4096 rows 2.65 ms;
@@ -251,7 +253,7 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
         max_chunks = (nv + granule - 1) // granule
         plan = torch.empty(max_chunks + 2, dtype=torch.int32, device=dev)          # [0 .. max_chunks]: row offsets, [-1]: count
         ws = _ws(lib.gp_conv_chunk_plan_workspace_bytes(nv, granule), dev)
-        target = CONV_TARGET_TILES or 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+        target = CONV_TARGET_TILES or 3 * torch.cuda.get_device_properties(dev).multi_processor_count - 16
         check(lib.gp_conv_chunk_plan(_ptr(nbr_map), nv, kv, granule, int(col_tiles), int(target), max_chunks, _ptr(plan),
                                      _ptr(plan[max_chunks + 1:]), _ptr(ws), ws.numel(), _stream()), "gp_conv_chunk_plan")
         host = plan.cpu().tolist()                                                   # host sync 1 of 2
