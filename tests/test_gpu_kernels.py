@@ -748,6 +748,55 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
         assert torch.equal(yg, y2), g
 
 
+def test_sparse_conv_f16x3_wide_rows_row_scales_and_non_finite_rows(ops):
+    """The 24-bit partial rows at their edges: 1024 output columns (the second register set of phase 2), the row-scaled split output,
+    rows of very different magnitudes (the block exponent is per pair row and 128 columns: a 1e-6 row next to a 1e+3 row keeps ITS
+    relative accuracy), an all-zero row, and non-finite activations: an Inf or NaN input row makes exactly the output rows that
+    gather it non-finite (fp32 partial rows: the same rows) and leaves every other row's bits alone."""
+    rng = np.random.default_rng(5)
+    c = surface_voxels(rng, 1500)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    nm = ops.kernel_map_build(grid, cs)
+    pairs = ops.conv_pairs_build(nm, 512)
+    nmc = nm.cpu().numpy()
+    Nv = len(c)
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(Nv, 64, generator=g) * torch.exp(torch.randn(Nv, 1, generator=g) * 4.0)      # row magnitudes over ~7 decades
+    X[11] = 0.0
+    W = torch.randn(27, 64, 1024, generator=g) * 0.05
+    p2 = 2.0 ** int(np.floor(np.log2(2.0 / float(W.abs().max()))))
+    hi, lo = ops.conv_weights_split(dev(W), p2)
+    sc = torch.full((1024,), 1.0 / p2)
+    xh, xl, inv = ops.split_f16(dev(X), per_row=True)
+    ys = tuple(torch.empty((Nv, 1024), dtype=torch.float16, device="cuda") for _ in range(2))
+    yinv = torch.empty(Nv, device="cuda")
+    y = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc), None, x_split=(xh, xl), x_row_inv=inv, out_split=ys, out_row_inv=yinv)
+    ref = o_student.sparse_conv3(X.double(), nmc.astype(np.int64), W.double())
+    # per output row: error against the row's own scale (the largest partial sum that enters it is bounded by the row's gathered inputs)
+    gathered = torch.zeros(Nv, dtype=torch.float64)
+    Xmax = X.abs().max(dim=1).values.double()
+    for k in range(27):
+        u = np.where(nmc[k] >= 0)[0]
+        gathered[u] = torch.maximum(gathered[u], Xmax[nmc[k][u]])
+    err = (y.cpu().double() - ref).abs().max(dim=1).values
+    bound = 2e-5 * gathered * float(W.abs().max()) * 64 ** 0.5 + 1e-30
+    assert bool((err <= bound).all()), float((err / bound).max())
+    back = (ys[0].float() + ys[1].float()) * yinv[:, None]
+    assert (back - y).abs().max(dim=1).values.le(2e-6 * y.abs().max(dim=1).values + 1e-30).all()
+    # non-finite rows
+    for bad in (float("inf"), float("nan")):
+        Xb = X.clone()
+        Xb[700, 5] = bad
+        bh, bl, invb = ops.split_f16(dev(Xb), per_row=True)
+        yb = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc), None, x_split=(bh, bl), x_row_inv=invb)
+        hit = np.zeros(Nv, dtype=bool)
+        for k in range(27):
+            hit |= nmc[k] == 700
+        fin = torch.isfinite(yb).all(dim=1).cpu().numpy()
+        assert not fin[hit].any() and fin[~hit].all(), (bad, int(hit.sum()), int((~fin).sum()))
+        assert torch.equal(yb[torch.from_numpy(~hit).cuda()], y[torch.from_numpy(~hit).cuda()])
+
+
 def test_embed_head_f16x3_matches_fp64_and_the_fp32_kernel(ops):
     """The student's 1x1x1 output layer + F.normalize in one kernel on pre-split rows (affinity_module.py:66,71,1547): fp32-class
     accuracy against fp64, the error class of the exact-fp32 kernel + l2norm_rows_ it replaces; ragged row count, an all-zero row
