@@ -127,7 +127,12 @@ int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t
 /* each segment).  The chunks are given by their row offsets chunk_row_off (DEVICE i32 [num_chunks+1], */
 /* 0 = first, nv = last, ascending): equal heights, or the heights of gp_conv_chunk_plan.              */
 /* gp_conv_weights_split: w fp32 [kv,cin,cout] -> w_hi/w_lo f16 [kv,cout,cin] of scale_pow2 * w.       */
-/* gp_sparse_conv_f16x3: partial fp32 [num_pairs,cout] workspace; epilogue as gp_sparse_conv (the     */
+/* gp_sparse_conv_f16x3: `partial` = 4 * num_pairs * cout bytes of workspace (the largest chunk's pairs */
+/* when chunked) for the partial rows between the two phases -- fp32 rows on the register-staged path   */
+/* (x fp32), 24-bit block floating point on the LDS-DMA path (x_hi / x_lo; 3 bytes per element + one    */
+/* exponent byte per (pair row, 128 columns): rounded at 2^-23 of the quarter's largest magnitude, half */
+/* of the rounding of the f16 hi + lo split that follows; an Inf / NaN activation row makes the output   */
+/* rows that gather it NaN); its contents are private to the call.  Epilogue as gp_sparse_conv (the     */
 /* caller folds 1/scale_pow2 into `scale`).  cin % 32 == 0, cout % 256 == 0, |x| < 65504.              */
 size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv);
 int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t num_chunks, const int32_t *chunk_row_off,
@@ -135,8 +140,8 @@ int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t 
                         int32_t *tile_desc /* i32 [num_pairs/256 + nseg, 4]: {k, first pair, count, 0} per tile */,
                         void *workspace, size_t workspace_bytes, void *stream);
 /* Chunk heights chosen from the kernel map so that every chunk's phase-1 launch -- sum over the offsets of ceil(pairs / 256)  */
-/* row tiles, times col_tiles (= cout / 256) column tiles -- stays within target_tiles (2 x the CU count = two rounds of        */
-/* one-tile workgroups; equal heights leave 4-8 % of the tile slots of their rounds empty).  Chunks close at multiples of        */
+/* row tiles, times col_tiles (= cout / 256) column tiles -- stays within target_tiles (the host passes 3 x the CU count - 16:   */
+/* three rounds of one-tile workgroups; equal heights leave 4-8 % of the tile slots of their rounds empty).  Chunks close at multiples of        */
 /* granule_rows (>= 64).  Outputs on the DEVICE: chunk_row_off i32 [max_chunks + 1], n_chunks i32 [1]; the caller reads them      */
 /* back to size the pair arrays and to pass the host copy to gp_sparse_conv_f16x3.                                               */
 size_t gp_conv_chunk_plan_workspace_bytes(int64_t nv, int32_t granule_rows);
