@@ -100,7 +100,7 @@ def conv_roofline(timer):
         return None
     ms, flop = r
     issued = 3.0 * flop / (ms * 1e-3) / 1e12
-    return {"kernel": "conv_phase1_dma_kernel + conv_phase2_kernel (one 512->512 layer)", "bound": "mfma",
+    return {"kernel": "conv_phase1_dma_kernel + conv_phase2_q24_kernel (one 512->512 layer)", "bound": "mfma",
             "achieved": round(issued, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / MFMA_F16_PEAK_TFLOPS, 4),
             "algorithmic_tflops": round(flop / (ms * 1e-3) / 1e12, 1), "algorithmic_flop_per_layer": flop,
             "avg_layer_ms": round(ms, 4)}

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/grbm -o c --output-format csv -- $B > $O/grbm.json 2> $O/grbm.log
 python3 $R/scripts/pmc_summarize.py $O cs_pool_kernel > $O/pool_pmc_summary.json
 python3 $R/scripts/pmc_summarize.py $O conv_phase > $O/conv_pmc_summary.json
-python3 $R/scripts/pmc_conv_layer.py $O/conv_pmc_summary.json > $O/conv_pmc_per_layer.json
+python3 $R/scripts/pmc_conv_layer.py $O/conv_pmc_summary.json $O/fetch.json > $O/conv_pmc_per_layer.json
 python3 $R/scripts/pmc_summarize.py $O affinity_cs_kernel affinity_block_kernel knn_ring_kernel lift_masks_views_kernel lv_sort_scores_kernel cs_fill_kernel \
         cs_count_kernel transpose_views_kernel nn_grid_query_wave_kernel embed_head_kernel classify16 scatter_mean fuse_top3 > $O/small_pmc_summary.json
 # keep the summaries only: per-dispatch traces and counter dumps are tens of MiB (gpurun_out/ is capped at 64 MiB)
