@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where is the GPU idle, per queue, in a rocprofv3 --kernel-trace of bench.py?  Reads *_kernel_trace.csv, keeps the last
-`--scenes` scenes (a scene = from one affinity_block_kernel to the next), and prints per queue: busy time, idle time, and the
+`--scenes` scenes (a scene = from one affinity kernel to the next), and prints per queue: busy time, idle time, and the
 largest idle gaps with the kernels on either side.  usage: trace_gaps.py <dir> [--scenes 4]"""
 import csv
 import glob
@@ -26,7 +26,7 @@ def short(n):
     return n.split("(")[0][:40]
 
 
-marks = [s for s, e, q, n in rows if "affinity_block_kernel" in n]
+marks = [s for s, e, q, n in rows if "affinity_block_kernel" in n or "affinity_cs_kernelILb0" in n]
 if len(marks) < nsc + 2:
     sys.exit("too few scenes in the trace")
 t0, t1 = marks[-nsc - 1], marks[-1]
