@@ -475,7 +475,10 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
         cs_glds16<AUX>(x_hi + s0, dst + (4 * wv) * CS_RB);
         cs_glds16<AUX>(x_lo + s0, dst + CS_PLANE + (4 * wv) * CS_RB);
         cs_glds16<AUX>(x_hi + s1, dst + (4 * wv) * CS_RB + 1024);
-        cs_glds16<AUX>(x_lo + s1, dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
+        // tuning bit 7: what would an 8-BIT lo plane buy?  Half of the lo rows come from the hot piece (the bytes of the gather as they
+        // would be; one instruction more than the real thing would issue), and the epilogue stores half of its lo bytes -- a price, not
+        // a result
+        cs_glds16<AUX>(x_lo + ((ablate & 128) ? 0 : s1), dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
         // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line)
         const int lo = (((mk >> wv) & 1u) && !hot_w) ? lane * 8 : 0;
         cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
@@ -661,7 +664,12 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
                         cs_st16_sc1(y_lo + grow * ld_y + colw + ec, l);
                     } else {
                         *reinterpret_cast<f16x8 *>(y_hi + grow * ld_y + colw + ec) = h;
-                        *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + colw + ec) = l;
+                        if (ablate & 128) {
+                            typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+                            *reinterpret_cast<f16x4_ *>(y_lo + grow * ld_y + colw + (ec >> 1)) = f16x4_{l[0], l[1], l[2], l[3]};   // 8 of the 16 bytes, packed
+                        } else {
+                            *reinterpret_cast<f16x8 *>(y_lo + grow * ld_y + colw + ec) = l;
+                        }
                     }
                 }
                 if (y_f32) {

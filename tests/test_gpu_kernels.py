@@ -570,7 +570,7 @@ def test_error_paths(ops):
     # tuning knobs: an undefined mask is rejected, a stamp buffer that is too small is rejected at the launch
     from geopurify_amd import _lib
     lib = _lib.load()
-    assert lib.gp_debug_set(4, 128) == -22 and lib.gp_debug_set(11, 8) == -22 and lib.gp_debug_set(8, 32) == -22 and lib.gp_debug_set(16, 0) == -22
+    assert lib.gp_debug_set(4, 1024) == -22 and lib.gp_debug_set(11, 8) == -22 and lib.gp_debug_set(8, 32) == -22 and lib.gp_debug_set(16, 0) == -22
     opm = ops.pool_mfma_build(nb2, w2, 64)
     xs2 = ops.split_f16(torch.randn(200, 512, device="cuda"), 512)
     ys2 = tuple(torch.empty((200, 512), dtype=torch.float16, device="cuda") for _ in range(2))
