@@ -421,10 +421,12 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;         // logical 8-half slot this lane fetches
     const int64_t da = x_lo - x_hi, db = w_lo - w_hi;                         // (in halfs)
     const _Float16 *ga_hi[NI], *gb_hi[NI];
+    int in_rows[NI];
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
         int row = (issuer ? wv : 0) * RPW + t * 16 + lrow;
         int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];              // clamped, unconditional: both loads overlap
+        in_rows[t] = in_row;
         ga_hi[t] = x_hi + (int64_t)in_row * ld_xh + q;
         // LDS row j * 16 + f of a wave's 128 weight rows (column tile j, MFMA column f) holds OUTPUT COLUMN f * 8 + j: a lane's eight
         // accumulators of a row are then eight consecutive columns of the partial row (one 16-byte and one 8-byte store per row in
@@ -459,19 +461,19 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     const int steps = cin / TK;
     issue(0, 0);
     // per-row power-of-two scales of the pre-split operand (x_hi + x_lo = x * 2^e(row), gp_split_f16_scaled): the partial
-    // row of a pair is multiplied back by 2^-e(input row).  Used in the epilogue only: the two dependent gathers (row id, then
-    // its scale; 16 rows per lane) are issued AFTER the first stage's DMA so that they ride behind it instead of holding the
-    // first DMA back (vector memory operations complete in order: round 4 stamps, prologue 12.0k cycles of a 92k-cycle tile).
-    float rinv[4][4];
+    // row of a pair is multiplied back by 2^-e(input row).  Used in the epilogue only, and there as 16 values per lane: the lanes
+    // that already hold a staged row's input id (four per row: one stores) fetch its scale -- ONE dependent load per lane, issued
+    // behind the first stage's DMA -- and park it in LDS behind the ring; the epilogue reads its 16 from there.  (Rounds 4-5 gathered
+    // row id + scale per lane and (i, r): 32 loads per lane in front of the second stage's DMA, 16 registers live through the loop.)
+    float *s_rinv = reinterpret_cast<float *>(smem_raw + sizeof(V2Smem));
     {
-        const int wm_ = wv >> 1, fq_ = lane >> 4;
+        float rv[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < NI; ++t) rv[t] = x_inv_scale ? x_inv_scale[in_rows[t]] : 1.f;
+        if (lp == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = wm_ * 64 + i * 16 + fq_ * 4 + r;
-                rinv[i][r] = x_inv_scale ? x_inv_scale[pair_in[base + (grow < cnt ? grow : cnt - 1)]] : 1.f;
-            }
+            for (int t = 0; t < NI; ++t) s_rinv[wv * RPW + t * 16 + lrow] = rv[t];
+        }
     }
     __syncthreads();
     if constexpr (STAMP) st_pro = cv_now();
@@ -535,7 +537,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int grow = wm * 64 + i * 16 + fq * 4 + r;
-                const float sc = rinv[i][r];
+                const float sc = s_rinv[grow];
                 const int64_t prow = base - pair_base + grow;
                 const int col = n0 + wn * 128 + fl * 8;
                 if (as_f32) {
@@ -1121,9 +1123,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_CHECK_ARG(x_hi || (ld_x % 4 == 0 && (uintptr_t)x % 16 == 0), "gp_sparse_conv_f16x3: x rows must be 16-byte aligned");
     GP_SMEM_ATTR(conv_phase1_kernel<false>, sizeof(V2Smem));
     GP_SMEM_ATTR(conv_phase1_kernel<true>, sizeof(V2Smem));
-    GP_SMEM_ATTR(conv_phase1_dma_kernel, sizeof(V2Smem));
-    GP_SMEM_ATTR(conv_phase1_tuning_kernel, sizeof(V2Smem));
-    GP_SMEM_ATTR(conv_phase1_stamp_kernel, sizeof(V2Smem));
+    constexpr size_t P1_DMA_SMEM = sizeof(V2Smem) + TM * sizeof(float);     // the ring + the tile's 256 row scales
+    GP_SMEM_ATTR(conv_phase1_dma_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_tuning_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_stamp_kernel, P1_DMA_SMEM);
 
     // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
     // blockIdx * 8 (a chunk overwrites the previous one's: the last chunk of the last call stays)
@@ -1189,9 +1192,9 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
                              g_gp_debug_bytes[1], (size_t)nblocks * 10 * sizeof(uint64_t));
-                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
-                else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
-                else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1_ARGS);
+                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
             } else {
                 GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
                 GP_CHECK_ARG(!x_row_inv_scale, "gp_sparse_conv_f16x3: the register-staged path splits unscaled fp32 rows");
