@@ -833,6 +833,19 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
     if (u >= row_end) return;
     const bool rowscale = y_inv_scale && y_hi && cout <= 1024;
     int mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    // the affine epilogue's scale / shift of this lane's first eight columns: the same for every row of the walk -- loaded once
+    // (in the loop they were 4 KiB of L1 requests per output row beside the row's 11 KiB of partial rows)
+    float sc0[8], sh0[8];
+    {
+        const int c = lane * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = (scale && c < cout) ? *reinterpret_cast<const float4 *>(scale + c + h * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 b = (shift && c < cout) ? *reinterpret_cast<const float4 *>(shift + c + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sc0[h * 4] = a.x; sc0[h * 4 + 1] = a.y; sc0[h * 4 + 2] = a.z; sc0[h * 4 + 3] = a.w;
+            sh0[h * 4] = b.x; sh0[h * 4 + 1] = b.y; sh0[h * 4 + 2] = b.z; sh0[h * 4 + 3] = b.w;
+        }
+    }
     for (; u < row_end; u += n_waves) {
         const int mypos = mypos_next;
         if (u + n_waves < row_end) mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u + n_waves] : -1;
@@ -845,16 +858,21 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
             const bool act = c < cout;
             conv_gather_sum_q24<WIDE ? 4 : GS_NL>(pb, e_off, mypos, kv, cout, c, act, pair_base, a);   // (the wide form: fewer loads in flight, no spills)
             if (!act) return;
-            float scv[8], shv[8];
+            if (c0 == 0) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c + h * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-                const float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                scv[h * 4] = sc.x; scv[h * 4 + 1] = sc.y; scv[h * 4 + 2] = sc.z; scv[h * 4 + 3] = sc.w;
-                shv[h * 4] = sh.x; shv[h * 4 + 1] = sh.y; shv[h * 4 + 2] = sh.z; shv[h * 4 + 3] = sh.w;
+                for (int j = 0; j < 8; ++j) a[j] = a[j] * sc0[j] + sh0[j];
+            } else {
+                float scv[8], shv[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 sc = scale ? *reinterpret_cast<const float4 *>(scale + c + h * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    const float4 sh = shift ? *reinterpret_cast<const float4 *>(shift + c + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    scv[h * 4] = sc.x; scv[h * 4 + 1] = sc.y; scv[h * 4 + 2] = sc.z; scv[h * 4 + 3] = sc.w;
+                    shv[h * 4] = sh.x; shv[h * 4 + 1] = sh.y; shv[h * 4 + 2] = sh.z; shv[h * 4 + 3] = sh.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = a[j] * scv[j] + shv[j];
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = a[j] * scv[j] + shv[j];
             if (residual) {
                 const float4 r0 = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
                 const float4 r1 = *reinterpret_cast<const float4 *>(residual + u * ld_res + c + 4);
