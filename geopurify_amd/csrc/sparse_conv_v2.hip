@@ -524,9 +524,9 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     // the quarter -- 3 + 1/128 bytes instead of 4 per element of the round trip phase 1 -> Infinity Cache -> phase 2 (2 x 2.0 GB per
     // 512 -> 512 layer in fp32).  Encoding costs ONE fused multiply-add per element: t = fma(acc, s, 1.5 * 2^23) lies in [2^23, 2^24),
     // where floats are the integers, so the hardware's round-to-nearest-even IS the quantisation and the three low bytes of t's bit
-    // pattern ARE u; eight elements = 24 bytes per lane, packed by six byte permutes.  The rounding is <= 2^-23 of the quarter's
-    // largest magnitude per partial row -- half of what the NEXT rounding on the path already is (phase 2 splits the summed row into
-    // f16 hi + lo at 2^-22 of the row's maximum).  E = 255 marks a quarter with an Inf or a NaN activation row (phase 2 writes NaN).
+    // pattern ARE u; eight elements = 24 bytes per lane, packed by six byte permutes.  The rounding is half a unit of 2^(E - 148): between
+    // 2^-23 and 2^-22 of the quarter's largest magnitude per partial row -- no more than the NEXT rounding on the path (phase 2 splits
+    // the summed row into f16 hi + lo at 2^-22 of the row's maximum).  E = 255 marks a quarter with an Inf or a NaN activation row (phase 2 writes NaN).
     unsigned char *pb = reinterpret_cast<unsigned char *>(P);
     const bool as_f32 = TUNE && (ablate & 32);               // tuning twin: the fp32 rows of rounds 1-4 (host pairs them with conv_phase2_kernel)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -130,8 +130,8 @@ int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t
 /* gp_sparse_conv_f16x3: `partial` = 4 * num_pairs * cout bytes of workspace (the largest chunk's pairs */
 /* when chunked) for the partial rows between the two phases -- fp32 rows on the register-staged path   */
 /* (x fp32), 24-bit block floating point on the LDS-DMA path (x_hi / x_lo; 3 bytes per element + one    */
-/* exponent byte per (pair row, 128 columns): rounded at 2^-23 of the quarter's largest magnitude, half */
-/* of the rounding of the f16 hi + lo split that follows; an Inf / NaN activation row makes the output   */
+/* exponent byte per (pair row, 128 columns): rounded within 2^-22 of the quarter's largest magnitude,   */
+/* the rounding of the f16 hi + lo split that follows; an Inf / NaN activation row makes the output      */
 /* rows that gather it NaN); its contents are private to the call.  Epilogue as gp_sparse_conv (the     */
 /* caller folds 1/scale_pow2 into `scale`).  cin % 32 == 0, cout % 256 == 0, |x| < 65504.              */
 size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv);

@@ -185,7 +185,7 @@ def test_conv_paths_agree_full_size(big):
     b = ops.sparse_conv(X, nm, W)
     assert (a - b).abs().max() < 2e-5 * max(1.0, float(b.abs().max()))               # f16x3 == exact fp32 MFMA
     xs = ops.split_f16(X)
-    # the LDS-DMA path keeps its partial rows as 24-bit block floating point (<= 2^-23 of a 128-column quarter's largest magnitude per
+    # the LDS-DMA path keeps its partial rows as 24-bit block floating point (within 2^-22 of a 128-column quarter's largest magnitude per
     # partial row, <= 27 partial rows per output row); with the fp32 rows of the tuning twin (knob 3, bit 5) it is the register
     # path's arithmetic bit for bit
     c = ops.sparse_conv_f16x3(None, pairs, hi, lo, sc, None, x_split=xs)
@@ -198,7 +198,7 @@ def test_conv_paths_agree_full_size(big):
         assert lib.gp_debug_set(3, 0) == 0
     assert torch.equal(a, c32)                                                        # register path == LDS-DMA path (fp32 partial rows)
     pmax = float((b.abs().max() * 32.0))                                              # (partial rows carry the weights' 2^5)
-    assert (c - a).abs().max().item() <= 27 * 2.0 ** -23 * pmax / 32.0
+    assert (c - a).abs().max().item() <= 27 * 2.0 ** -22 * pmax / 32.0
     assert (c - b).abs().max() < 2e-5 * max(1.0, float(b.abs().max()))
     one = ops.conv_pairs_build(nm, None)
     d = ops.sparse_conv_f16x3(X, one, hi, lo, sc, None)
