@@ -752,7 +752,7 @@ def test_conv_partial_rows_24bit_encoding_byte_for_byte(ops):
     """The partial rows between the two phases are BYTES with a stated format (include/geopurify_hip.h): per pair
     row and 128-column quarter an exponent byte E = the exponent field of (largest |v| + 1 ulp) and per element u = rint(v 2^(148 - E)) +
     2^22 in three little-endian bytes; a quarter's 384 bytes = its 16 lanes' first 16 bytes, then their last 8; the exponent bytes follow
-    the rows.  Restated here in numpy from the fp32 partial rows the tuning twin leaves in the same buffer (knob 3, bit 5) and compared
+    the rows.  Restated in numpy (oracle/conv_partial.py) from the fp32 partial rows the tuning twin leaves in the same buffer (knob 3, bit 5) and compared
     byte for byte; the decoded values are within half a unit 2^(E - 149) <= 2^-22 of the quarter's maximum of the fp32 rows."""
     from geopurify_amd._lib import load
     lib = load()
@@ -778,22 +778,15 @@ def test_conv_partial_rows_24bit_encoding_byte_for_byte(ops):
     ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc), None, x_split=(xh, xl), x_row_inv=inv)
     raw = pairs.partial.view(torch.uint8).flatten().cpu().numpy()
     P = pairs.num_pairs
-    nq = cout // 128
-    e_off = (P * cout * 3 + 15) & ~15
-    v = P32.reshape(P, nq, 128).astype(np.float32)
-    m = np.abs(v).max(axis=2)
-    Em = ((m.view(np.uint32).astype(np.int64) + 1) >> 23)
-    assert Em.min() >= 22 and Em.max() < 255                                          # (no clamp is active on these operands)
-    got_E = raw[e_off:e_off + P * nq].reshape(P, nq).astype(np.int64)
-    assert np.array_equal(got_E, Em)
-    u = np.rint(v.astype(np.float64) * np.exp2(148.0 - Em)[:, :, None]).astype(np.int64) + (1 << 22)
-    assert u.min() > 0 and u.max() < (1 << 23)
-    lanes = u.reshape(P, nq, 16, 8)                                                   # lane f owns columns 8 f .. 8 f + 7
-    b = np.stack([(lanes >> (8 * t)) & 255 for t in range(3)], axis=-1).astype(np.uint8).reshape(P, nq, 16, 24)
-    want = np.concatenate([b[..., :16].reshape(P, nq, 256), b[..., 16:].reshape(P, nq, 128)], axis=2).reshape(-1)
-    assert np.array_equal(raw[:P * cout * 3], want)
-    dec = (u - (1 << 22)).astype(np.float64) * np.exp2(Em - 148.0)[:, :, None]
-    assert (np.abs(dec - v) <= np.exp2(Em - 149.0)[:, :, None]).all() and (np.exp2(Em - 149.0) <= m * 2.0 ** -22).all()
+    from oracle import conv_partial as o_cp
+    want_rows, want_E = o_cp.encode(P32)
+    e_off = o_cp.exponent_offset(P, cout)
+    assert np.array_equal(raw[e_off:e_off + want_E.size], want_E)
+    assert np.array_equal(raw[:want_rows.size], want_rows)
+    dec = o_cp.decode(raw[:want_rows.size], raw[e_off:e_off + want_E.size], P, cout)
+    half_unit = np.exp2(want_E.reshape(P, -1).astype(np.float64) - 149.0)
+    m = np.abs(P32.reshape(P, -1, 128)).max(axis=2)
+    assert (np.abs(dec - P32).reshape(P, -1, 128) <= half_unit[:, :, None]).all() and (half_unit <= m * 2.0 ** -22 * (1 + 1e-6)).all()
 
 
 def test_sparse_conv_f16x3_wide_rows_row_scales_and_non_finite_rows(ops):

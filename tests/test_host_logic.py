@@ -313,3 +313,37 @@ def test_bench_rank_watchdog_and_config_v_default():
     assert time.time() - t0 < 200
     assert "still running after 45 s" in out.stderr and "last stderr lines of the ranks" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_conv_partial_row_format_restatement():
+    """oracle/conv_partial.py (the numpy statement of the 24-bit partial rows the GPU tests compare the kernels with, byte for byte): round
+    trip within half a unit of the block exponent and <= 2^-22 of the quarter's maximum; an all-ones mantissa takes the next exponent; u stays
+    inside 23 bits; a NaN / Inf quarter is marked 255; the layout puts lane f's first 16 bytes at 16 f and its last 8 at 256 + 8 f."""
+    import numpy as np
+    from oracle import conv_partial as cp
+    rng = np.random.default_rng(0)
+    P, cout = 37, 384
+    v = (rng.standard_normal((P, cout)) * np.exp(rng.standard_normal((P, 1)) * 5.0)).astype(np.float32)
+    v[3, :128] = 0.0
+    v[3, 7] = np.float32(1.9999999)                       # mantissa all ones: exponent field 127 -> E = 128
+    v[5, 130] = np.float32(-1024.0)
+    rows, E = cp.encode(v)
+    assert rows.size == P * cout * 3 and E.size == P * cout // 128
+    Eq = E.reshape(P, -1).astype(np.int64)
+    assert Eq[3, 0] == 128
+    dec = cp.decode(rows, E, P, cout)
+    m = np.abs(v.reshape(P, -1, 128)).max(axis=2)
+    half = np.exp2(Eq - 149.0)
+    assert (np.abs(dec - v).reshape(P, -1, 128) <= half[:, :, None]).all() and (half <= m * 2.0 ** -22 * (1 + 1e-6)).all() and (half > m * 2.0 ** -24).all()   # (an all-ones mantissa: 2^-22 (1 + 2^-24))
+    # layout: element j of lane f of quarter q of row p
+    p_, q_, f_, j_ = 11, 2, 9, 6
+    u = int(np.rint(float(v[p_, q_ * 128 + f_ * 8 + j_]) * 2.0 ** (148 - int(Eq[p_, q_])))) + (1 << 22)
+    rec = rows.reshape(P, cout // 128, 384)[p_, q_]
+    lane = np.concatenate([rec[f_ * 16:f_ * 16 + 16], rec[256 + f_ * 8:256 + f_ * 8 + 8]])
+    assert int(lane[3 * j_]) | int(lane[3 * j_ + 1]) << 8 | int(lane[3 * j_ + 2]) << 16 == u
+    bad = v.copy()
+    bad[2, 200] = np.nan
+    bad[4, 10] = np.inf
+    Eb = cp.exponents(bad)
+    assert Eb[2, 1] == 255 and Eb[4, 0] == 255 and (Eb[2, 0] < 255) and (Eb[4, 1] < 255)
+    assert cp.exponent_offset(P, cout) == ((P * cout * 3 + 15) // 16) * 16
