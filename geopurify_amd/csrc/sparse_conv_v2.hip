@@ -677,7 +677,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
                                    const float *__restrict__ residual, int64_t ld_res, int relu,
                                    float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ y_hi,
                                    _Float16 *__restrict__ y_lo, int64_t ld_yh, int64_t row_begin, int64_t row_count,
-                                   int pair_base, float *__restrict__ y_inv_scale) {
+                                   int pair_base, float *__restrict__ y_inv_scale, const _Float16 *__restrict__ res_hi,
+                                   const _Float16 *__restrict__ res_lo, int64_t ld_rh, const float *__restrict__ res_inv) {
+    // (res_hi / res_lo / res_inv: the residual as the split planes an earlier layer wrote -- (hi + lo) * res_inv[row] -- instead of fp32 rows)
     // Waves walk the chunk's rows with a stride of the whole grid (row w, w + W, ...), the NEXT row's 27 positions loaded while this
     // row's partial rows are gathered: the host sizes the grid to what is resident at once (6 waves per SIMD at 80 registers), so
     // that a chunk is not one full round of waves plus a third of one, and the position -> rows dependency is paid once per wave.
@@ -712,6 +714,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
                     float4 r = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
                     a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
                 }
+                if (res_hi) {
+                    typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
+                    const f16x4r rh = *reinterpret_cast<const f16x4r *>(res_hi + u * ld_rh + c), rl = *reinterpret_cast<const f16x4r *>(res_lo + u * ld_rh + c);
+                    const float ri = res_inv ? res_inv[u] : 1.f;
+                    a.x += ((float)rh[0] + (float)rl[0]) * ri; a.y += ((float)rh[1] + (float)rl[1]) * ri;
+                    a.z += ((float)rh[2] + (float)rl[2]) * ri; a.w += ((float)rh[3] + (float)rl[3]) * ri;
+                }
                 if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
                 if (y) *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;      // fp32 copy only where a later layer reads it (residual, linear)
                 av[ch] = a;
@@ -744,6 +753,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         if (residual) {
             float4 r = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
             a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        if (res_hi) {
+            typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
+            const f16x4r rh = *reinterpret_cast<const f16x4r *>(res_hi + u * ld_rh + c), rl = *reinterpret_cast<const f16x4r *>(res_lo + u * ld_rh + c);
+            const float ri = res_inv ? res_inv[u] : 1.f;
+            a.x += ((float)rh[0] + (float)rl[0]) * ri; a.y += ((float)rh[1] + (float)rl[1]) * ri;
+            a.z += ((float)rh[2] + (float)rl[2]) * ri; a.w += ((float)rh[3] + (float)rl[3]) * ri;
         }
         if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
         if (y) *reinterpret_cast<float4 *>(y + u * ld_y + c) = a;
@@ -824,7 +840,10 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
                        int kv, int cout, const float *__restrict__ scale, const float *__restrict__ shift,
                        const float *__restrict__ residual, int64_t ld_res, int relu, float *__restrict__ y, int64_t ld_y,
                        _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int64_t ld_yh, int64_t row_begin, int64_t row_count,
-                       int pair_base, float *__restrict__ y_inv_scale) {
+                       int pair_base, float *__restrict__ y_inv_scale, const _Float16 *__restrict__ res_hi,
+                       const _Float16 *__restrict__ res_lo, int64_t ld_rh, const float *__restrict__ res_inv) {
+    // (res_hi / res_lo / res_inv: the residual read from the split planes an earlier layer wrote for ITS consumer -- (hi + lo) * res_inv[row],
+    //  the value that layer's successor multiplied with -- so that no fp32 copy of a block's input is written only to be added once)
     // the row walk of conv_phase2_kernel: rows w, w + W, ... per wave, the next row's 27 positions loaded under this row's gathers
     const int lane = gp_lane();
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -877,6 +896,12 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
                 const float4 r0 = *reinterpret_cast<const float4 *>(residual + u * ld_res + c);
                 const float4 r1 = *reinterpret_cast<const float4 *>(residual + u * ld_res + c + 4);
                 a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+            }
+            if (res_hi) {
+                const f16x8 rh = *reinterpret_cast<const f16x8 *>(res_hi + u * ld_rh + c), rl = *reinterpret_cast<const f16x8 *>(res_lo + u * ld_rh + c);
+                const float ri = res_inv ? res_inv[u] : 1.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += ((float)rh[j] + (float)rl[j]) * ri;
             }
             if (relu) {
 #pragma unroll
@@ -1130,7 +1155,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                                     int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
                                     const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
-                                    void *stream_) {
+                                    const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, void *stream_) {
+    GP_CHECK_ARG(!res_hi || (res_lo && !residual && ld_rh % 8 == 0 && (uintptr_t)res_hi % 16 == 0 && (uintptr_t)res_lo % 16 == 0),
+                 "gp_sparse_conv_f16x3: the residual comes as fp32 rows OR as 16-byte aligned split planes (res_hi + res_lo), not both");
+    GP_CHECK_ARG(res_hi || (!res_lo && !res_row_inv_scale), "gp_sparse_conv_f16x3: res_lo / res_row_inv_scale belong to res_hi");
     GP_CHECK_ARG((x || (x_hi && x_lo)) && pair_in && pair_pos && pair_off && tile_start && tile_desc && nseg > 0 && w_hi && w_lo && partial && (y || y_hi), "gp_sparse_conv_f16x3: null argument");
     GP_CHECK_ARG(!x_hi || (ld_xh % 8 == 0 && (uintptr_t)x_hi % 16 == 0 && (uintptr_t)x_lo % 16 == 0), "gp_sparse_conv_f16x3: pre-split rows must be 16-byte aligned");
     GP_CHECK_ARG(!y_hi || (y_lo && ld_yh % 4 == 0), "gp_sparse_conv_f16x3: y_hi/y_lo come as a pair");
@@ -1231,14 +1259,16 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         if (q24 && p2_wg_per_cu == 6) p2_res = (int64_t)gp_cu_count() * 4;
         const unsigned p2_grid = (unsigned)((p2_res > 0 && p2_res < p2_full) ? p2_res : p2_full);
 #define P2Q_ARGS reinterpret_cast<const unsigned char *>(partial), q_e_off, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, \
-                 relu, y, ld_y, static_cast<_Float16 *>(y_hi), static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale
+                 relu, y, ld_y, static_cast<_Float16 *>(y_hi), static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale, \
+                 static_cast<const _Float16 *>(res_hi), static_cast<const _Float16 *>(res_lo), ld_rh, res_row_inv_scale
         if (q24 && cout > 512) conv_phase2_q24_kernel<true><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
         else if (q24) conv_phase2_q24_kernel<false><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
 #undef P2Q_ARGS
         else
             conv_phase2_kernel<<<p2_grid, 256, 0, s>>>(
                 partial, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, relu, y, ld_y, static_cast<_Float16 *>(y_hi),
-                static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale);
+                static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale,
+                static_cast<const _Float16 *>(res_hi), static_cast<const _Float16 *>(res_lo), ld_rh, res_row_inv_scale);
     }
     GP_CHECK_LAUNCH();
     return GP_OK;

@@ -326,8 +326,14 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                       x_split=None, out_split=None, x_row_inv=None, out_row_inv=None, want_f32=True):
     """x fp32 [nv, >=cin] and/or x_split=(hi, lo) f16 (pre-split operand -> LDS-DMA path);
     out_split=(hi, lo) f16 buffers to also receive the split output.  x_row_inv fp32 [nv]: the per-row inverse scales of
-    a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled)."""
+    a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled).
+    residual: fp32 rows [nv, >=cout], or a tuple (hi, lo, row_inv | None) of the split planes an earlier layer wrote -- the producer then
+    needs no fp32 copy."""
     lib = _lib.load()
+    res_planes = residual if isinstance(residual, (tuple, list)) else None
+    if res_planes is not None:
+        residual = None
+    rh, rl, ri = (tuple(res_planes) + (None,))[:3] if res_planes is not None else (None, None, None)
     kv, cout, cin = w_hi.shape
     nv = pairs.nv
     dev = w_hi.device
@@ -344,7 +350,8 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
                                    out.stride(0) if out is not None else 0, _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                    int(pairs.num_chunks), pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off,
-                                   _ptr(x_row_inv), _ptr(out_row_inv), _stream()),
+                                   _ptr(x_row_inv), _ptr(out_row_inv), _ptr(rh), _ptr(rl), rh.stride(0) if rh is not None else 0, _ptr(ri),
+                                   _stream()),
           "gp_sparse_conv_f16x3")
     return out
 

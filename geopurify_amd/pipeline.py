@@ -41,6 +41,9 @@ class StudentWeights:
     def __init__(self, state_dict, device, eps=1e-5, mode="f16x3"):
         sd = {k: v.detach() for k, v in state_dict.items()}
         self.mode = mode
+        # fast path: a residual block's input is added back from the split planes its first convolution reads (GP_RESIDUAL_PLANES=0: from
+        # fp32 rows, which the producing layer then writes as well -- rounds 1-5a)
+        self.residual_from_planes = os.environ.get("GP_RESIDUAL_PLANES", "1") != "0"
         w0 = sd["input_layer.0.kernel"].float()
         self.cin = w0.shape[1]
         self.cin_pad = _pad_to(self.cin, CONV_PAD)
@@ -127,12 +130,16 @@ class StudentWeights:
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
             ctx["pairs"] = ops.conv_pairs_build(nbr_map, col_tiles=max(1, self.hidden // 256))
         xs = (x_split if x_split is not None else self.split_input(x)) if fast else None
-        h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast)
+        # On the fast path a block's input is added back from the SPLIT PLANES its first convolution reads (hi + lo) * row scale -- the
+        # value that convolution multiplies with -- so no layer writes fp32 rows unless the dense output layer needs them (no fused head).
+        planes_res = fast and self.residual_from_planes
+        h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast, want_f32=not planes_res)
         for b in range(self.num_blocks):
             t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast, want_f32=not fast)   # conv1 output: next conv only
             last = b == self.num_blocks - 1
             head = last and fast and self.head is not None          # the output layer reads the split planes only
-            h, hs = self._conv(2 + 2 * b, t, ctx, residual=h, x_split=ts, want_split=fast and (not last or head), want_f32=not head)
+            h, hs = self._conv(2 + 2 * b, t, ctx, residual=hs if planes_res else h, x_split=ts, want_split=fast and (not last or head),
+                               want_f32=not (head or (planes_res and not last)))
         self.last_pairs = ctx["pairs"]
         if mark is not None:
             mark("student convolutions")                  # (stage marks of bench.py's per-stage pass)

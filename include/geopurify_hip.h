@@ -173,7 +173,11 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          const float *scale, const float *shift, const float *residual, int64_t ld_res,
                          int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                          int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
-                         const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale, void *stream);
+                         const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
+                         const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, void *stream);
+/* res_hi / res_lo f16 [nv, ld_rh] (+ res_row_inv_scale fp32 [nv] or NULL): the residual as the split planes an earlier layer wrote  */
+/* (its y_hi / y_lo / y_row_inv_scale) instead of fp32 rows -- (hi + lo) * inv, the value that layer's consumer multiplied with; the    */
+/* producer then needs no fp32 copy (y = NULL).  `residual` and res_hi exclude each other.                                             */
 /* Chunked execution (num_chunks >= 1, the chunks the pairs were built with): phase 1 / phase 2 alternate  */
 /* per chunk so that `partial` (then sized for the largest chunk) stays in the Infinity Cache;             */
 /* chunk_row_off_host = HOST copy of the row offsets, chunk_tile_off_host / chunk_pair_off_host =           */

@@ -700,6 +700,22 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     assert (y2 - y).abs().max().item() <= 27 * 2.0 ** -22 * part_max * float(sc.max())
     err2 = (y2.cpu().double() - ref).abs().max().item()
     assert err2 < 5e-5 and err2 < 4 * err32 + 1e-6, (err2, err32)
+    # the residual as the split planes of an earlier layer (hi + lo) * row scale instead of fp32 rows: the same sum up to the planes' 2^-22
+    # of the row's largest magnitude; fp32 rows AND planes together are an error
+    rh, rl, rinv = ops.split_f16(dev(res), per_row=True)
+    y3 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(rh, rl, rinv), relu=True, x_split=xs)
+    res_back = (rh.float() + rl.float()) * rinv[:, None]
+    assert (res_back - dev(res)).abs().max().item() <= 2.0 ** -22 * float(res.abs().max())
+    assert (y3 - y2).abs().max().item() <= 2.0 ** -21 * float(res.abs().max()) + 1e-7
+    from geopurify_amd._lib import GeoPurifyHipError
+    lib_c = load()
+    with pytest.raises(GeoPurifyHipError):
+        from geopurify_amd.ops import _ptr, check, _stream
+        check(lib_c.gp_sparse_conv_f16x3(None, 0, _ptr(xs[0]), _ptr(xs[1]), xs[0].stride(0), _ptr(pairs.pair_in), _ptr(pairs.pair_pos), _ptr(pairs.pair_off),
+                                         _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, Nv, 27, _ptr(hi), _ptr(lo), 96, 256,
+                                         _ptr(pairs.partial), None, None, _ptr(dev(res)), 256, 1, _ptr(y3), 256, None, None, 0, int(pairs.num_chunks),
+                                         pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off, None, None, _ptr(rh), _ptr(rl), rh.stride(0), _ptr(rinv),
+                                         _stream()), "gp_sparse_conv_f16x3")
     assert (ys[0].float() + ys[1].float() - y2).abs().max() <= 2e-6 * max(1.0, float(y2.abs().max()))
     # chunk heights chosen from the kernel map (gp_conv_chunk_plan): every launch within the tile target, the chunk tables consistent
     # with the map, and -- a row's sum does not depend on which rows share its tiles -- the same bits
