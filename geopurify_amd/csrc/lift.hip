@@ -293,11 +293,14 @@ __global__ void lift_masks_views_kernel(const float *__restrict__ mt /*[V, h*w, 
     int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     if (e >= total) return;
     int lane = gp_lane();
-    const int v = ent_view[e];
+    // one wave per entry: its view and pixel are wave-uniform -- said so to the compiler (readfirstlane), the tap tables of the pixel
+    // (2 + 8 values) then come through the scalar cache instead of ten 64-lane loads of one address each
+    const int v = __builtin_amdgcn_readfirstlane(ent_view[e]);
+    const int ex = __builtin_amdgcn_readfirstlane((int)ent_x[e]), ey = __builtin_amdgcn_readfirstlane((int)ent_y[e]);
     int sg = -1;
     if (keep[v])                                                 // wave-uniform
         lift_masks_point_sorted(mt + (int64_t)v * h * w * Q, Q, h, w, sscore + (int64_t)v * Q, order + (int64_t)v * Q, tx0, twx, ty0, twy,
-                                out_h, out_w, (int)ent_x[e], (int)ent_y[e], lane, sg);
+                                out_h, out_w, ex, ey, lane, sg);
     if (lane == 0) seg[e] = sg;
 }
 
