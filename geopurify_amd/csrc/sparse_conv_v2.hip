@@ -433,7 +433,11 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         // the 24-bit format below), and the permutation costs nothing: it is the source address of the LDS-DMA
         const int wcol = (row & 128) | ((row & 15) << 3) | ((row >> 4) & 7);
         gb_hi[t] = w_hi + ((int64_t)k * cout + n0 + wcol) * cin + q;
+        // tuning bit 6: the ADDRESSES of a step-blocked weight layout ([offset][column tile][K step][256 rows][32]): a step's 16 KiB
+        // contiguous, every LDS-DMA instruction one 1-KiB run instead of 16 half lines.  Wrong values, the right traffic: a price.
+        if (TUNE && (ablate & 64)) gb_hi[t] = w_hi + ((int64_t)k * cout + n0) * cin + row * 32 + q;
     }
+    const int bmul = (TUNE && (ablate & 64)) ? TN : 1;        // halfs of the weight operand per half of a K step
     auto issue = [&](int c0, int buf) {
         if (!issuer) return;
 #pragma unroll
@@ -441,8 +445,8 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
             const int r0 = wv * RPW + t * 16;
             glds16(ga_hi[t] + c0, &sm.a_hi[buf][r0][0]);
             glds16(ga_hi[t] + da + c0, &sm.a_lo[buf][r0][0]);
-            glds16(gb_hi[t] + c0, &sm.b_hi[buf][r0][0]);
-            glds16(gb_hi[t] + db + c0, &sm.b_lo[buf][r0][0]);
+            glds16(gb_hi[t] + c0 * bmul, &sm.b_hi[buf][r0][0]);
+            glds16(gb_hi[t] + db + c0 * bmul, &sm.b_lo[buf][r0][0]);
         }
     };
 
