@@ -120,11 +120,11 @@ def conv_ceilings(hp, dev):
     from geopurify_amd import _lib, ops
     st = hp.student
     pairs = getattr(st, "last_pairs", None)
-    lay = [l for l in st.layers if l[0] == "f16x3" and l[1][0].shape[1] == l[1][0].shape[2]]
+    lay = [l for l in st.layers if l[0] == "f16x3" and ops.conv_weights_shape(l[1][0])[1] == ops.conv_weights_shape(l[1][0])[2]]
     if pairs is None or not lay:
         return None
     _, (hi, lo), scale, shift = lay[0]
-    nv, c = pairs.nv, hi.shape[1]
+    nv, c = pairs.nv, ops.conv_weights_shape(hi)[1]
     lib = _lib.load()
     g = torch.Generator(device=dev).manual_seed(3)
 
@@ -409,7 +409,8 @@ class ConvTimer:
             e0.record(s)
             r = orig(x, pairs, w_hi, w_lo, *a, **k)
             e1.record(s)
-            timer.events.append((e0, e1, int(w_hi.shape[2]), int(w_hi.shape[1]), int(pairs.num_pairs)))
+            _, co_, ci_ = ops.conv_weights_shape(w_hi)
+            timer.events.append((e0, e1, ci_, co_, int(pairs.num_pairs)))
             return r
         ops.sparse_conv_f16x3 = timed
 

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(NT2)
 conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__restrict__ pair_in,
                    const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc,
                    int nseg, int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
-                   float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base) {
+                   float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base, int w_blocked) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
@@ -283,6 +283,14 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
     const float *xa = x + (int64_t)in_row * ld_x + s_half * 16;
     const _Float16 *wbh = w_hi + ((int64_t)k * cout + n0 + s_row) * cin + s_half * 16;
     const _Float16 *wbl = w_lo + ((int64_t)k * cout + n0 + s_row) * cin + s_half * 16;
+    if (w_blocked) {
+        // step-blocked weights: column c of the tile sits in layout row (c & 128) | (c & 7) << 4 | (c >> 3 & 15) (the LDS-DMA kernel's row)
+        const int rho = (s_row & 128) | ((s_row & 7) << 4) | ((s_row >> 3) & 15);
+        const int64_t o = ((((int64_t)k * n_tiles + nt) * (cin / TK)) * TN + rho) * TK + s_half * 16;
+        wbh = w_hi + o;
+        wbl = w_lo + o;
+    }
+    const int bmul = w_blocked ? TN : 1;
 
     float4 ra[4];
     f16x8 rbh[2], rbl[2];
@@ -292,8 +300,8 @@ conv_phase1_kernel(const float *__restrict__ x, int64_t ld_x, const int32_t *__r
             ra[i] = a_ok ? *reinterpret_cast<const float4 *>(xa + c0 + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            rbh[i] = *reinterpret_cast<const f16x8 *>(wbh + c0 + i * 8);
-            rbl[i] = *reinterpret_cast<const f16x8 *>(wbl + c0 + i * 8);
+            rbh[i] = *reinterpret_cast<const f16x8 *>(wbh + c0 * bmul + i * 8);
+            rbl[i] = *reinterpret_cast<const f16x8 *>(wbl + c0 * bmul + i * 8);
         }
     };
     auto store_step = [&](int buf) {
@@ -393,7 +401,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                      const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
                      const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout,
                      float *__restrict__ P, int n_tiles, int ablate_, int tile_begin, int tile_count, int pair_base,
-                     const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp, int64_t q_e_off) {
+                     const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp, int64_t q_e_off, int w_blocked) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
     uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0, st_dma = 0, st_wait = 0;
@@ -433,11 +441,12 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         // the 24-bit format below), and the permutation costs nothing: it is the source address of the LDS-DMA
         const int wcol = (row & 128) | ((row & 15) << 3) | ((row >> 4) & 7);
         gb_hi[t] = w_hi + ((int64_t)k * cout + n0 + wcol) * cin + q;
-        // tuning bit 6: the ADDRESSES of a step-blocked weight layout ([offset][column tile][K step][256 rows][32]): a step's 16 KiB
-        // contiguous, every LDS-DMA instruction one 1-KiB run instead of 16 half lines.  Wrong values, the right traffic: a price.
-        if (TUNE && (ablate & 64)) gb_hi[t] = w_hi + ((int64_t)k * cout + n0) * cin + row * 32 + q;
+        // step-blocked weights (gp_conv_weights_split_blocked: [offset][column tile][K step][256 LDS rows][32]): a step's 16 KiB are
+        // contiguous and every LDS-DMA instruction of the weight operand is ONE 1-KiB run instead of 16 half lines (a quarter fewer L2
+        // requests in the K loop); the row permutation above is part of that layout
+        if (w_blocked) gb_hi[t] = w_hi + ((((int64_t)k * n_tiles + nt) * (cin / TK)) * TN + row) * TK + q;
     }
-    const int bmul = (TUNE && (ablate & 64)) ? TN : 1;        // halfs of the weight operand per half of a K step
+    const int bmul = w_blocked ? TN : 1;                      // halfs of the weight operand between two K steps, over TK
     auto issue = [&](int c0, int buf) {
         if (!issuer) return;
 #pragma unroll
@@ -605,8 +614,8 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                   const int32_t *__restrict__ off, const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg,  \
                   int kv, const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P, \
                   int n_tiles, int ablate, int tile_begin, int tile_count, int pair_base, const float *__restrict__ x_inv_scale,           \
-                  uint64_t *__restrict__ stamp, int64_t q_e_off
-#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp, q_e_off
+                  uint64_t *__restrict__ stamp, int64_t q_e_off, int w_blocked
+#define P1_FWD x_hi, x_lo, ld_xh, pair_in, off, tile_start, tile_desc, nseg, kv, w_hi, w_lo, cin, cout, P, n_tiles, ablate, tile_begin, tile_count, pair_base, x_inv_scale, stamp, q_e_off, w_blocked
 // the product kernel (tuning bits compiled out) and its twin with the bits of knob 3 live, under its own name in a trace
 // (bench.py's data-movement ceiling of the convolution and scripts/bench_conv.py's ablations launch the twin)
 __global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
@@ -1040,6 +1049,26 @@ __global__ void weight_split_kernel(const float *__restrict__ w, int kv, int cin
     }
 }
 
+// the same split into the step-blocked layout of the two-phase kernels: [kv][cout / 256][cin / 32][256 rows][32 halfs], row rho of a
+// column tile = its column (rho & 128) | (rho & 15) << 3 | (rho >> 4 & 7) (the LDS row the LDS-DMA kernel stages it in)
+__global__ void weight_split_blocked_kernel(const float *__restrict__ w, int kv, int cin, int cout, float s,
+                                            _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+    const int64_t total = (int64_t)kv * cin * cout;
+    const int steps = cin / TK, nt = cout / TN;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % TK);
+        const int rho = (int)((i / TK) % TN);
+        const int st = (int)((i / ((int64_t)TK * TN)) % steps);
+        const int t = (int)((i / ((int64_t)TK * TN * steps)) % nt);
+        const int64_t k = i / ((int64_t)TK * TN * steps * nt);
+        const int c = (rho & 128) | ((rho & 15) << 3) | ((rho >> 4) & 7);
+        const float v = w[(k * cin + st * TK + kk) * cout + t * TN + c] * s;
+        const _Float16 h = (_Float16)v;
+        hi[i] = h;
+        lo[i] = (_Float16)(v - (float)h);
+    }
+}
+
 size_t scan_tmp32(int64_t n) {
     size_t t = 0;
     (void)rocprim::exclusive_scan(nullptr, t, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), 0);
@@ -1119,6 +1148,16 @@ extern "C" int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, in
     return GP_OK;
 }
 
+extern "C" int gp_conv_weights_split_blocked(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2, void *w_hi,
+                                             void *w_lo, void *stream_) {
+    GP_CHECK_ARG(w && w_hi && w_lo && kv > 0 && cin > 0 && cout > 0, "gp_conv_weights_split_blocked: null/empty argument");
+    GP_CHECK_ARG(cin % TK == 0 && cout % TN == 0, "gp_conv_weights_split_blocked: cin=%d must be a multiple of %d and cout=%d of %d", cin, TK, cout, TN);
+    weight_split_blocked_kernel<<<2048, 256, 0, gp_stream(stream_)>>>(w, kv, cin, cout, scale_pow2, static_cast<_Float16 *>(w_hi),
+                                                                      static_cast<_Float16 *>(w_lo));
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
 extern "C" int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
                             void *stream_) {
     GP_CHECK_ARG(x && hi && lo && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0, "gp_split_f16: bad argument");
@@ -1159,7 +1198,9 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                                     int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
                                     const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
-                                    const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, void *stream_) {
+                                    const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, int32_t w_blocked,
+                                    void *stream_) {
+    GP_CHECK_ARG(w_blocked == 0 || w_blocked == 1, "gp_sparse_conv_f16x3: w_blocked is 0 (row-major weights) or 1 (gp_conv_weights_split_blocked)");
     GP_CHECK_ARG(!res_hi || (res_lo && !residual && ld_rh % 8 == 0 && (uintptr_t)res_hi % 16 == 0 && (uintptr_t)res_lo % 16 == 0),
                  "gp_sparse_conv_f16x3: the residual comes as fp32 rows OR as 16-byte aligned split planes (res_hi + res_lo), not both");
     GP_CHECK_ARG(res_hi || (!res_lo && !res_row_inv_scale), "gp_sparse_conv_f16x3: res_lo / res_row_inv_scale belong to res_hi");
@@ -1237,7 +1278,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
             const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
-                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off
+                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off, w_blocked
             if (dma_path) {
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
@@ -1249,7 +1290,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 GP_CHECK_ARG(x, "gp_sparse_conv_f16x3: fp32 x required for the register-staged path");
                 GP_CHECK_ARG(!x_row_inv_scale, "gp_sparse_conv_f16x3: the register-staged path splits unscaled fp32 rows");
 #define P1R_ARGS x, ld_x, pair_in, pair_off, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), \
-                 static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base
+                 static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, w_blocked
                 if (tune) conv_phase1_kernel<true><<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1R_ARGS);
                 else conv_phase1_kernel<false><<<(unsigned)nblocks, NT2, sizeof(V2Smem), s>>>(P1R_ARGS);
 #undef P1R_ARGS

@@ -283,15 +283,33 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
     return cp
 
 
-def conv_weights_split(w, scale_pow2):
-    """w fp32 [kv,cin,cout] -> (w_hi, w_lo) f16 [kv,cout,cin] of scale_pow2*w."""
+def conv_weights_split(w, scale_pow2, blocked=None):
+    """w fp32 [kv,cin,cout] -> (w_hi, w_lo) f16 of scale_pow2*w.
+    blocked (default: whenever the shape allows, cin % 32 == 0 and cout % 256 == 0): the step-blocked layout of the two-phase
+    convolution, tensors of shape [kv, cout/256, cin/32, 256, 32] -- sparse_conv_f16x3 recognises it by its five dimensions;
+    else [kv,cout,cin] (the dense output layer's operand, gp_embed_head_f16x3; also accepted by sparse_conv_f16x3)."""
     lib = _lib.load()
     kv, cin, cout = w.shape
+    if blocked is None:
+        blocked = cin % 32 == 0 and cout % 256 == 0 and os.environ.get("GP_CONV_WEIGHTS_BLOCKED", "1") != "0"   # (0: A/B against [kv,cout,cin])
+    if blocked:
+        hi = torch.empty((kv, cout // 256, cin // 32, 256, 32), dtype=torch.float16, device=w.device)
+        lo = torch.empty_like(hi)
+        check(lib.gp_conv_weights_split_blocked(_ptr(w), kv, cin, cout, float(scale_pow2), _ptr(hi), _ptr(lo), _stream()),
+              "gp_conv_weights_split_blocked")
+        return hi, lo
     hi = torch.empty((kv, cout, cin), dtype=torch.float16, device=w.device)
     lo = torch.empty((kv, cout, cin), dtype=torch.float16, device=w.device)
     check(lib.gp_conv_weights_split(_ptr(w), kv, cin, cout, float(scale_pow2), _ptr(hi), _ptr(lo), _stream()),
           "gp_conv_weights_split")
     return hi, lo
+
+
+def conv_weights_shape(w_hi):
+    """(kv, cout, cin) of a split weight tensor in either layout"""
+    if w_hi.dim() == 5:
+        return int(w_hi.shape[0]), int(w_hi.shape[1]) * 256, int(w_hi.shape[2]) * 32
+    return tuple(int(v) for v in w_hi.shape)
 
 
 def split_f16(x, d=None, scale=None, per_row=False):
@@ -334,7 +352,8 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     if res_planes is not None:
         residual = None
     rh, rl, ri = (tuple(res_planes) + (None,))[:3] if res_planes is not None else (None, None, None)
-    kv, cout, cin = w_hi.shape
+    kv, cout, cin = conv_weights_shape(w_hi)
+    w_blocked = int(w_hi.dim() == 5)
     nv = pairs.nv
     dev = w_hi.device
     if pairs.partial is None or pairs.partial.shape[1] < cout:
@@ -351,7 +370,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    out.stride(0) if out is not None else 0, _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                    int(pairs.num_chunks), pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off,
                                    _ptr(x_row_inv), _ptr(out_row_inv), _ptr(rh), _ptr(rl), rh.stride(0) if rh is not None else 0, _ptr(ri),
-                                   _stream()),
+                                   w_blocked, _stream()),
           "gp_sparse_conv_f16x3")
     return out
 

@@ -67,7 +67,7 @@ class StudentWeights:
                 and os.environ.get("GP_EMBED_HEAD", "f16x3") != "f32"):
             amax = float(self.w_out.abs().max().item())
             p2 = 2.0 ** int(np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
-            hi, lo = ops.conv_weights_split(self.w_out.reshape(1, self.hidden, self.embed), p2)
+            hi, lo = ops.conv_weights_split(self.w_out.reshape(1, self.hidden, self.embed), p2, blocked=False)   # the dense head's operand
             self.head = (hi, lo, 1.0 / p2)
 
     @staticmethod
@@ -97,7 +97,7 @@ class StudentWeights:
         if kind == "f16x3":
             out_split = None
             if want_split:
-                nv, cout = ctx["pairs"].nv, w[0].shape[1]
+                nv, cout = ctx["pairs"].nv, ops.conv_weights_shape(w[0])[1]
                 dev = w[0].device
                 out_split = (torch.empty((nv, cout), dtype=torch.float16, device=dev), torch.empty((nv, cout), dtype=torch.float16, device=dev),
                              torch.empty(nv, dtype=torch.float32, device=dev))

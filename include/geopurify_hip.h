@@ -174,7 +174,13 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          int32_t relu, float *y, int64_t ld_y, void *y_hi, void *y_lo, int64_t ld_yh,
                          int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
                          const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
-                         const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, void *stream);
+                         const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, int32_t w_blocked,
+                         void *stream);
+/* w_blocked = 1: w_hi / w_lo come from gp_conv_weights_split_blocked -- the same halves as [kv][cout / 256][cin / 32][256][32]: a K   */
+/* step's 16 KiB of a column tile contiguous (one 1-KiB run per LDS-DMA instruction instead of 16 half lines), row rho of a tile =     */
+/* its column (rho & 128) | (rho & 15) << 3 | (rho >> 4 & 7).  cin % 32 == 0, cout % 256 == 0.  0: the [kv][cout][cin] halves above.    */
+int gp_conv_weights_split_blocked(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2,
+                                  void *w_hi, void *w_lo, void *stream);
 /* res_hi / res_lo f16 [nv, ld_rh] (+ res_row_inv_scale fp32 [nv] or NULL): the residual as the split planes an earlier layer wrote  */
 /* (its y_hi / y_lo / y_row_inv_scale) instead of fp32 rows -- (hi + lo) * inv, the value that layer's consumer multiplied with; the    */
 /* producer then needs no fp32 copy (y = NULL).  `residual` and res_hi exclude each other.                                             */

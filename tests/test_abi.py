@@ -47,7 +47,7 @@ def test_debug_knobs_reject_what_is_not_in_the_table():
     for key, value in ((0, 0), (16, 0), (-1, 0),                 # no such knob
                        (8, 32), (8, -1),                         # matrix-core affinity mask (round 5): bits 0-4 only
                        (4, 1024), (4, 2048), (4, -1),            # pooling mask: bits >= 10 are undefined
-                       (3, 128), (11, 8), (11, 1), (7, 1), (5, 2), (15, 3), (1, 5), (10, 65)):
+                       (3, 64), (11, 8), (11, 1), (7, 1), (5, 2), (15, 3), (1, 5), (10, 65)):
         assert lib.gp_debug_set(key, value) == EINVAL, (key, value)
         assert b"gp_debug_set" in lib.gp_last_error()
     for key, value in ((4, 9), (4, 128), (4, 0), (3, 2), (3, 32), (3, 0), (11, 4), (11, 0), (15, 2), (15, 0), (7, 2), (7, 0), (8, 31), (8, 0)):

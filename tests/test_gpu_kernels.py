@@ -715,7 +715,7 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
                                          _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, Nv, 27, _ptr(hi), _ptr(lo), 96, 256,
                                          _ptr(pairs.partial), None, None, _ptr(dev(res)), 256, 1, _ptr(y3), 256, None, None, 0, int(pairs.num_chunks),
                                          pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off, None, None, _ptr(rh), _ptr(rl), rh.stride(0), _ptr(rinv),
-                                         _stream()), "gp_sparse_conv_f16x3")
+                                         int(hi.dim() == 5), _stream()), "gp_sparse_conv_f16x3")
     assert (ys[0].float() + ys[1].float() - y2).abs().max() <= 2e-6 * max(1.0, float(y2.abs().max()))
     # chunk heights chosen from the kernel map (gp_conv_chunk_plan): every launch within the tile target, the chunk tables consistent
     # with the map, and -- a row's sum does not depend on which rows share its tiles -- the same bits
