@@ -45,7 +45,7 @@ SIGNATURES = {
     "gp_sparse_conv_f16x3": (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, c_int32, _P, _P,
                                        c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P,
                                        c_int64, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), _P, _P,
-                                       _P, _P, c_int64, _P, c_int32, _P]),
+                                       _P, _P, c_int64, _P, c_int32, c_int32, _P]),
     "gp_conv_weights_split_blocked": (c_int32, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
     "gp_pow2_scale": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_size_t, _P]),
     "gp_split_f16_scaled": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P]),

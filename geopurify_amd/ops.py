@@ -346,7 +346,10 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     out_split=(hi, lo) f16 buffers to also receive the split output.  x_row_inv fp32 [nv]: the per-row inverse scales of
     a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled).
     residual: fp32 rows [nv, >=cout], or a tuple (hi, lo, row_inv | None) of the split planes an earlier layer wrote -- the producer then
-    needs no fp32 copy."""
+    needs no fp32 copy.
+    INTERLEAVED rows: any of x_split / out_split / residual may be (t, None[, row_inv]) with t f16 [nv, 2 * channels] holding per 32-channel
+    step [hi 32 | lo 32]: the LDS-DMA kernel stages a row and step as one full 128-byte line (interleave_planes / deinterleave_planes
+    convert)."""
     lib = _lib.load()
     res_planes = residual if isinstance(residual, (tuple, list)) else None
     if res_planes is not None:
@@ -362,6 +365,9 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
         out = torch.empty((nv, cout), dtype=torch.float32, device=dev)        # want_f32=False: only the split planes are written
     xh, xl = x_split if x_split is not None else (None, None)
     yh, yl = out_split if out_split is not None else (None, None)
+    # interleaved rows ([K step][hi 32 | lo 32], ONE tensor of 2 x channels halfs per row): given as (tensor, None)
+    plane_flags = (1 if (xh is not None and xl is None) else 0) | (2 if (yh is not None and yl is None) else 0) | \
+                  (4 if (rh is not None and rl is None) else 0)
     check(lib.gp_sparse_conv_f16x3(_ptr(x), x.stride(0) if x is not None else 0, _ptr(xh), _ptr(xl),
                                    xh.stride(0) if xh is not None else 0, _ptr(pairs.pair_in), _ptr(pairs.pair_pos),
                                    _ptr(pairs.pair_off), _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
@@ -370,9 +376,22 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
                                    out.stride(0) if out is not None else 0, _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                    int(pairs.num_chunks), pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off,
                                    _ptr(x_row_inv), _ptr(out_row_inv), _ptr(rh), _ptr(rl), rh.stride(0) if rh is not None else 0, _ptr(ri),
-                                   w_blocked, _stream()),
+                                   w_blocked, plane_flags, _stream()),
           "gp_sparse_conv_f16x3")
     return out
+
+
+def interleave_planes(hi, lo):
+    """(hi, lo) f16 [n, c] -> one f16 [n, 2 c] of interleaved rows, per 32-channel step [hi 32 | lo 32] (torch ops: tests, tools)"""
+    n, c = hi.shape
+    return torch.stack([hi.reshape(n, c // 32, 32), lo.reshape(n, c // 32, 32)], dim=2).reshape(n, 2 * c).contiguous()
+
+
+def deinterleave_planes(t):
+    """the inverse of interleave_planes"""
+    n, c2 = t.shape
+    v = t.reshape(n, c2 // 64, 2, 32)
+    return v[:, :, 0].reshape(n, c2 // 2).contiguous(), v[:, :, 1].reshape(n, c2 // 2).contiguous()
 
 
 def l2norm_rows_(x, d=None):

@@ -44,6 +44,8 @@ class StudentWeights:
         # fast path: a residual block's input is added back from the split planes its first convolution reads (GP_RESIDUAL_PLANES=0: from
         # fp32 rows, which the producing layer then writes as well -- rounds 1-5a)
         self.residual_from_planes = os.environ.get("GP_RESIDUAL_PLANES", "1") != "0"
+        # ... and the layers hand each other INTERLEAVED rows, [K step][hi 32 | lo 32] (GP_ROWS_INTERLEAVED=0: separate hi / lo planes)
+        self.interleaved_rows = os.environ.get("GP_ROWS_INTERLEAVED", "1") != "0"
         w0 = sd["input_layer.0.kernel"].float()
         self.cin = w0.shape[1]
         self.cin_pad = _pad_to(self.cin, CONV_PAD)
@@ -90,17 +92,21 @@ class StudentWeights:
         else:
             self.layers.append(("f32", w, scale, shift))
 
-    def _conv(self, li, x, ctx, residual=None, x_split=None, want_split=False, want_f32=True):
-        """x_split / the returned split: (hi, lo, row_inv_scale) -- operands pre-scaled by a power of two per row.
-        want_f32=False: the fp32 copy of the output is not written (only the next convolution reads this layer)."""
+    def _conv(self, li, x, ctx, residual=None, x_split=None, want_split=False, want_f32=True, il=False):
+        """x_split / the returned split: (hi, lo, row_inv_scale) -- operands pre-scaled by a power of two per row -- or, il=True,
+        (rows, None, row_inv_scale) with the hi / lo halves interleaved per 32-channel step (what the next convolution stages in full
+        lines).  want_f32=False: the fp32 copy of the output is not written (only the next convolution reads this layer)."""
         kind, w, scale, shift = self.layers[li]
         if kind == "f16x3":
             out_split = None
             if want_split:
                 nv, cout = ctx["pairs"].nv, ops.conv_weights_shape(w[0])[1]
                 dev = w[0].device
-                out_split = (torch.empty((nv, cout), dtype=torch.float16, device=dev), torch.empty((nv, cout), dtype=torch.float16, device=dev),
-                             torch.empty(nv, dtype=torch.float32, device=dev))
+                if il:
+                    out_split = (torch.empty((nv, 2 * cout), dtype=torch.float16, device=dev), None, torch.empty(nv, dtype=torch.float32, device=dev))
+                else:
+                    out_split = (torch.empty((nv, cout), dtype=torch.float16, device=dev), torch.empty((nv, cout), dtype=torch.float16, device=dev),
+                                 torch.empty(nv, dtype=torch.float32, device=dev))
             y = ops.sparse_conv_f16x3(x, ctx["pairs"], w[0], w[1], scale, shift, residual=residual, relu=True,
                                       x_split=x_split[:2] if x_split is not None else None,
                                       out_split=out_split[:2] if out_split is not None else None,
@@ -133,13 +139,15 @@ class StudentWeights:
         # On the fast path a block's input is added back from the SPLIT PLANES its first convolution reads (hi + lo) * row scale -- the
         # value that convolution multiplies with -- so no layer writes fp32 rows unless the dense output layer needs them (no fused head).
         planes_res = fast and self.residual_from_planes
-        h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast, want_f32=not planes_res)
+        # ... and every layer but the last writes its output as INTERLEAVED rows (the dense head reads separate planes)
+        il = planes_res and self.interleaved_rows
+        h, hs = self._conv(0, x, ctx, x_split=xs, want_split=fast, want_f32=not planes_res, il=il)
         for b in range(self.num_blocks):
-            t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast, want_f32=not fast)   # conv1 output: next conv only
+            t, ts = self._conv(1 + 2 * b, h, ctx, x_split=hs, want_split=fast, want_f32=not fast, il=il)   # conv1 output: next conv only
             last = b == self.num_blocks - 1
             head = last and fast and self.head is not None          # the output layer reads the split planes only
             h, hs = self._conv(2 + 2 * b, t, ctx, residual=hs if planes_res else h, x_split=ts, want_split=fast and (not last or head),
-                               want_f32=not (head or (planes_res and not last)))
+                               want_f32=not (head or (planes_res and not last)), il=il and not last)
         self.last_pairs = ctx["pairs"]
         if mark is not None:
             mark("student convolutions")                  # (stage marks of bench.py's per-stage pass)

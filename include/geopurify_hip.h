@@ -175,7 +175,10 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          int32_t num_chunks, const int32_t *chunk_row_off_host, const int32_t *chunk_tile_off_host,
                          const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
                          const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, int32_t w_blocked,
-                         void *stream);
+                         int32_t plane_flags, void *stream);
+/* plane_flags (mask): 1 = x_hi is ONE tensor of INTERLEAVED rows, [cin / 32 steps][hi 32 | lo 32] halfs per row (ld_xh >= 2 cin; x_lo  */
+/* unused): the LDS-DMA kernel then stages a row and K step as ONE full 128-byte line instead of two half lines; 2 = y_hi receives the   */
+/* output in that form (y_lo unused; what the next layer reads); 4 = the residual planes res_hi come in that form.  0: separate planes. */
 /* w_blocked = 1: w_hi / w_lo come from gp_conv_weights_split_blocked -- the same halves as [kv][cout / 256][cin / 32][256][32]: a K   */
 /* step's 16 KiB of a column tile contiguous (one 1-KiB run per LDS-DMA instruction instead of 16 half lines), row rho of a tile =     */
 /* its column (rho & 128) | (rho & 15) << 3 | (rho >> 4 & 7).  cin % 32 == 0, cout % 256 == 0.  0: the [kv][cout][cin] halves above.    */

@@ -707,6 +707,17 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     res_back = (rh.float() + rl.float()) * rinv[:, None]
     assert (res_back - dev(res)).abs().max().item() <= 2.0 ** -22 * float(res.abs().max())
     assert (y3 - y2).abs().max().item() <= 2.0 ** -21 * float(res.abs().max()) + 1e-7
+    # INTERLEAVED rows ([K step][hi 32 | lo 32]: operand, output and residual as ONE tensor each; the LDS-DMA kernel stages full lines):
+    # the same arithmetic on the same values -- bit for bit the separate planes' result, and the output rows are the planes' halves
+    ys3 = tuple(torch.empty((Nv, 256), dtype=torch.float16, device="cuda") for _ in range(2))
+    y3b = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(rh, rl, rinv), relu=True, x_split=xs, out_split=ys3)
+    assert torch.equal(y3b, y3)
+    y_il = torch.full((Nv, 512), float("nan"), dtype=torch.float16, device="cuda")
+    y4 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(ops.interleave_planes(rh, rl), None, rinv), relu=True,
+                               x_split=(ops.interleave_planes(*xs), None), out_split=(y_il, None))
+    assert torch.equal(y4, y3)
+    h4, l4 = ops.deinterleave_planes(y_il)
+    assert torch.equal(h4, ys3[0]) and torch.equal(l4, ys3[1])
     from geopurify_amd._lib import GeoPurifyHipError
     lib_c = load()
     with pytest.raises(GeoPurifyHipError):
@@ -715,7 +726,7 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
                                          _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, Nv, 27, _ptr(hi), _ptr(lo), 96, 256,
                                          _ptr(pairs.partial), None, None, _ptr(dev(res)), 256, 1, _ptr(y3), 256, None, None, 0, int(pairs.num_chunks),
                                          pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off, None, None, _ptr(rh), _ptr(rl), rh.stride(0), _ptr(rinv),
-                                         int(hi.dim() == 5), _stream()), "gp_sparse_conv_f16x3")
+                                         int(hi.dim() == 5), 0, _stream()), "gp_sparse_conv_f16x3")
     assert (ys[0].float() + ys[1].float() - y2).abs().max() <= 2e-6 * max(1.0, float(y2.abs().max()))
     # chunk heights chosen from the kernel map (gp_conv_chunk_plan): every launch within the tile target, the chunk tables consistent
     # with the map, and -- a row's sum does not depend on which rows share its tiles -- the same bits
