@@ -132,6 +132,10 @@ def conv_ceilings(hp, dev):
         xs = ops.split_f16(x, c, per_row=True)
         ys = (torch.empty((nv, c), dtype=torch.float16, device=dev), torch.empty((nv, c), dtype=torch.float16, device=dev),
               torch.empty(nv, dtype=torch.float32, device=dev))
+        if getattr(st, "interleaved_rows", False) and getattr(st, "residual_from_planes", False):
+            # the form the student's layers hand each other: interleaved rows in, interleaved rows out
+            xs = (ops.interleave_planes(xs[0], xs[1]), None, xs[2])
+            ys = (torch.empty((nv, 2 * c), dtype=torch.float16, device=dev), None, ys[2])
         f = lambda: ops.sparse_conv_f16x3(None, pairs, w_hi, w_lo, scale, shift, relu=True, x_split=xs[:2], x_row_inv=xs[2],
                                           out_split=ys[:2], out_row_inv=ys[2], want_f32=False)
         lib.gp_debug_set(3, knob)
