@@ -1076,8 +1076,14 @@ __global__ void split_rows_scaled_kernel(const float *__restrict__ x, int64_t ld
             f16x4 h, l;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { h[k] = (_Float16)v[k]; l[k] = (_Float16)(v[k] - (float)h[k]); }
-            *reinterpret_cast<f16x4 *>(hi + r * ld_h + c) = h;
-            *reinterpret_cast<f16x4 *>(lo + r * ld_h + c) = l;
+            if (lo) {
+                *reinterpret_cast<f16x4 *>(hi + r * ld_h + c) = h;
+                *reinterpret_cast<f16x4 *>(lo + r * ld_h + c) = l;
+            } else {                                                   // interleaved rows: [32-column step][hi 32 | lo 32] in ONE tensor
+                _Float16 *ph = hi + r * ld_h + ((c >> 5) << 6) + (c & 31);
+                *reinterpret_cast<f16x4 *>(ph) = h;
+                *reinterpret_cast<f16x4 *>(ph + 32) = l;
+            }
         }
     }
 }
@@ -1269,7 +1275,8 @@ extern "C" int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n,
 
 extern "C" int gp_split_f16_scaled(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
                                    const float *scale, float *row_inv_scale, void *stream_) {
-    GP_CHECK_ARG(x && hi && lo && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0, "gp_split_f16_scaled: bad argument");
+    GP_CHECK_ARG(x && hi && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0, "gp_split_f16_scaled: bad argument");
+    GP_CHECK_ARG(lo || (d % 32 == 0 && ld_h >= 2 * (int64_t)d), "gp_split_f16_scaled: lo = NULL asks for interleaved rows in hi: d %% 32 == 0 and ld_h >= 2 d");
     GP_CHECK_ARG(!(scale && row_inv_scale), "gp_split_f16_scaled: one global scale OR per-row scales");
     int64_t waves = n < 16384 ? n : 16384;
     split_rows_scaled_kernel<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(

@@ -312,12 +312,20 @@ def conv_weights_shape(w_hi):
     return tuple(int(v) for v in w_hi.shape)
 
 
-def split_f16(x, d=None, scale=None, per_row=False):
+def split_f16(x, d=None, scale=None, per_row=False, interleaved=False):
     """fp32 rows -> (hi, lo) f16 rows with x * s = hi + lo.  Unscaled (s = 1): exact to 2^-22 relative only for |x| >= 2^-3
     (below that the lo half is a subnormal f16: absolute error 2^-25).  scale = device scalar from pow2_scale(): one power of
     two for the whole block; per_row=True: a power of two per row, returns (hi, lo, row_inv_scale)."""
     lib = _lib.load()
     d = x.shape[1] if d is None else d
+    if interleaved:
+        # (rows, None, row_inv_scale): per 32-column step [hi 32 | lo 32] in one tensor -- the operand form sparse_conv_f16x3 stages in full lines
+        assert per_row and d % 32 == 0, "interleaved rows are the row-scaled operand of the convolution"
+        rows = torch.empty((x.shape[0], 2 * d), dtype=torch.float16, device=x.device)
+        rinv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        check(lib.gp_split_f16_scaled(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(rows), None, rows.stride(0), None, _ptr(rinv), _stream()),
+              "gp_split_f16_scaled")
+        return rows, None, rinv
     hi = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
     lo = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
     if scale is None and not per_row:

@@ -123,7 +123,9 @@ class StudentWeights:
     def split_input(self, x):
         """The first layer's operand in the form the fast path stages it: (hi, lo, row_inv_scale) of x[:, :cin_pad].  Needs the voxel
         means only, so a scheduler can run it ahead (HotPath.prepare)."""
-        return ops.split_f16(x, self.cin_pad, per_row=True) if self.fast else None
+        if not self.fast:
+            return None
+        return ops.split_f16(x, self.cin_pad, per_row=True, interleaved=self.residual_from_planes and self.interleaved_rows)
 
     def forward(self, x, nbr_map, pairs=None, x_split=None, mark=None, planes=False):
         """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed].

@@ -161,6 +161,8 @@ int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, v
 /* no host sync; workspace >= 4 bytes).  gp_split_f16_scaled: hi + lo = x * s with s = *scale (global, nullable) or,   */
 /* when row_inv_scale != NULL, a per-row s(row) chosen the same way, row_inv_scale[row] = 1/s(row).  Exact (powers of  */
 /* two); consumers multiply back: gp_pool_mfma_apply(out_scale), gp_sparse_conv_f16x3(x_row_inv_scale).                */
+/* gp_split_f16_scaled with lo = NULL: INTERLEAVED rows into hi ([d / 32 steps][hi 32 | lo 32], ld_h >= 2 d): the operand  */
+/* form of gp_sparse_conv_f16x3's plane_flags bit 0.                                                                      */
 int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n, float *scale2, void *workspace,
                   size_t workspace_bytes, void *stream);
 int gp_split_f16_scaled(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,

@@ -718,6 +718,10 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     assert torch.equal(y4, y3)
     h4, l4 = ops.deinterleave_planes(y_il)
     assert torch.equal(h4, ys3[0]) and torch.equal(l4, ys3[1])
+    # the split kernel writes that form itself (lo = NULL): the same halves as its planes
+    ph, pl, pinv = ops.split_f16(dev(X), per_row=True)
+    rows, none_, rinv2 = ops.split_f16(dev(X), per_row=True, interleaved=True)
+    assert none_ is None and torch.equal(rinv2, pinv) and torch.equal(rows, ops.interleave_planes(ph, pl))
     from geopurify_amd._lib import GeoPurifyHipError
     lib_c = load()
     with pytest.raises(GeoPurifyHipError):
