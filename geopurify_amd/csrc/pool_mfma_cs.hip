@@ -465,8 +465,8 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
     auto issue = [&](i32x4 id, unsigned mk, int k, int slot) {
         unsigned char *dst = smem_raw + slot * CS_STAGE;
         const int ida = du ? id.y : id.x, idb = du ? id.w : id.z;
-        // Every stage is EXACTLY CS_DMA = 6 LDS-DMA instructions per wave, in every tuning mask: the hand-over's hand-counted
-        // `vmcnt(CS_DMA)` means "the older stage has landed" only then.  Tuning bit 1 (no row gather) and bit 3 (no weight
+        // Every stage is 4 row pieces + 2 fragment pieces IF the wave's group has a fragment in it, in every tuning mask: the hand-over's
+        // hand-counted `vmcnt` (handover_behind) means "the older stage has landed" only then.  Tuning bit 1 (no row gather) and bit 3 (no weight
         // fragments) therefore do not drop instructions, they make all lanes fetch ONE hot 16-byte piece instead (round 3
         // dropped them: the ceiling launches of bench.py handed a slot over with half of the older stage in flight, and the
         // 64-row kernel of pool_mfma.hip, whose row ids ride in the ring, read stale ids and faulted).
@@ -479,10 +479,18 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
         // would be; one instruction more than the real thing would issue), and the epilogue stores half of its lo bytes -- a price, not
         // a result
         cs_glds16<AUX>(x_lo + ((ablate & 128) ? 0 : s1), dst + CS_PLANE + (4 * wv) * CS_RB + 1024);
-        // an empty fragment is never read: all lanes fetch its first 16 bytes (one hot line)
-        const int lo = (((mk >> wv) & 1u) && !hot_w) ? lane * 8 : 0;
-        cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
-        cs_glds16(wal + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + CS_WPL + wv * 1024);
+        // an empty fragment (half of them on the S scene) is never read and -- round 5 -- never fetched: the wave issues 4 instead of 6
+        // instructions for that stage, and the hand-over that lets this stage stay in flight counts accordingly (cs_stage_dma below).
+        // (Rounds 3-5a fetched one hot piece instead, to keep the count fixed: a third of the loop's LDS-DMA instructions were dummies.)
+        if ((mk >> wv) & 1u) {
+            const int lo = hot_w ? 0 : lane * 8;
+            cs_glds16(wah + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + wv * 1024);
+            cs_glds16(wal + (int64_t)k * (CS_NG * 512) + lo, dst + CS_OFF_W + CS_WPL + wv * 1024);
+        }
+    };
+    // hand-over with the stage of mask `mk` (the youngest, issued by THIS wave) allowed to stay in flight: 4 row pieces + its fragment's 2
+    auto handover_behind = [&](unsigned mk) {
+        if ((mk >> wv) & 1u) cs_handover<CS_DMA>(); else cs_handover<CS_DMA - 2>();
     };
     auto load_ids = [&](int k) { return *reinterpret_cast<const i32x4 *>(idg + (int64_t)k * CS_KS); };
 
@@ -515,7 +523,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
         idv = load_ids(k2);
         mC = mkg[k2];
         asm volatile("" ::"s"(idv.x), "s"(idv.y), "s"(idv.z), "s"(idv.w), "s"(mC));   // (waited for here, not inside the loop)
-        cs_handover<CS_DMA>();
+        handover_behind(mB);                                   // stage 0 has landed; stage 1 may be in flight
     }
     if constexpr (STAMP) st_pro = cs_now();
     // Software pipeline (the fragment reads of all eight waves leave the barrier together and take ~500 cycles to come back;
@@ -611,7 +619,7 @@ cs_pool_body(const _Float16 *__restrict__ x_hi_, const _Float16 *__restrict__ x_
                 cs_wait_a(ah1, al1);
                 asm volatile("" ::"s"(idn.x), "s"(idn.y), "s"(idn.z), "s"(idn.w), "s"(mN));
                 if constexpr (STAMP) { st_b = cs_now(); st_work += st_b - st_a; }
-                if (s + 2 < n) cs_handover<CS_DMA>(); else cs_handover<0>();
+                if (s + 2 < n) handover_behind(mC); else cs_handover<0>();      // (mC: the stage issued in this step)
                 if constexpr (STAMP) st_wait += cs_now() - st_b;
                 mP = m; mA = mB; mB = mC; mC = mN; idv = idn;
             }
