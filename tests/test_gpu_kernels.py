@@ -718,6 +718,18 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     assert torch.equal(y4, y3)
     h4, l4 = ops.deinterleave_planes(y_il)
     assert torch.equal(h4, ys3[0]) and torch.equal(l4, ys3[1])
+    # ... and through the fp32-partial twin (knob 3 bit 5: the round 1-4 phase-2 kernel, four columns per lane) the same equality
+    assert lib.gp_debug_set(3, 32) == 0
+    try:
+        ys5 = tuple(torch.empty((Nv, 256), dtype=torch.float16, device="cuda") for _ in range(2))
+        y5 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(rh, rl, rinv), relu=True, x_split=xs, out_split=ys5)
+        y_il5 = torch.full((Nv, 512), float("nan"), dtype=torch.float16, device="cuda")
+        y6 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(ops.interleave_planes(rh, rl), None, rinv), relu=True,
+                                   x_split=(ops.interleave_planes(*xs), None), out_split=(y_il5, None))
+    finally:
+        assert lib.gp_debug_set(3, 0) == 0
+    h6, l6 = ops.deinterleave_planes(y_il5)
+    assert torch.equal(y6, y5) and torch.equal(h6, ys5[0]) and torch.equal(l6, ys5[1])
     # the split kernel writes that form itself (lo = NULL): the same halves as its planes
     ph, pl, pinv = ops.split_f16(dev(X), per_row=True)
     rows, none_, rinv2 = ops.split_f16(dev(X), per_row=True, interleaved=True)
