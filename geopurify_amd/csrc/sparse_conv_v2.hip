@@ -274,6 +274,36 @@ __device__ __forceinline__ void mma_step_f16x3_off(const unsigned char *smem, co
         for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
     }
 }
+// The step in two parts around the stage hand-over (the PIPE schedules of conv_phase1_dma_body).  head: every LDS read of the stage and
+// the hi*hi / hi*lo terms; tail: the lo*hi terms, on registers only (al, bh stay live across the hand-over) -- the matrix work a wave
+// still has in hand when it leaves the barrier.  Per accumulator the order is hi*hi, hi*lo, lo*hi as in mma_step_f16x3_off: same bits.
+template <int NRT>
+__device__ __forceinline__ void mma_head_f16x3_off(const unsigned char *smem, const uint32_t (&fa_hi)[4], const uint32_t (&fa_lo)[4],
+                                                   uint32_t a_off, const V2Smem &sm, int buf, int wn, int fl, int fsw, f32x4 (&acc)[4][8],
+                                                   f16x8 (&al)[NRT > 0 ? NRT : 1], f16x8 (&bh)[8]) {
+    f16x8 ah[NRT > 0 ? NRT : 1];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8 *>(smem + fa_hi[i] + a_off);
+        al[i] = *reinterpret_cast<const f16x8 *>(smem + fa_lo[i] + a_off);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8 *>(&sm.b_hi[buf][wn * 128 + j * 16 + fl][fsw]);
+        f16x8 bl = *reinterpret_cast<const f16x8 *>(&sm.b_lo[buf][wn * 128 + j * 16 + fl][fsw]);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+    }
+}
+template <int NRT, int J0, int J1>
+__device__ __forceinline__ void mma_tail_f16x3(f32x4 (&acc)[4][8], const f16x8 (&al)[NRT > 0 ? NRT : 1], const f16x8 (&bh)[8]) {
+#pragma unroll
+    for (int j = J0; j < J1; ++j)
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+}
 // grid.x = (#m-tiles upper bound) * n_tiles ; tile -> offset k by a search in tile_off (device)
 // (TUNE: the tuning bits of `ablate_` -- knob 3 -- are honoured; the product instantiation compiles them out)
 template <bool TUNE>
@@ -408,16 +438,29 @@ __device__ __forceinline__ uint64_t cv_real() {
     return t;
 }
 
-// STAMP (tuning twin only): wave 0 of every workgroup writes 10 x uint64 into `stamp`: {real-time start, real-time length, prologue
+// STAMP (tuning twin only): waves 0 and 4 of every workgroup write 16 x uint64 into `stamp` (wave 0: [0..11], wave 4: [12..15] = its DMA-issue / wait / barrier cycles and HW_ID): {real-time start, real-time length, prologue
 // (descriptor + row ids + first stage landed), K loop, partial-store ISSUE, store drain (vmcnt(0)), whole tile -- shader cycles --,
-// XCC id | pairs << 8, cycles of the loop spent issuing LDS-DMA, cycles of the loop spent in the end-of-step wait + barrier}
+// XCC id | pairs << 8, cycles of the loop spent issuing LDS-DMA, in the hand-over's `s_waitcnt`, in its `s_barrier`, HW_ID}
 // Round-4 stamps of this loop (scripts/stamp_conv.py, profiles/r04_conv_stamps.log): per step 550-820 cycles of DMA issue during
 // which neither wave of a SIMD feeds the matrix pipe, 2 150 of reads + MFMA, 1 850 waiting at the barrier for the SIMD partner's
 // MFMAs -- 4 550-4 800 cycles for 3 072 cycles of matrix work.  Measured and left out: waves 0-3 issue ALL of a stage's LDS-DMA (64 rows of each operand), waves 4-7 none, so that a SIMD's second wave
 // multiplies while the first absorbs the memory pipeline's back-pressure: the step falls to 4 150 cycles (-8.6 %), the in-kernel
 // clock from 2.04 to 1.99 GHz, and the layer takes the same 1.929 ms -- on all-zero operands the same cycle count runs at
 // 2.37 GHz and 1.664 ms: the layer is bound by the clock the chip holds under this load, not by the schedule.
-template <bool TUNE, bool STAMP>
+// PIPE (round 6): the order of a step's work around the stage hand-over.
+//   0  rounds 1-5: issue the next stage's LDS-DMA at the top of the step, multiply, `vmcnt(0)` + barrier.  The compiler sinks half of
+//      the step's MFMAs below the barrier, so a stage's DMA is issued ~48 MFMAs AFTER the barrier that freed its slot and has only
+//      the other half of a step to land; all eight waves issue DMA at once (the matrix pipes idle meanwhile) and meet at once.
+//   1  the hand-over sits between a step's LDS reads (head: hi*hi, hi*lo) and its register-only tail (lo*hi); the DMA of stage
+//      s + 2 is issued RIGHT AFTER barrier s into the slot that barrier freed -- a full step in flight instead of half of one --
+//      and the tail's 32 MFMAs follow it.
+//   2  the same, and the two waves of a SIMD (wave w and w + 4) take the two orders: waves 0-3 issue their DMA first, waves 4-7
+//      multiply their tail first -- one wave of every SIMD feeds the matrix pipe while the other sits in the memory pipeline's queue.
+//   3  (interleaved rows + step-blocked weights only) waves 0-3 stage ALL of a stage -- 64 rows of each operand, 16 LDS-DMA instructions
+//      each, right after the barrier -- and waves 4-7 none: the wave the SIMD's arbiter prefers (the older one: wave w over w + 4) sits in
+//      the memory pipeline's queue while its partner multiplies alone, then overtakes it; both reach the next barrier together.
+// Same products in the same order per accumulator in every form: bit-identical partial rows.
+template <bool TUNE, bool STAMP, int PIPE = 0>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
                      const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
@@ -427,7 +470,7 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
                      const float *__restrict__ x_inv_scale, uint64_t *__restrict__ stamp, int64_t q_e_off, int w_blocked, int x_il) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ablate = TUNE ? ablate_ : 0;
-    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0, st_dma = 0, st_wait = 0;
+    uint64_t st_t0 = 0, st_r0 = 0, st_pro = 0, st_loop = 0, st_iss = 0, st_dma = 0, st_wait = 0, st_bar = 0;
     if constexpr (STAMP) { st_t0 = cv_now(); st_r0 = cv_real(); }
     V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -498,8 +541,38 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         if (w_blocked) gb_hi[t] = w_hi + ((((int64_t)k * n_tiles + nt) * (cin / TK)) * TN + row) * TK + q;
     }
     const int bmul = w_blocked ? TN : 1;                      // halfs of the weight operand between two K steps, over TK
+    // PIPE 3: waves 0-3 stage 64 rows of each operand (x_il && w_blocked: checked on the host).  Gathered rows as 32-bit byte offsets
+    // from the uniform base (the host checks nv * row bytes < 4 GiB); a wave's four weight instructions per plane are 1 KiB apart.
+    uint32_t goff3[8];
+    int in_rows3[8];
+    const _Float16 *gb3 = nullptr;
+    if constexpr (PIPE == 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (wv & 3) * 64 + i * 8 + (lane >> 3);
+            const int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];
+            in_rows3[i] = in_row;
+            const int L = (lane & 7) ^ ((row >> 1) & 7);
+            goff3[i] = (uint32_t)in_row * (uint32_t)(ld_xh * 2) + (uint32_t)L * 16u;
+        }
+        gb3 = w_hi + ((((int64_t)k * n_tiles + nt) * (cin / TK)) * TN + (wv & 3) * 64 + lrow) * TK + q;
+    }
     auto issue = [&](int c0, int buf) {
         if (!issuer) return;
+        if constexpr (PIPE == 3) {
+            if (wv >= 4) return;
+            const unsigned char *xb = reinterpret_cast<const unsigned char *>(x_hi) + (size_t)c0 * 4;       // a K step = 128 bytes of a row
+            unsigned char *lA = smem_raw + (uint32_t)buf * a_bufstride + (uint32_t)(wv * 64) * 128u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) glds16(xb + goff3[i], lA + i * 1024);
+            const _Float16 *wb = gb3 + (int64_t)c0 * TN;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                glds16(wb + t * 16 * TK, &sm.b_hi[buf][wv * 64 + t * 16][0]);
+                glds16(wb + db + t * 16 * TK, &sm.b_lo[buf][wv * 64 + t * 16][0]);
+            }
+            return;
+        }
         const uint32_t ab = (uint32_t)buf * a_bufstride;
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
@@ -544,65 +617,176 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     // behind the first stage's DMA -- and park it in LDS behind the ring; the epilogue reads its 16 from there.  (Rounds 4-5 gathered
     // row id + scale per lane and (i, r): 32 loads per lane in front of the second stage's DMA, 16 registers live through the loop.)
     float *s_rinv = reinterpret_cast<float *>(smem_raw + sizeof(V2Smem));
-    if (x_il) {
+    // (PIPE: the second stage rides behind the scale loads -- both ring slots are free -- and the scales are parked by an LDS store the
+    // compiler does not see: a visible one waits for EVERY LDS-DMA in flight, i.e. for the second stage)
+    const uint32_t rinv_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw + (uint32_t)sizeof(V2Smem);
+    auto park = [&](int idx, float v) {
+        if constexpr (PIPE != 0) asm volatile("ds_write_b32 %0, %1" ::"v"(rinv_a + (uint32_t)idx * 4u), "v"(v) : "memory");
+        else s_rinv[idx] = v;
+    };
+    // (PIPE: scale loads, second stage, wait and LDS stores are hand-ordered -- inline-asm loads the compiler does not count: it would
+    // drain the ring, `vmcnt(0)`, wherever one of their registers is touched.  Without scales the loads read the pair list, a valid
+    // array of >= nv words, and the value is replaced; a one-step layer stages step 0 twice: straight-line code either way.)
+    const float *rinv_src = (PIPE != 0 && !x_inv_scale) ? reinterpret_cast<const float *>(pair_in) : x_inv_scale;
+    auto load_rinv = [&](int row) -> float {
+        if constexpr (PIPE != 0) {
+            float v;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(rinv_src + row) : "memory");
+            return v;
+        } else {
+            return x_inv_scale ? x_inv_scale[row] : 1.f;
+        }
+    };
+    if constexpr (PIPE == 3) {
+        float rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rv[i] = load_rinv(in_rows3[i]);         // (waves 4-7 too: clamped rows, values unused)
+        issue(steps > 1 ? TK : 0, 1);
+        // waves 0-3: stage 0 (16 operations) and the 8 scale loads have landed, stage 1 (16) stays in flight; waves 4-7: the scale loads
+        if (wv < 4) asm volatile("s_waitcnt vmcnt(16)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
+        if (wv < 4 && (lane & 7) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) park(wv * 64 + i * 8 + (lane >> 3), x_inv_scale ? rv[i] : 1.f);
+        }
+    } else if (x_il) {
         float rv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rv[i] = x_inv_scale ? x_inv_scale[in_rows[i]] : 1.f;
+        for (int i = 0; i < 4; ++i) rv[i] = load_rinv(in_rows[i]);
+        if constexpr (PIPE != 0) {
+            issue(steps > 1 ? TK : 0, 1);
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = x_inv_scale ? rv[i] : 1.f;
+        }
         if ((lane & 7) == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_rinv[wv * RPW + i * 8 + (lane >> 3)] = rv[i];
+            for (int i = 0; i < 4; ++i) park(wv * RPW + i * 8 + (lane >> 3), rv[i]);
         }
     } else {
         float rv[NI];
 #pragma unroll
-        for (int t = 0; t < NI; ++t) rv[t] = x_inv_scale ? x_inv_scale[in_rows[2 * t]] : 1.f;
+        for (int t = 0; t < NI; ++t) rv[t] = load_rinv(in_rows[2 * t]);
+        if constexpr (PIPE != 0) {
+            issue(steps > 1 ? TK : 0, 1);
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(rv[0]), "+v"(rv[1])::"memory");
+#pragma unroll
+            for (int t = 0; t < NI; ++t) rv[t] = x_inv_scale ? rv[t] : 1.f;
+        }
         if (lp == 0) {
 #pragma unroll
-            for (int t = 0; t < NI; ++t) s_rinv[wv * RPW + t * 16 + lrow] = rv[t];
+            for (int t = 0; t < NI; ++t) park(wv * RPW + t * 16 + lrow, rv[t]);
         }
     }
-    __syncthreads();
+    // hand-over: `s_waitcnt vmcnt(N) lgkmcnt(0)` (this wave's LDS reads and scale stores are done; all but its N youngest vector-memory
+    // operations -- they complete in order -- have landed) and the workgroup's barrier.  STAMP: the two waits timed apart.
+    auto handover = [&](auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        if constexpr (STAMP) {
+            const uint64_t a = cv_now();
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+            const uint64_t b = cv_now();
+            asm volatile("s_barrier" ::: "memory");
+            st_wait += b - a;
+            st_bar += cv_now() - b;
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+        }
+    };
+    if constexpr (PIPE != 0) {
+        // stage 0 has landed; stage 1 (this wave's 8 -- PIPE 3: 16 or no -- youngest operations) stays in flight
+        if constexpr (PIPE == 3) handover(std::integral_constant<int, 16>{});
+        else handover(std::integral_constant<int, 8>{});
+        st_wait = st_bar = 0;
+    } else {
+        __syncthreads();
+    }
     if constexpr (STAMP) st_pro = cv_now();
     // the last tile of a (chunk, offset) segment is partly filled (8192-row chunks: 1 tile in 9, a third full on average): a
     // wave multiplies only the 16-row tiles that hold pairs -- matrix work the chip's power budget does not have to pay for.
     // nrt is wave-uniform and fixed for the tile: one copy of the loop per value (a switch INSIDE the loop costs 98 spills).
-    auto k_loop = [&](auto nrt_c) {
+    auto k_loop = [&](auto nrt_c, auto role_c) {
         constexpr int NRT = decltype(nrt_c)::value;
-        for (int s = 0; s < steps; ++s) {
-            const int buf = s & 1;
-            uint64_t st_a = 0;
-            if constexpr (STAMP) st_a = cv_now();
-            if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
-            if constexpr (STAMP) st_dma += cv_now() - st_a;
-            if constexpr (NRT > 0)
-                if (!(ablate & 2)) mma_step_f16x3_off<NRT>(smem_raw, fa_hi, fa_lo, (uint32_t)buf * a_bufstride, sm, buf, wn, fl, fsw, acc);
-            if constexpr (STAMP) st_a = cv_now();
-            __syncthreads();
-            if constexpr (STAMP) st_wait += cv_now() - st_a;
+        if constexpr (PIPE != 0) {
+            // waves w and w + 4 share a SIMD (checked with HW_REG_HW_ID in the stamped twin): PIPE 2 gives them the two orders
+            // (one copy of the loop per order: a run-time switch inside the loop spills)
+            constexpr bool tail_first = PIPE == 2 && decltype(role_c)::value;
+            constexpr bool no_dma = PIPE == 3 && decltype(role_c)::value;          // (PIPE 3: waves 4-7 stage nothing)
+            f16x8 al[NRT > 0 ? NRT : 1], bh[8];
+            for (int s = 0; s < steps; ++s) {
+                const int buf = s & 1;
+                if constexpr (NRT > 0)
+                    if (!(ablate & 2)) mma_head_f16x3_off<NRT>(smem_raw, fa_hi, fa_lo, (uint32_t)buf * a_bufstride, sm, buf, wn, fl, fsw, acc, al, bh);
+                __builtin_amdgcn_sched_barrier(0);
+                // stage s + 1 (issued one step ago) has landed, every wave is done reading stage s
+                handover(std::integral_constant<int, 0>{});
+                uint64_t st_a = 0;
+                if constexpr (tail_first) {
+                    if constexpr (NRT > 0)
+                        if (!(ablate & 2)) mma_tail_f16x3<NRT, 0, 8>(acc, al, bh);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (STAMP) st_a = cv_now();
+                    if (s + 2 < steps) issue((s + 2) * TK, buf);
+                    if constexpr (STAMP) st_dma += cv_now() - st_a;
+                } else {
+                    if constexpr (STAMP) st_a = cv_now();
+                    if constexpr (!no_dma) { if (s + 2 < steps) issue((s + 2) * TK, buf); }
+                    if constexpr (STAMP) st_dma += cv_now() - st_a;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (NRT > 0)
+                        if (!(ablate & 2)) mma_tail_f16x3<NRT, 0, 8>(acc, al, bh);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int s = 0; s < steps; ++s) {
+                const int buf = s & 1;
+                uint64_t st_a = 0;
+                if constexpr (STAMP) st_a = cv_now();
+                if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
+                if constexpr (STAMP) st_dma += cv_now() - st_a;
+                if constexpr (NRT > 0)
+                    if (!(ablate & 2)) mma_step_f16x3_off<NRT>(smem_raw, fa_hi, fa_lo, (uint32_t)buf * a_bufstride, sm, buf, wn, fl, fsw, acc);
+                if constexpr (STAMP) handover(std::integral_constant<int, 0>{});
+                else __syncthreads();
+            }
         }
     };
-    if (nrt == 4) k_loop(std::integral_constant<int, 4>{});
-    else if (nrt == 3) k_loop(std::integral_constant<int, 3>{});
-    else if (nrt == 2) k_loop(std::integral_constant<int, 2>{});
-    else if (nrt == 1) k_loop(std::integral_constant<int, 1>{});
-    else k_loop(std::integral_constant<int, 0>{});
+    auto k_loops = [&](auto role_c) {
+        if (nrt == 4) k_loop(std::integral_constant<int, 4>{}, role_c);
+        else if (nrt == 3) k_loop(std::integral_constant<int, 3>{}, role_c);
+        else if (nrt == 2) k_loop(std::integral_constant<int, 2>{}, role_c);
+        else if (nrt == 1) k_loop(std::integral_constant<int, 1>{}, role_c);
+        else k_loop(std::integral_constant<int, 0>{}, role_c);
+    };
+    if ((PIPE == 2 || PIPE == 3) && wv >= 4) k_loops(std::true_type{});
+    else k_loops(std::false_type{});
     if constexpr (STAMP) st_loop = cv_now();
     auto stamp_out = [&]() {
         if constexpr (STAMP) {
             st_iss = cv_now();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint64_t t3 = cv_now(), r3 = cv_real();
-            if (tid == 0 && stamp) {
-                uint64_t *o = stamp + (int64_t)blockIdx.x * 10;
-                unsigned xcc;
+            if ((tid == 0 || tid == 256) && stamp) {
+                uint64_t *o = stamp + (int64_t)blockIdx.x * 16;
+                unsigned xcc, hwid;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_loop - st_pro; o[4] = st_iss - st_loop;
-                o[5] = t3 - st_iss; o[6] = t3 - st_t0; o[7] = (uint64_t)(xcc & 0xff) | ((uint64_t)cnt << 8);
-                o[8] = st_dma; o[9] = st_wait;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                if (tid == 0) {
+                    o[0] = st_r0; o[1] = r3 - st_r0; o[2] = st_pro - st_t0; o[3] = st_loop - st_pro; o[4] = st_iss - st_loop;
+                    o[5] = t3 - st_iss; o[6] = t3 - st_t0; o[7] = (uint64_t)(xcc & 0xff) | ((uint64_t)cnt << 8);
+                    o[8] = st_dma; o[9] = st_wait; o[10] = st_bar; o[11] = hwid;
+                } else {                                  // wave 4: the SIMD partner of wave 0 (its HW_ID says so)
+                    o[12] = st_dma; o[13] = st_wait; o[14] = st_bar; o[15] = hwid;
+                }
             }
         }
     };
     if (ablate & 8) { stamp_out(); return; }
+    // (tuning bit 8 of knob 3, 256: the tiles of the CENTRE offset -- the identity map, 13.5 % of the pairs -- multiply and store nothing, and
+    // phase 2's twin does not read their rows: the price of those partial rows' round trip, i.e. the most a fold of the centre offset into
+    // phase 2 could return)
+    if ((ablate & 256) && k == (kv >> 1)) { stamp_out(); return; }
     // ---- epilogue: accumulators straight to the partial buffer (no LDS staging: that made every slice's LDS reads wait for the
     //      previous slice's stores -- one vector-memory counter -- 4 store round trips per tile, a third of the kernel's time).
     // PARTIAL ROWS ARE STORED AS 24-BIT BLOCK FLOATING POINT (round 5): per pair row and 128-column quarter (= what one wave owns) an
@@ -694,6 +878,13 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 __global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
 __global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false>(P1_FWD); }
 __global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true>(P1_FWD); }
+// the PIPE schedules (see conv_phase1_dma_body)
+__global__ void __launch_bounds__(NT2) conv_phase1_pipe1_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, 1>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_pipe2_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, 2>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_pipe3_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, 3>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_pipe3_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, 3>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_pipe1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, 1>(P1_FWD); }
+__global__ void __launch_bounds__(NT2) conv_phase1_pipe2_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, 2>(P1_FWD); }
 
 #undef P1_PARAMS
 #undef P1_FWD
@@ -929,7 +1120,7 @@ __device__ __forceinline__ void conv_gather_sum_q24(const unsigned char *__restr
     }
 }
 
-template <bool WIDE /* cout > 512: a second register set for columns 512 .. */>
+template <bool WIDE /* cout > 512: a second register set for columns 512 .. */, bool NO_CENTRE = false /* tuning twin: see knob 3, 256 */>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, const int32_t *__restrict__ pair_pos, int64_t nv,
                        int kv, int cout, const float *__restrict__ scale, const float *__restrict__ shift,
@@ -949,7 +1140,8 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
     int64_t u = row_begin + wave0;
     if (u >= row_end) return;
     const bool rowscale = y_inv_scale && y_hi && cout <= 1024;
-    int mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u] : -1;
+    const int kv_read = NO_CENTRE ? (kv >> 1) : -1;          // (twin: the lane of the centre offset reads nothing)
+    int mypos_next = (lane < kv && lane != kv_read) ? pair_pos[(int64_t)lane * nv + u] : -1;
     // the affine epilogue's scale / shift of this lane's first eight columns: the same for every row of the walk -- loaded once
     // (in the loop they were 4 KiB of L1 requests per output row beside the row's 11 KiB of partial rows)
     float sc0[8], sh0[8];
@@ -965,7 +1157,7 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
     }
     for (; u < row_end; u += n_waves) {
         const int mypos = mypos_next;
-        if (u + n_waves < row_end) mypos_next = (lane < kv) ? pair_pos[(int64_t)lane * nv + u + n_waves] : -1;
+        if (u + n_waves < row_end) mypos_next = (lane < kv && lane != kv_read) ? pair_pos[(int64_t)lane * nv + u + n_waves] : -1;
         float av[WIDE ? 2 : 1][8];
         float amax = 0.f;
         // columns [0, 512) and [512, 1024) with static register sets (the row-scaled split needs the whole row before its first store);
@@ -1319,6 +1511,12 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_SMEM_ATTR(conv_phase1_dma_kernel, P1_DMA_SMEM);
     GP_SMEM_ATTR(conv_phase1_tuning_kernel, P1_DMA_SMEM);
     GP_SMEM_ATTR(conv_phase1_stamp_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_pipe1_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_pipe2_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_pipe1_stamp_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_pipe3_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_pipe3_stamp_kernel, P1_DMA_SMEM);
+    GP_SMEM_ATTR(conv_phase1_pipe2_stamp_kernel, P1_DMA_SMEM);
 
     // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
     // blockIdx * 8 (a chunk overwrites the previous one's: the last chunk of the last call stays)
@@ -1376,15 +1574,23 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                      (long long)chunk_pairs, cout);
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            int pipe = (g_conv_ablate & 128) ? 2 : ((g_conv_ablate & 64) ? 1 : 0);   // bits 6 / 7: the PIPE schedules (host choice of kernel)
+            if ((g_conv_ablate & 192) == 192) pipe = ((plane_flags & 1) && w_blocked && nv * ld_xh * 2 < ((int64_t)1 << 32)) ? 3 : 2;
+            const int tune = g_conv_ablate & ~(16 | 64 | 128);          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off, w_blocked, plane_flags & 1
             if (dma_path) {
-                GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 10 * sizeof(uint64_t),
+                GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 16 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
-                             g_gp_debug_bytes[1], (size_t)nblocks * 10 * sizeof(uint64_t));
-                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                             g_gp_debug_bytes[1], (size_t)nblocks * 16 * sizeof(uint64_t));
+                if (stamp && pipe == 3) conv_phase1_pipe3_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (pipe == 3 && !tune) conv_phase1_pipe3_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (stamp && pipe == 2) conv_phase1_pipe2_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (stamp && pipe == 1) conv_phase1_pipe1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (pipe == 2 && !tune) conv_phase1_pipe2_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                else if (pipe == 1 && !tune) conv_phase1_pipe1_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
                 else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
                 else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
             } else {
@@ -1407,7 +1613,8 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
 #define P2Q_ARGS reinterpret_cast<const unsigned char *>(partial), q_e_off, pair_pos, nv, kv, cout, scale, shift, residual, ld_res, \
                  relu, y, ld_y, static_cast<_Float16 *>(y_hi), static_cast<_Float16 *>(y_lo), ld_yh, row_begin, row_count, pair_base, y_row_inv_scale, \
                  static_cast<const _Float16 *>(res_hi), static_cast<const _Float16 *>(res_lo), ld_rh, res_row_inv_scale, plane_flags
-        if (q24 && cout > 512) conv_phase2_q24_kernel<true><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
+        if (q24 && cout <= 512 && (g_conv_ablate & 256)) conv_phase2_q24_kernel<false, true><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
+        else if (q24 && cout > 512) conv_phase2_q24_kernel<true><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
         else if (q24) conv_phase2_q24_kernel<false><<<p2_grid, 256, 0, s>>>(P2Q_ARGS);
 #undef P2Q_ARGS
         else

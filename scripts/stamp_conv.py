@@ -54,13 +54,13 @@ def stamped(label, X, W, pairs, abl):
     t = timeit(run, 16)
     print(f"{label:18s} knob3={abl:3d} chunks {pairs.num_chunks:2d}: layer {t:7.3f} ms", flush=True)
     nblk = 1 << 16
-    buf = torch.zeros(nblk * 10, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
     assert lib.gp_debug_ptr(1, buf.data_ptr(), buf.numel() * 8) == 0
     run(); torch.cuda.synchronize()
     buf.zero_()
     run(); torch.cuda.synchronize()
     lib.gp_debug_ptr(1, None, 0); lib.gp_debug_set(3, 0)
-    s = buf.cpu().numpy().reshape(-1, 10).astype(np.float64)
+    s = buf.cpu().numpy().reshape(-1, 16).astype(np.float64)
     s = s[s[:, 6] > 0]                                     # workgroups of the LAST chunk launches that owned a tile
     real_us, pro, loop, iss, drain, tot = s[:, 1] / 100.0, s[:, 2], s[:, 3], s[:, 4], s[:, 5], s[:, 6]
     clk = tot / (s[:, 1] / 100.0) / 1e3                    # GHz: shader cycles per 100-MHz real-time tick
