@@ -55,6 +55,8 @@ def parse():
                     help="both: after the headline run also time the DROP-IN call SonataXAffinityTrainer.evaluate_scene(20-tuple of "
                          "CPU tensors) (run/validation.py:408), reported as the extra object `api_tuple` -- never as `value`")
     ap.add_argument("--scenes", type=int, default=2, help="distinct synthetic scenes rotated through the steps")
+    ap.add_argument("--time-every", type=int, default=3, help="HIP-event pairs around the pooling launches and the convolution layers of every "
+                    "N-th timed scene (1 = every scene: the pairs then cost 1.1 %% of the rate)")
     ap.add_argument("--streams", type=int, default=2, help="--schedule alternate: HIP streams that consecutive scenes alternate over "
                     "(1 = everything on one stream); --schedule split always uses two")
     ap.add_argument("--schedule", default="auto", choices=["auto", "split", "alternate"],
@@ -712,6 +714,8 @@ def main():
         with torch.cuda.stream(streams[0]):
             if after is not None:
                 streams[0].wait_event(after)
+            else:
+                streams[0].wait_stream(streams[1])
             e_first = mk()
             batch = pl.build_scene_batch(scenes[j], rigids[j], dev)
             e_load, h1 = mk(), time.perf_counter()
@@ -722,8 +726,11 @@ def main():
             done.record(streams[0])
         if tl:      # GP_BENCH_TIMELINE=1: where the look-ahead ran relative to the student it was meant to run beside
             timeline.append({"after": after, "gpu": (e_first, e_load, e_lift, done), "host": (h0, h1, h2, time.perf_counter())})
-        for t in _tensors([batch, F, text, prep]):      # the consumer stream: the allocator keeps the blocks until its kernels ran
-            t.record_stream(streams[1])
+        # No record_stream on these tensors (round 6): the allocator answered each with an event record on the consumer stream when the block
+        # was freed -- ~40 markers in a row at every scene boundary, 0.14 ms in which streams[1] ran nothing (rocprofv3 kernel trace,
+        # profiles/r06_scene_boundary_gap.log).  The blocks are safe without: they belong to streams[0], and every LATER kernel of streams[0] sits
+        # behind `after` -- the start of the NEXT refine on streams[1], i.e. behind every kernel of the scene that used them (or, for a scene
+        # that was not lifted ahead, behind the whole of streams[1]: the wait_stream above).
         pending[i] = (batch, F, text, scale, done, prep)
 
     def _step_split(i, prefetch):
@@ -806,13 +813,18 @@ def main():
     log("timing")
     counts.zero_()
     fork_streams()                                    # the side streams start after the zeroing (default stream)
-    pool_timer.enabled = conv_timer.enabled = True
+    # HIP-event pairs around every pooling launch and every convolution layer of EVERY --time-every-th scene of the timed region: a
+    # pair costs ~8 us of stream time (the marker waits for the kernel in front of it and holds the one behind), 56 pairs per scene =
+    # 0.24 ms = 1.1 % of the scene when every scene is timed (profiles/r06_event_pairs_price.log); the default, every 3rd scene (both rotated
+    # scenes take their turn), still prices 152 pooling launches of a 24-scene timed region
+    timers_on = os.environ.get("GP_BENCH_NO_TIMERS") != "1"
     t0 = time.perf_counter()
     last = None
     n_local = args.steps if args.scenes else 0
     host_t["hook"] = 0.0
     for i in range(n_local):
         t_s = time.perf_counter()
+        pool_timer.enabled = conv_timer.enabled = timers_on and i % max(args.time_every, 1) == 0
         last = step(i, prefetch=i + 1 < n_local)
         host_t["step"] += time.perf_counter() - t_s
     join_streams()                                    # every scene's histogram atomics precede the collective
@@ -861,6 +873,7 @@ def main():
         D = cfg.feat_dim
         per_row = 2 * D * 4 + 96 * 8                      # algorithmic bytes per voxel row and application of A
         tot_ms, tot_rows = pool_timer.totals()
+        tot_ms = tot_ms or float("nan")                 # (GP_BENCH_NO_TIMERS=1: nothing was timed)
         n_launch = max(len(pool_timer.events), 1)
         pool_ms = tot_ms / n_launch                       # mean launch duration and mean algorithmic bytes per launch over the
         pool_bytes_mean = tot_rows / n_launch * per_row   # timed launches (scenes differ in size): achieved = their ratio
@@ -953,7 +966,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), **pmc_traffic(hp.stats["pool_kernel"], int(round(tot_rows / n_launch))),
                          "algorithmic_bytes_per_launch": int(round(pool_bytes_mean)), "avg_launch_ms": round(pool_ms, 5),
-                         "launches": n_launch,
+                         "launches": n_launch, "timed_every_nth_scene": args.time_every,
                          "launch_ms_p10": round(p10, 5), "launch_ms_p50": round(p50, 5), "launch_ms_p90": round(p90, 5),
                          "avg_launch_ms_isolated": round(pool_ms_alone, 4),
                          "isolated_passes_ms": [round(a, 4) for a in alone],
