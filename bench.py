@@ -259,7 +259,7 @@ def training_step_rate(batch, dev, sd, steps=6):
             "roofline_train": roof}
 
 
-def api_tuple_rate(batches, vlms, sd, cfg, pool_iters, dev, steps=4):
+def api_tuple_rate(batches, vlms, sd, cfg, pool_iters, dev, steps=20, side_stream=None):
     """Throughput of the drop-in entry point itself (run/validation.py:408-411): the reference's DataLoader hands
     `evaluate_scene` the positional 20-tuple of CPU tensors (scene_based_collate_fn).  The same scenes as the headline run,
     as pinned-host tuples (points, colours + normals, labels, per-view lists, the [V*N,2] visibility table, the V RGB images:
@@ -325,9 +325,64 @@ def api_tuple_rate(batches, vlms, sd, cfg, pool_iters, dev, steps=4):
         run(i, d)
     torch.cuda.synchronize()
     pref = (time.perf_counter() - t0) / steps
+    # look-ahead: geopurify_amd.data_loader.LookAheadLoader around the loader -- it copies the next pinned tuple on its own stream and
+    # OFFERS the device tuple (SonataXAffinityTrainer.offer_next): parse, lift and prepare of the next scene run on the trainer's side
+    # stream beside this scene's student
+    from geopurify_amd.data_loader import LookAheadLoader
+    model.side_stream = side_stream                       # (this process's streams share four hardware queues: no new ones here)
+
+    class _Tuples:                                        # (stands in for the DataLoader: pinned 20-tuples, the scene's VLM set per scene)
+        def __init__(self, count):
+            self.count = count
+
+        def __len__(self):
+            return self.count
+
+        def __iter__(self):
+            for i in range(self.count):
+                yield src[i % n]
+    src = tuples
+    if os.environ.get("GP_API_DEVICE_TUPLES") == "1":     # (experiment: the tuples already on the device -- what does the copy cost the look-ahead?)
+        src = [tuple(x.to(dev) if torch.is_tensor(x) else x for x in t) for t in tuples]
+    marks = []
+    if os.environ.get("GP_API_TIMELINE") == "1":          # (tuning aid: where a scene's GPU time goes in the look-ahead form)
+        hp_api = model._hot_path()
+        orig_refine = hp_api.refine
+
+        def refine_marked(batch, F, after_student=None, prepared=None):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+
+            def hook():
+                ev[1].record()
+                if after_student is not None:
+                    after_student()
+                ev[2].record()
+            r = orig_refine(batch, F, after_student=hook, prepared=prepared)
+            ev[3].record()
+            marks.append((ev, prepared is not None))
+            return r
+        hp_api.refine = refine_marked
+    for rep in range(2):                                  # (the first pass warms the copy and side streams' allocator pools)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, d in enumerate(LookAheadLoader(_Tuples(steps), model, dev, copy_stream=copy_stream)):
+            off = getattr(model, "_offered", None)
+            if off is not None:                               # the synthetic 2D outputs are per scene: the offered scene's own
+                model._offered = (off[0], vlms[(i + 1) % n], off[2])
+            run(i, d)
+        torch.cuda.synchronize()
+        ahead = (time.perf_counter() - t0) / steps
+    for ev, pre in marks[-6:]:
+        log(f"api look-ahead, scene on the GPU (lifted ahead: {pre}): student {ev[0].elapsed_time(ev[1]):6.2f} ms, wait for the look-ahead "
+            f"{ev[1].elapsed_time(ev[2]):6.2f} ms, affinity + pooling + gather {ev[2].elapsed_time(ev[3]):6.2f} ms")
     return {"entry_point": "geopurify_amd.affinity_module.SonataXAffinityTrainer.evaluate_scene(20-tuple), run/validation.py:408",
             "serial": {"value": round(1.0 / serial, 3), "unit": "scenes/s", "ms_per_scene": round(serial * 1e3, 3)},
             "prefetched": {"value": round(1.0 / pref, 3), "unit": "scenes/s", "ms_per_scene": round(pref * 1e3, 3)},
+            "look_ahead": {"value": round(1.0 / ahead, 3), "unit": "scenes/s", "ms_per_scene": round(ahead * 1e3, 3),
+                           "what": "for batch_data in geopurify_amd.data_loader.LookAheadLoader(loader, model): evaluate_scene(batch_data) -- the next "
+                                   "pinned tuple copied on the wrapper's stream and offered (offer_next): parse + lift + prepare of the next scene "
+                                   "beside this scene's student; results bit-identical to the serial call"},
             "h2d_ms": round(h2d_ms, 3), "tuple_mbytes": round(nbytes / 1e6, 1), "steps": steps,
             "note": "pinned host tuples; loader math is not inside (the tuple carries its results); never the headline `value`"}
 
@@ -678,7 +733,7 @@ def main():
         main_prio = int(os.environ.get("GP_BENCH_MAIN_PRIORITY", "0"))
         streams = [torch.cuda.Stream(device=dev, priority=side_prio), torch.cuda.Stream(device=dev, priority=main_prio)]
     pending = {}                                        # scene index -> (batch, F, text, scale, lift-done event), lifted ahead
-    host_t = {"hook": 0.0, "step": 0.0}                 # host seconds inside the look-ahead hook / inside step() (timed region)
+    host_t = {"hook": 0.0, "step": 0.0, "blocked": 0.0, "readbacks": 0}      # host seconds inside the look-ahead hook / inside step() (timed region)
 
     def _tensors(obj):
         if torch.is_tensor(obj):
@@ -822,11 +877,13 @@ def main():
     last = None
     n_local = args.steps if args.scenes else 0
     host_t["hook"] = 0.0
+    ops.READBACK["seconds"], ops.READBACK["calls"] = 0.0, 0
     for i in range(n_local):
         t_s = time.perf_counter()
         pool_timer.enabled = conv_timer.enabled = timers_on and i % max(args.time_every, 1) == 0
         last = step(i, prefetch=i + 1 < n_local)
         host_t["step"] += time.perf_counter() - t_s
+    host_t["blocked"], host_t["readbacks"] = ops.READBACK["seconds"], ops.READBACK["calls"]
     join_streams()                                    # every scene's histogram atomics precede the collective
     busy_ev = torch.cuda.Event(enable_timing=False)
     busy_ev.record()
@@ -982,8 +1039,13 @@ def main():
             "student": {"pairs": pairs, "gflop_per_scene": round(flops / 1e9, 1)},
             "host_ms_per_scene": {"enqueue_total": round(host_t["step"] / max(n_local, 1) * 1e3, 3),
                                   "look_ahead_hook": round(host_t["hook"] / max(n_local, 1) * 1e3, 3),
-                                  "note": "host wall time inside step() per scene (kernel enqueue incl. the look-ahead's read-backs); when it "
-                                          "approaches ms_per_step the host, not the GPU, paces the scenes"},
+                                  "blocked_in_readbacks": round(host_t["blocked"] / max(n_local, 1) * 1e3, 3),
+                                  "readbacks": round(host_t["readbacks"] / max(n_local, 1), 2),
+                                  "host_work": round((host_t["step"] - host_t["blocked"]) / max(n_local, 1) * 1e3, 3),
+                                  "note": "host wall time inside step() per scene = host_work (Python + ctypes + launches: what the host must "
+                                          "do per scene) + blocked_in_readbacks (the look-ahead's device -> host read-backs, which wait for "
+                                          "kernels that are gated behind the start of the previous scene's student: the GPU sets their "
+                                          "length, not the host); the host paces the scenes only when host_work approaches ms_per_step"},
             "iou_target_points": iou_target_points,
             "iou_intersection_points": iou_intersection_points,
         }
@@ -1020,7 +1082,7 @@ def main():
                 with torch.cuda.stream(streams[0]):
                     bts = [pl.build_scene_batch(scenes[j], rigids[j], dev, batch_views=False) for j in range(min(args.scenes, 2))]
                 torch.cuda.synchronize()
-                out["api_tuple"] = api_tuple_rate(bts, vlms, sd, cfg, args.pool_iters, dev)
+                out["api_tuple"] = api_tuple_rate(bts, vlms, sd, cfg, args.pool_iters, dev, side_stream=streams[0])
             except Exception as e:
                 out["api_tuple"] = {"value": None, "error": repr(e)}
         if not args.no_cpu_baseline and world == 1:

@@ -20,7 +20,7 @@ extern "C" int gp_version(void) { return 100; }
 //   1  tiled pooling: float4 per lane (0 = auto, 1..4)             2  tiled pooling: unroll (0..8; knob default 4)
 //   3  convolution phase 1 (mask): 1 no loads after step 0 and 4 no LDS staging stores (register-staged path only), 2 no MFMA,
 //      8 no partial stores, 16 register-staged path, 32 fp32 partial rows (rounds 1-4) instead of 24-bit block floating point,
-//      64 / 128 the PIPE 1 / PIPE 2 schedule of phase 1 (host choice of kernel; same bits), 256 no partial rows of the centre offset
+//      256 no partial rows of the centre offset
 //      (written or read: the price of a centre-offset fold), 512 nothing (selects the twin)
 //   4  matrix-core pooling (mask): 1 no reads / MFMA, 2 hot piece instead of the row gather, 4 no epilogue, 8 hot piece instead of
 //      the weight fragments, 16 no output stores, 32 every wave issues its DMA first, 64 stamp the issue segment, 128 the bytes of an
@@ -40,7 +40,7 @@ const KnobRule k_rules[16] = {
     {0, -1, 0},          // 0: no such knob
     {0, 4, 0},           // 1
     {0, 8, 0},           // 2
-    {0, 0, 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | 256u | 512u},   // 3
+    {0, 0, 1u | 2u | 4u | 8u | 16u | 32u | 256u | 512u},               // 3
     {0, 0, 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | 256u | 512u},     // 4
     {0, 1, 0},           // 5
     {0, 256, 0},         // 6

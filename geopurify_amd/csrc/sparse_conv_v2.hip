@@ -274,36 +274,6 @@ __device__ __forceinline__ void mma_step_f16x3_off(const unsigned char *smem, co
         for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
     }
 }
-// The step in two parts around the stage hand-over (the PIPE schedules of conv_phase1_dma_body).  head: every LDS read of the stage and
-// the hi*hi / hi*lo terms; tail: the lo*hi terms, on registers only (al, bh stay live across the hand-over) -- the matrix work a wave
-// still has in hand when it leaves the barrier.  Per accumulator the order is hi*hi, hi*lo, lo*hi as in mma_step_f16x3_off: same bits.
-template <int NRT>
-__device__ __forceinline__ void mma_head_f16x3_off(const unsigned char *smem, const uint32_t (&fa_hi)[4], const uint32_t (&fa_lo)[4],
-                                                   uint32_t a_off, const V2Smem &sm, int buf, int wn, int fl, int fsw, f32x4 (&acc)[4][8],
-                                                   f16x8 (&al)[NRT > 0 ? NRT : 1], f16x8 (&bh)[8]) {
-    f16x8 ah[NRT > 0 ? NRT : 1];
-#pragma unroll
-    for (int i = 0; i < NRT; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8 *>(smem + fa_hi[i] + a_off);
-        al[i] = *reinterpret_cast<const f16x8 *>(smem + fa_lo[i] + a_off);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8 *>(&sm.b_hi[buf][wn * 128 + j * 16 + fl][fsw]);
-        f16x8 bl = *reinterpret_cast<const f16x8 *>(&sm.b_lo[buf][wn * 128 + j * 16 + fl][fsw]);
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-    }
-}
-template <int NRT, int J0, int J1>
-__device__ __forceinline__ void mma_tail_f16x3(f32x4 (&acc)[4][8], const f16x8 (&al)[NRT > 0 ? NRT : 1], const f16x8 (&bh)[8]) {
-#pragma unroll
-    for (int j = J0; j < J1; ++j)
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-}
 // grid.x = (#m-tiles upper bound) * n_tiles ; tile -> offset k by a search in tile_off (device)
 // (TUNE: the tuning bits of `ablate_` -- knob 3 -- are honoured; the product instantiation compiles them out)
 template <bool TUNE>
@@ -447,20 +417,22 @@ __device__ __forceinline__ uint64_t cv_real() {
 // multiplies while the first absorbs the memory pipeline's back-pressure: the step falls to 4 150 cycles (-8.6 %), the in-kernel
 // clock from 2.04 to 1.99 GHz, and the layer takes the same 1.929 ms -- on all-zero operands the same cycle count runs at
 // 2.37 GHz and 1.664 ms: the layer is bound by the clock the chip holds under this load, not by the schedule.
-// PIPE (round 6): the order of a step's work around the stage hand-over.
-//   0  rounds 1-5: issue the next stage's LDS-DMA at the top of the step, multiply, `vmcnt(0)` + barrier.  The compiler sinks half of
-//      the step's MFMAs below the barrier, so a stage's DMA is issued ~48 MFMAs AFTER the barrier that freed its slot and has only
-//      the other half of a step to land; all eight waves issue DMA at once (the matrix pipes idle meanwhile) and meet at once.
-//   1  the hand-over sits between a step's LDS reads (head: hi*hi, hi*lo) and its register-only tail (lo*hi); the DMA of stage
-//      s + 2 is issued RIGHT AFTER barrier s into the slot that barrier freed -- a full step in flight instead of half of one --
-//      and the tail's 32 MFMAs follow it.
-//   2  the same, and the two waves of a SIMD (wave w and w + 4) take the two orders: waves 0-3 issue their DMA first, waves 4-7
-//      multiply their tail first -- one wave of every SIMD feeds the matrix pipe while the other sits in the memory pipeline's queue.
-//   3  (interleaved rows + step-blocked weights only) waves 0-3 stage ALL of a stage -- 64 rows of each operand, 16 LDS-DMA instructions
-//      each, right after the barrier -- and waves 4-7 none: the wave the SIMD's arbiter prefers (the older one: wave w over w + 4) sits in
-//      the memory pipeline's queue while its partner multiplies alone, then overtakes it; both reach the next barrier together.
-// Same products in the same order per accumulator in every form: bit-identical partial rows.
-template <bool TUNE, bool STAMP, int PIPE = 0>
+// Round 6 (profiles/r06_conv_schedules.log; source: commit fc740de, `PIPE` 1-3 of this body, all bit-identical to it):
+//  * the hand-over's two waits stamped apart: `s_waitcnt vmcnt(0)` costs 48 of a step's 4 545 cycles -- the next stage HAS landed when a wave
+//    gets there; a deeper ring (weights two steps ahead, five half-stages in 160 KiB) has nothing to hide.  The `s_barrier` is where wave 0
+//    sits, 1 780 cycles per step, waiting for wave 4, its SIMD partner (HW_ID says so in 100 % of the tiles): the arbiter serves the older
+//    wave's MFMAs and LDS-DMA first (DMA issue: 470 cycles in wave 0, 1 180 in wave 4), so the younger one runs the end of every step alone,
+//    every LDS round trip exposed.
+//  * PIPE 1: hand-over between a step's LDS reads (head: hi*hi, hi*lo) and its register-only tail (lo*hi), the DMA of stage s + 2 issued
+//    right behind barrier s -- a full step in flight;  PIPE 2: the same with waves 4-7 multiplying their tail BEFORE they issue;  PIPE 3:
+//    waves 0-3 stage everything (16 instructions each), waves 4-7 nothing.  Stamped twins: 4 545 -> 4 404 / 3 941 / 4 065 cycles per step,
+//    the in-kernel clock 2.38 -> 2.38 / 2.28 / 2.30 GHz; PRODUCT kernels, layer alone on one box: 1.573-1.579 (this loop) vs 1.639 / 1.587-1.592 /
+//    1.592 ms.  The compiler's schedule of this loop already sinks half of a step's MFMAs below the barrier, which is most of what the
+//    hand-written orders buy; what they save in cycles beyond that the clock gives back (13 % fewer cycles, 4 % less clock, 0 % less time).
+//  * the centre-offset fold priced (tuning bit 8): with the centre offset's partial rows neither written nor read the twin's layer takes
+//    1.597 instead of 1.635 ms -- 2.3 % is the MOST a fold could return, before its own costs (a 128-row x 512-column tile per workgroup or a
+//    row-maximum exchange between the two column tiles): not built.
+template <bool TUNE, bool STAMP>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
                      const int32_t *__restrict__ pair_in, const int32_t *__restrict__ off,
@@ -541,38 +513,8 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         if (w_blocked) gb_hi[t] = w_hi + ((((int64_t)k * n_tiles + nt) * (cin / TK)) * TN + row) * TK + q;
     }
     const int bmul = w_blocked ? TN : 1;                      // halfs of the weight operand between two K steps, over TK
-    // PIPE 3: waves 0-3 stage 64 rows of each operand (x_il && w_blocked: checked on the host).  Gathered rows as 32-bit byte offsets
-    // from the uniform base (the host checks nv * row bytes < 4 GiB); a wave's four weight instructions per plane are 1 KiB apart.
-    uint32_t goff3[8];
-    int in_rows3[8];
-    const _Float16 *gb3 = nullptr;
-    if constexpr (PIPE == 3) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (wv & 3) * 64 + i * 8 + (lane >> 3);
-            const int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];
-            in_rows3[i] = in_row;
-            const int L = (lane & 7) ^ ((row >> 1) & 7);
-            goff3[i] = (uint32_t)in_row * (uint32_t)(ld_xh * 2) + (uint32_t)L * 16u;
-        }
-        gb3 = w_hi + ((((int64_t)k * n_tiles + nt) * (cin / TK)) * TN + (wv & 3) * 64 + lrow) * TK + q;
-    }
     auto issue = [&](int c0, int buf) {
         if (!issuer) return;
-        if constexpr (PIPE == 3) {
-            if (wv >= 4) return;
-            const unsigned char *xb = reinterpret_cast<const unsigned char *>(x_hi) + (size_t)c0 * 4;       // a K step = 128 bytes of a row
-            unsigned char *lA = smem_raw + (uint32_t)buf * a_bufstride + (uint32_t)(wv * 64) * 128u;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) glds16(xb + goff3[i], lA + i * 1024);
-            const _Float16 *wb = gb3 + (int64_t)c0 * TN;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                glds16(wb + t * 16 * TK, &sm.b_hi[buf][wv * 64 + t * 16][0]);
-                glds16(wb + db + t * 16 * TK, &sm.b_lo[buf][wv * 64 + t * 16][0]);
-            }
-            return;
-        }
         const uint32_t ab = (uint32_t)buf * a_bufstride;
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
@@ -617,150 +559,55 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
     // behind the first stage's DMA -- and park it in LDS behind the ring; the epilogue reads its 16 from there.  (Rounds 4-5 gathered
     // row id + scale per lane and (i, r): 32 loads per lane in front of the second stage's DMA, 16 registers live through the loop.)
     float *s_rinv = reinterpret_cast<float *>(smem_raw + sizeof(V2Smem));
-    // (PIPE: the second stage rides behind the scale loads -- both ring slots are free -- and the scales are parked by an LDS store the
-    // compiler does not see: a visible one waits for EVERY LDS-DMA in flight, i.e. for the second stage)
-    const uint32_t rinv_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw + (uint32_t)sizeof(V2Smem);
-    auto park = [&](int idx, float v) {
-        if constexpr (PIPE != 0) asm volatile("ds_write_b32 %0, %1" ::"v"(rinv_a + (uint32_t)idx * 4u), "v"(v) : "memory");
-        else s_rinv[idx] = v;
-    };
-    // (PIPE: scale loads, second stage, wait and LDS stores are hand-ordered -- inline-asm loads the compiler does not count: it would
-    // drain the ring, `vmcnt(0)`, wherever one of their registers is touched.  Without scales the loads read the pair list, a valid
-    // array of >= nv words, and the value is replaced; a one-step layer stages step 0 twice: straight-line code either way.)
-    const float *rinv_src = (PIPE != 0 && !x_inv_scale) ? reinterpret_cast<const float *>(pair_in) : x_inv_scale;
-    auto load_rinv = [&](int row) -> float {
-        if constexpr (PIPE != 0) {
-            float v;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(rinv_src + row) : "memory");
-            return v;
-        } else {
-            return x_inv_scale ? x_inv_scale[row] : 1.f;
-        }
-    };
-    if constexpr (PIPE == 3) {
-        float rv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rv[i] = load_rinv(in_rows3[i]);         // (waves 4-7 too: clamped rows, values unused)
-        issue(steps > 1 ? TK : 0, 1);
-        // waves 0-3: stage 0 (16 operations) and the 8 scale loads have landed, stage 1 (16) stays in flight; waves 4-7: the scale loads
-        if (wv < 4) asm volatile("s_waitcnt vmcnt(16)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
-        if (wv < 4 && (lane & 7) == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) park(wv * 64 + i * 8 + (lane >> 3), x_inv_scale ? rv[i] : 1.f);
-        }
-    } else if (x_il) {
+    if (x_il) {
         float rv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rv[i] = load_rinv(in_rows[i]);
-        if constexpr (PIPE != 0) {
-            issue(steps > 1 ? TK : 0, 1);
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rv[i] = x_inv_scale ? rv[i] : 1.f;
-        }
+        for (int i = 0; i < 4; ++i) rv[i] = x_inv_scale ? x_inv_scale[in_rows[i]] : 1.f;
         if ((lane & 7) == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) park(wv * RPW + i * 8 + (lane >> 3), rv[i]);
+            for (int i = 0; i < 4; ++i) s_rinv[wv * RPW + i * 8 + (lane >> 3)] = rv[i];
         }
     } else {
         float rv[NI];
 #pragma unroll
-        for (int t = 0; t < NI; ++t) rv[t] = load_rinv(in_rows[2 * t]);
-        if constexpr (PIPE != 0) {
-            issue(steps > 1 ? TK : 0, 1);
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(rv[0]), "+v"(rv[1])::"memory");
-#pragma unroll
-            for (int t = 0; t < NI; ++t) rv[t] = x_inv_scale ? rv[t] : 1.f;
-        }
+        for (int t = 0; t < NI; ++t) rv[t] = x_inv_scale ? x_inv_scale[in_rows[2 * t]] : 1.f;
         if (lp == 0) {
 #pragma unroll
-            for (int t = 0; t < NI; ++t) park(wv * RPW + t * 16 + lrow, rv[t]);
+            for (int t = 0; t < NI; ++t) s_rinv[wv * RPW + t * 16 + lrow] = rv[t];
         }
     }
-    // hand-over: `s_waitcnt vmcnt(N) lgkmcnt(0)` (this wave's LDS reads and scale stores are done; all but its N youngest vector-memory
-    // operations -- they complete in order -- have landed) and the workgroup's barrier.  STAMP: the two waits timed apart.
-    auto handover = [&](auto n_c) {
-        constexpr int N = decltype(n_c)::value;
-        if constexpr (STAMP) {
-            const uint64_t a = cv_now();
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-            const uint64_t b = cv_now();
-            asm volatile("s_barrier" ::: "memory");
-            st_wait += b - a;
-            st_bar += cv_now() - b;
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-        }
-    };
-    if constexpr (PIPE != 0) {
-        // stage 0 has landed; stage 1 (this wave's 8 -- PIPE 3: 16 or no -- youngest operations) stays in flight
-        if constexpr (PIPE == 3) handover(std::integral_constant<int, 16>{});
-        else handover(std::integral_constant<int, 8>{});
-        st_wait = st_bar = 0;
-    } else {
-        __syncthreads();
-    }
+    __syncthreads();
     if constexpr (STAMP) st_pro = cv_now();
     // the last tile of a (chunk, offset) segment is partly filled (8192-row chunks: 1 tile in 9, a third full on average): a
     // wave multiplies only the 16-row tiles that hold pairs -- matrix work the chip's power budget does not have to pay for.
     // nrt is wave-uniform and fixed for the tile: one copy of the loop per value (a switch INSIDE the loop costs 98 spills).
-    auto k_loop = [&](auto nrt_c, auto role_c) {
+    auto k_loop = [&](auto nrt_c) {
         constexpr int NRT = decltype(nrt_c)::value;
-        if constexpr (PIPE != 0) {
-            // waves w and w + 4 share a SIMD (checked with HW_REG_HW_ID in the stamped twin): PIPE 2 gives them the two orders
-            // (one copy of the loop per order: a run-time switch inside the loop spills)
-            constexpr bool tail_first = PIPE == 2 && decltype(role_c)::value;
-            constexpr bool no_dma = PIPE == 3 && decltype(role_c)::value;          // (PIPE 3: waves 4-7 stage nothing)
-            f16x8 al[NRT > 0 ? NRT : 1], bh[8];
-            for (int s = 0; s < steps; ++s) {
-                const int buf = s & 1;
-                if constexpr (NRT > 0)
-                    if (!(ablate & 2)) mma_head_f16x3_off<NRT>(smem_raw, fa_hi, fa_lo, (uint32_t)buf * a_bufstride, sm, buf, wn, fl, fsw, acc, al, bh);
-                __builtin_amdgcn_sched_barrier(0);
-                // stage s + 1 (issued one step ago) has landed, every wave is done reading stage s
-                handover(std::integral_constant<int, 0>{});
-                uint64_t st_a = 0;
-                if constexpr (tail_first) {
-                    if constexpr (NRT > 0)
-                        if (!(ablate & 2)) mma_tail_f16x3<NRT, 0, 8>(acc, al, bh);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (STAMP) st_a = cv_now();
-                    if (s + 2 < steps) issue((s + 2) * TK, buf);
-                    if constexpr (STAMP) st_dma += cv_now() - st_a;
-                } else {
-                    if constexpr (STAMP) st_a = cv_now();
-                    if constexpr (!no_dma) { if (s + 2 < steps) issue((s + 2) * TK, buf); }
-                    if constexpr (STAMP) st_dma += cv_now() - st_a;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (NRT > 0)
-                        if (!(ablate & 2)) mma_tail_f16x3<NRT, 0, 8>(acc, al, bh);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            for (int s = 0; s < steps; ++s) {
-                const int buf = s & 1;
-                uint64_t st_a = 0;
-                if constexpr (STAMP) st_a = cv_now();
-                if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
-                if constexpr (STAMP) st_dma += cv_now() - st_a;
-                if constexpr (NRT > 0)
-                    if (!(ablate & 2)) mma_step_f16x3_off<NRT>(smem_raw, fa_hi, fa_lo, (uint32_t)buf * a_bufstride, sm, buf, wn, fl, fsw, acc);
-                if constexpr (STAMP) handover(std::integral_constant<int, 0>{});
-                else __syncthreads();
+        for (int s = 0; s < steps; ++s) {
+            const int buf = s & 1;
+            uint64_t st_a = 0;
+            if constexpr (STAMP) st_a = cv_now();
+            if (s + 1 < steps) issue((s + 1) * TK, buf ^ 1);
+            if constexpr (STAMP) st_dma += cv_now() - st_a;
+            if constexpr (NRT > 0)
+                if (!(ablate & 2)) mma_step_f16x3_off<NRT>(smem_raw, fa_hi, fa_lo, (uint32_t)buf * a_bufstride, sm, buf, wn, fl, fsw, acc);
+            if constexpr (STAMP) {                            // the hand-over's two waits timed apart
+                st_a = cv_now();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const uint64_t st_b = cv_now();
+                asm volatile("s_barrier" ::: "memory");
+                st_wait += st_b - st_a;
+                st_bar += cv_now() - st_b;
+            } else {
+                __syncthreads();
             }
         }
     };
-    auto k_loops = [&](auto role_c) {
-        if (nrt == 4) k_loop(std::integral_constant<int, 4>{}, role_c);
-        else if (nrt == 3) k_loop(std::integral_constant<int, 3>{}, role_c);
-        else if (nrt == 2) k_loop(std::integral_constant<int, 2>{}, role_c);
-        else if (nrt == 1) k_loop(std::integral_constant<int, 1>{}, role_c);
-        else k_loop(std::integral_constant<int, 0>{}, role_c);
-    };
-    if ((PIPE == 2 || PIPE == 3) && wv >= 4) k_loops(std::true_type{});
-    else k_loops(std::false_type{});
+    if (nrt == 4) k_loop(std::integral_constant<int, 4>{});
+    else if (nrt == 3) k_loop(std::integral_constant<int, 3>{});
+    else if (nrt == 2) k_loop(std::integral_constant<int, 2>{});
+    else if (nrt == 1) k_loop(std::integral_constant<int, 1>{});
+    else k_loop(std::integral_constant<int, 0>{});
     if constexpr (STAMP) st_loop = cv_now();
     auto stamp_out = [&]() {
         if constexpr (STAMP) {
@@ -783,8 +630,8 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
         }
     };
     if (ablate & 8) { stamp_out(); return; }
-    // (tuning bit 8 of knob 3, 256: the tiles of the CENTRE offset -- the identity map, 13.5 % of the pairs -- multiply and store nothing, and
-    // phase 2's twin does not read their rows: the price of those partial rows' round trip, i.e. the most a fold of the centre offset into
+    // (tuning bit 8 of knob 3, 256: the tiles of the CENTRE offset -- the identity map, 13.5 % of the pairs -- store nothing, and phase 2's
+    // twin does not read their rows: the price of those partial rows' round trip, i.e. the most a fold of the centre offset into
     // phase 2 could return)
     if ((ablate & 256) && k == (kv >> 1)) { stamp_out(); return; }
     // ---- epilogue: accumulators straight to the partial buffer (no LDS staging: that made every slice's LDS reads wait for the
@@ -878,13 +725,6 @@ conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restri
 __global__ void __launch_bounds__(NT2) conv_phase1_dma_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false>(P1_FWD); }
 __global__ void __launch_bounds__(NT2) conv_phase1_tuning_kernel(P1_PARAMS) { conv_phase1_dma_body<true, false>(P1_FWD); }
 __global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true>(P1_FWD); }
-// the PIPE schedules (see conv_phase1_dma_body)
-__global__ void __launch_bounds__(NT2) conv_phase1_pipe1_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, 1>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_pipe2_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, 2>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_pipe3_kernel(P1_PARAMS) { conv_phase1_dma_body<false, false, 3>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_pipe3_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, 3>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_pipe1_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, 1>(P1_FWD); }
-__global__ void __launch_bounds__(NT2) conv_phase1_pipe2_stamp_kernel(P1_PARAMS) { conv_phase1_dma_body<true, true, 2>(P1_FWD); }
 
 #undef P1_PARAMS
 #undef P1_FWD
@@ -1511,15 +1351,9 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_SMEM_ATTR(conv_phase1_dma_kernel, P1_DMA_SMEM);
     GP_SMEM_ATTR(conv_phase1_tuning_kernel, P1_DMA_SMEM);
     GP_SMEM_ATTR(conv_phase1_stamp_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_pipe1_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_pipe2_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_pipe1_stamp_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_pipe3_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_pipe3_stamp_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_pipe2_stamp_kernel, P1_DMA_SMEM);
 
     // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
-    // blockIdx * 8 (a chunk overwrites the previous one's: the last chunk of the last call stays)
+    // blockIdx * 16 uint64 (a chunk overwrites the previous one's: the last chunk of the last call stays)
     uint64_t *stamp = static_cast<uint64_t *>(g_gp_debug_ptr[1]);
     GP_CHECK_ARG(cout % TN == 0, "gp_sparse_conv_f16x3: cout=%d must be a multiple of %d on this path", cout, TN);
     hipStream_t s = gp_stream(stream_);
@@ -1574,9 +1408,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                      (long long)chunk_pairs, cout);
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            int pipe = (g_conv_ablate & 128) ? 2 : ((g_conv_ablate & 64) ? 1 : 0);   // bits 6 / 7: the PIPE schedules (host choice of kernel)
-            if ((g_conv_ablate & 192) == 192) pipe = ((plane_flags & 1) && w_blocked && nv * ld_xh * 2 < ((int64_t)1 << 32)) ? 3 : 2;
-            const int tune = g_conv_ablate & ~(16 | 64 | 128);          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off, w_blocked, plane_flags & 1
@@ -1584,13 +1416,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 16 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
                              g_gp_debug_bytes[1], (size_t)nblocks * 16 * sizeof(uint64_t));
-                if (stamp && pipe == 3) conv_phase1_pipe3_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
-                else if (pipe == 3 && !tune) conv_phase1_pipe3_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
-                else if (stamp && pipe == 2) conv_phase1_pipe2_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
-                else if (stamp && pipe == 1) conv_phase1_pipe1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
-                else if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
-                else if (pipe == 2 && !tune) conv_phase1_pipe2_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
-                else if (pipe == 1 && !tune) conv_phase1_pipe1_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
+                if (stamp) conv_phase1_stamp_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
                 else if (tune) conv_phase1_tuning_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
                 else conv_phase1_dma_kernel<<<(unsigned)nblocks, NT2, P1_DMA_SMEM, s>>>(P1_ARGS);
             } else {

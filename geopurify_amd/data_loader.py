@@ -187,3 +187,52 @@ class ScannetLoaderFull(Dataset):
                            dataset=cfg.dataset, img_dim=cfg.image_dim, vis_thres=cfg.vis_thres, cut_bound=cfg.cut_bound,
                            voxel_size=self.voxel_size, category_split=self.category_split, split=self.split, val_keep=self.val_keep,
                            label_2d_ids=None, input_color=self.input_color, min_visible=cfg.min_visible)
+
+
+class LookAheadLoader:
+    """Wraps the evaluation DataLoader of run/validation.py:296-321 (any iterable of the positional 20-tuples) so that the drop-in
+    call `model.evaluate_scene(batch_data)` (run/validation.py:408) runs at the rate of the device pipeline:
+
+        for batch_data in LookAheadLoader(val_loader, model):      # instead of: for batch_data in val_loader:
+            eval_results = model.evaluate_scene(batch_data)
+
+    While scene i is being evaluated the wrapper has already (1) fetched tuple i + 1 from the loader, (2) copied its tensors to the
+    device on its own copy stream (asynchronously when the loader pins its memory) and (3) OFFERED the device tuple to the trainer
+    (SonataXAffinityTrainer.offer_next), which parses it, lifts it and runs HotPath.prepare on a side stream beside scene i's
+    student.  The yielded tuple is the device tuple; every result equals the serial call's bit for bit.
+    The copy of tuple i + 1 is ordered behind the end of scene i - 1 on the evaluating stream (`model.last_scene_done`): the blocks it
+    is handed were last read there, so no record_stream markers are needed."""
+
+    def __init__(self, loader, model, device=None, copy_stream=None):
+        self.loader, self.model = loader, model
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # (a process maps its streams onto a handful of hardware queues -- four by default -- and two streams on one queue run in order:
+        # a program that already owns streams should hand one over instead of letting every helper create its own)
+        self.copy_stream = copy_stream if copy_stream is not None else torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _upload(self, batch_data):
+        if batch_data is None:
+            return None, None
+        last = getattr(self.model, "last_scene_done", None)
+        with torch.cuda.stream(self.copy_stream):
+            if last is not None:
+                self.copy_stream.wait_event(last)
+            dev = tuple(x.to(self.device, non_blocking=True) if torch.is_tensor(x) and x.numel() else x for x in batch_data)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return dev, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        cur, cur_ev = self._upload(next(it, None))
+        while cur is not None:
+            nxt, nxt_ev = self._upload(next(it, None))
+            if cur_ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(cur_ev)          # (scenes that were not lifted ahead read it here)
+            if nxt is not None:
+                self.model.offer_next(nxt, ready=nxt_ev)
+            yield cur
+            cur, cur_ev = nxt, nxt_ev

@@ -31,6 +31,21 @@ def _chk(t, dtype, name):
     return t
 
 
+# host time spent BLOCKED in the hot path's device -> host read-backs (voxel count, per-view counts, chunk plan, pair bounds, union
+# rows): a scheduler that runs them ahead (bench.py's look-ahead) reports its own enqueue time net of these waits
+READBACK = {"seconds": 0.0, "calls": 0}
+
+
+def readback(t):
+    """t.tolist() of a small device tensor, the wait accounted in READBACK (one host synchronisation of the calling stream)"""
+    import time
+    t0 = time.perf_counter()
+    v = t.tolist()
+    READBACK["seconds"] += time.perf_counter() - t0
+    READBACK["calls"] += 1
+    return v
+
+
 def _dbl16(m):
     a = np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(16))
     return (ctypes.c_double * 16)(*a.tolist())
@@ -53,7 +68,7 @@ def voxelize(coords, rigid):
     nvd = torch.zeros(1, dtype=torch.int64, device=dev)
     check(lib.gp_voxelize_f64(_ptr(coords), n, _dbl16(rigid), _ptr(ca), _ptr(inds), _ptr(inv), _ptr(nvd),
                               _ptr(order), _ptr(seg), _ptr(ws), ws.numel(), _stream()), "gp_voxelize_f64")
-    nv = int(nvd.item())
+    nv = int(readback(nvd)[0])
     return {"coords_aug": ca[:nv], "inds": inds[:nv], "inds_reconstruct": inv, "order": order,
             "seg_start": seg[:nv + 1], "nv": nv}
 
@@ -256,7 +271,7 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
         target = CONV_TARGET_TILES or 3 * torch.cuda.get_device_properties(dev).multi_processor_count - 16
         check(lib.gp_conv_chunk_plan(_ptr(nbr_map), nv, kv, granule, int(col_tiles), int(target), max_chunks, _ptr(plan),
                                      _ptr(plan[max_chunks + 1:]), _ptr(ws), ws.numel(), _stream()), "gp_conv_chunk_plan")
-        host = plan.cpu().tolist()                                                   # host sync 1 of 2
+        host = readback(plan)                                                        # host sync 1 of 2
         nchunks = host[max_chunks + 1]
         rows = host[:nchunks + 1]
         row_off = plan[:nchunks + 1]
@@ -274,7 +289,7 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
     tile_desc = torch.empty(((kv * nv) // 256 + nseg + 1, 4), dtype=torch.int32, device=dev)
     check(lib.gp_conv_pairs_build(_ptr(nbr_map), nv, kv, nchunks, _ptr(row_off), _ptr(pair_in), _ptr(pair_pos), _ptr(seg_off),
                                   _ptr(tile_start), _ptr(tile_desc), _ptr(ws), ws.numel(), _stream()), "gp_conv_pairs_build")
-    bounds = torch.stack([seg_off[::kv], tile_start[::kv]]).cpu().tolist()     # the host sync of this call (number of pairs)
+    bounds = readback(torch.stack([seg_off[::kv], tile_start[::kv]]))          # the host sync of this call (number of pairs)
     num_pairs = bounds[0][-1]
     cp = ConvPairs(pair_in, pair_pos, seg_off, tile_start, nseg, num_pairs, nv)
     cp.tile_desc = tile_desc
@@ -620,7 +635,7 @@ def pool_cs_plan(nbr, rows_per_block=128, structure=False):
     tail = bu_off.as_strided((2,), (1,), bu_off.storage_offset() + nb)                        # [total, largest union]: ONE read-back
     check(lib.gp_pool_cs_count(_ptr(nbr), nv, int(k), rpb, _ptr(bu_off), _ptr(bu_n), tail[1:].data_ptr(), _ptr(ws), ws.numel(), _stream()),
           "gp_pool_cs_count")
-    total, max_union = (int(v) for v in tail.tolist())                                        # the one host sync
+    total, max_union = (int(v) for v in readback(tail))                                       # the one host sync
     bu_row = torch.empty(total, dtype=torch.int32, device=dev)
     bu_mask = torch.empty(total // 32, dtype=torch.int32, device=dev)
     wa_hi = torch.empty(total // 32 * 8 * 512, dtype=torch.float16, device=dev)

@@ -258,7 +258,7 @@ def build_scene_batch(scene, rigid, device="cuda", val_keep=10_000_000, batch_vi
         ent = ops.views_visible_lists(coords64, torch.from_numpy(params).to(dev), scene.depth_all_dev, W, H, cfg.cut_bound,
                                       cfg.vis_thres, cfg.min_visible, val_keep)
         tail = torch.cat([ent["view_off"], _voxel_extent(vox)])
-        host = tail.cpu().tolist()                                        # sync #2 (entries per view + extent)
+        host = ops.readback(tail)                                         # sync #2 (entries per view + extent)
         views = []
         for i in range(V):
             o, n_v = host[i], host[i + 1] - host[i]

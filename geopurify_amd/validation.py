@@ -90,7 +90,7 @@ def scene_tail(hot_path, eval_results, scene_coords, scene_label, test_classes, 
     return pred
 
 
-def validate(scenes, evaluate_fn, args, hot_path=None, logger=None, rank=0, world_size=1):
+def validate(scenes, evaluate_fn, args, hot_path=None, logger=None, rank=0, world_size=1, offer_fn=None):
     """scenes: list of (scene_id, batch) providers (callables returning a SceneBatch);
     evaluate_fn(batch, scene_id) -> the evaluate_scene dict.  Returns (mIoU_Base, mIoU_Novel)."""
     logger = logger or get_logger()
@@ -100,11 +100,22 @@ def validate(scenes, evaluate_fn, args, hot_path=None, logger=None, rank=0, worl
     split = args.get("category_split")
     summary = None
     with torch.no_grad():
+        # offer_fn given: one scene of look-ahead -- the provider of scene i + 1 runs before scene i is evaluated and its batch is
+        # offered to the evaluator (`offer_fn(batch, scene_id)`: SonataXAffinityTrainer.offer_next), which lifts it beside scene i's
+        # student.  Without it the providers run scene by scene, each right before its evaluation (rounds 1-5).
+        ahead = offer_fn is not None
+        nxt = scenes[0][1]() if (scenes and ahead) else None
         for i, (scene_id, provider) in enumerate(scenes):
-            batch = provider()
+            if ahead:
+                batch = nxt
+                nxt = scenes[i + 1][1]() if i + 1 < len(scenes) else None
+            else:
+                batch = provider()
             if batch is None:
                 print(f"Warning: batch_data is None at iteration {i}, skipping...")
                 continue
+            if ahead and nxt is not None:
+                offer_fn(nxt, scenes[i + 1][0])
             res = evaluate_fn(batch, scene_id)
             scene_tail(hot_path, res, batch.scene_coords, batch.scene_label, C, args.test_ignore_label, counts)
             if rank == 0:
@@ -179,11 +190,26 @@ def main(argv=None):
             return pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda", val_keep=int(args.get("val_keep", 10 ** 7)))
         return make
 
+    vlm_of = {}
+
+    def provider_with_vlm(sid):
+        make = provider_for(sid)
+
+        def run():
+            b = make()
+            vlm_of[sid] = state["vlm"]                  # (the synthetic 2D outputs are per scene)
+            return b
+        return run
+
     def evaluate(batch, sid):
-        model.vlm = state["vlm"]
+        model.vlm = vlm_of.pop(sid)
         return model.evaluate_scene(batch, vis_prefix=sid)
 
-    result, counts = validate([(s, provider_for(s)) for s in scene_ids], evaluate, args, hp, logger, rank, world)
+    def offer(batch, sid):
+        model.offer_next(batch, vlm=vlm_of[sid])
+
+    result, counts = validate([(s, provider_with_vlm(s)) for s in scene_ids], evaluate, args, hp, logger, rank, world,
+                              offer_fn=offer if args.get("look_ahead", True) else None)
     if rank == 0:
         logger.info("==> Train/Eval done!")
     if world > 1:

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Phase-1 schedules of the 512->512 layer on ONE box: the product operand form (interleaved row-scaled rows, step-blocked weights,
-balanced chunks) under knob 3 = 0 (rounds 1-5 loop), 64 (PIPE 1), 128 (PIPE 2), ... interleaved over several rounds so that box drift
-shows; bit equality of the outputs; then the stamped twin of each schedule (where a step's cycles go: DMA issue, `s_waitcnt`, `s_barrier`
-apart, for wave 0 and its SIMD partner wave 4).
-usage: conv_pipe_ab.py [knob3 values ...]        default: 0 64 128"""
+"""The 512->512 layer on ONE box in the product operand form (interleaved row-scaled rows, step-blocked weights, balanced chunks) under
+several values of knob 3, interleaved over several rounds so that box drift shows; bit equality of the outputs; then the stamped twin
+(where a step's cycles go: DMA issue, `s_waitcnt`, `s_barrier` apart, for wave 0 and its SIMD partner wave 4).
+knob 3: 0 product kernels, 512 the tuning twin with nothing switched, 256 the twin without the centre offset's partial rows (the price of
+a centre-offset fold), 2 no MFMA, ...  (Round 6's PIPE 1-3 schedules -- knob values 64 / 128 / 192 -- exist in commit fc740de only:
+profiles/r06_conv_schedules.log.)
+usage: conv_pipe_ab.py [knob3 values ...]        default: 0 512 256"""
 import os
 import sys
 import dataclasses
@@ -14,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geopurify_amd import _lib, ops, pipeline as pl, synthetic as syn  # noqa: E402
 
-KNOBS = [int(a) for a in sys.argv[1:]] or [0, 64, 128]
+KNOBS = [int(a) for a in sys.argv[1:]] or [0, 512, 256]
 ROUNDS = int(os.environ.get("GP_AB_ROUNDS", "3"))
 STAMPS = os.environ.get("GP_AB_STAMPS", "1") != "0"
 cfg = dataclasses.replace(syn.CONFIGS["S"], num_views=1)
@@ -80,7 +82,7 @@ for r in range(ROUNDS):
 print("medians over the rounds: " + "   ".join(f"knob3={k}: {np.median(v):.3f} ms" for k, v in res.items()), flush=True)
 
 if STAMPS:
-    for k in [k for k in KNOBS if not (k & ~(64 | 128))]:
+    for k in [0]:
         run, ys = layer(k)
         for _ in range(30):
             run()

@@ -71,8 +71,10 @@ def stamped(label, X, W, pairs, abl):
           f"(p10 {np.percentile(real_us, 10):.1f}, p90 {np.percentile(real_us, 90):.1f})")
     print(f"  cycles per full tile: prologue {f(pro)}  K loop {f(loop)} ({np.mean(loop[full]) / 16:.0f} per step; MFMA issue alone = 3072)  "
           f"store issue {f(iss)}  store drain {f(drain)}  total {f(tot)}")
-    print(f"  inside the K loop, wave 0 (stamps cost ~10 %): DMA issue {np.mean(s[full, 8]) / 16:6.0f} cycles per step, end-of-step wait + barrier "
-          f"{np.mean(s[full, 9]) / 16:6.0f}, reads + MFMA {(np.mean(loop[full]) - np.mean(s[full, 8]) - np.mean(s[full, 9])) / 16:6.0f}", flush=True)
+    print(f"  inside the K loop, wave 0 (stamps cost ~10 %): DMA issue {np.mean(s[full, 8]) / 16:6.0f} cycles per step, end-of-step s_waitcnt "
+          f"{np.mean(s[full, 9]) / 16:6.0f} + s_barrier {np.mean(s[full, 10]) / 16:6.0f}, reads + MFMA "
+          f"{(np.mean(loop[full]) - np.mean(s[full, 8]) - np.mean(s[full, 9]) - np.mean(s[full, 10])) / 16:6.0f}; wave 4 (same SIMD): DMA issue "
+          f"{np.mean(s[full, 12]) / 16:6.0f}, s_waitcnt {np.mean(s[full, 13]) / 16:6.0f}, s_barrier {np.mean(s[full, 14]) / 16:6.0f}", flush=True)
     return ys
 
 

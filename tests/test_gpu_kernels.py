@@ -585,7 +585,7 @@ def test_error_paths(ops):
     hi5, lo5 = ops.conv_weights_split(torch.randn(27, 64, 256, device="cuda") * 0.05, 1.0)
     xs5 = ops.split_f16(torch.randn(len(c), 64, device="cuda"))
     good5 = ops.sparse_conv_f16x3(None, pairs, hi5, lo5, x_split=xs5)
-    stamps = torch.zeros(4096 * 10, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")          # 16 x uint64 per workgroup (waves 0 and 4)
     try:
         assert lib.gp_debug_ptr(1, small.data_ptr(), small.numel() * 8) == 0
         with pytest.raises(GeoPurifyHipError, match="stamp buffer"):
@@ -596,9 +596,11 @@ def test_error_paths(ops):
     finally:
         assert lib.gp_debug_ptr(1, None, 0) == 0
     assert torch.equal(y5, good5)
-    st = stamps.view(-1, 10).cpu()
+    st = stamps.view(-1, 16).cpu()
     st = st[st[:, 6] > 0]
     assert len(st) > 0 and bool((st[:, 2] + st[:, 3] <= st[:, 6]).all())   # prologue + K loop inside the tile's total cycles
+    assert bool((st[:, 8] + st[:, 9] + st[:, 10] <= st[:, 3]).all())       # DMA issue + s_waitcnt + s_barrier inside the K loop (wave 0)
+    assert bool((((st[:, 11] >> 4) & 3) == ((st[:, 15] >> 4) & 3)).all())  # waves 0 and 4 of a workgroup share a SIMD (HW_ID bits 5:4)
 
 
 def test_pooling_tuning_masks_keep_the_ring_discipline(ops):

@@ -181,6 +181,32 @@ def test_reference_api_tuple_path(env):
     a = model.evaluate_scene(env["batch"])["scene_features"]
     assert torch.equal(a, bres["scene_features"])                                  # tuple path == SceneBatch path
     assert bres["text_features"].shape == (cfg.num_classes, cfg.feat_dim)
+    # the look-ahead form (offer_next: a loader wrapper hands over the NEXT scene's tuple; its copy / parse / lift / prepare run on the
+    # trainer's side stream beside this scene's student): three scenes in a row, every result bit-identical to the serial call
+    tup2 = tuple(t.clone().pin_memory() if torch.is_tensor(t) else t for t in tup)
+    seq = [tup, tup2, tup]
+    outs = []
+    for i, t in enumerate(seq):
+        if i + 1 < len(seq):
+            model.offer_next(seq[i + 1])
+        outs.append(model.evaluate_scene(t)["scene_features"].clone())
+    torch.cuda.synchronize()
+    assert model._ahead is None and model._offered is None
+    for o in outs:
+        assert torch.equal(o, bres["scene_features"])
+    # ... and through the loader wrapper a user puts around the reference's DataLoader (copies ahead on its own stream, offers the device tuple)
+    from geopurify_amd.data_loader import LookAheadLoader
+    n_seen = 0
+    for d in LookAheadLoader([tup2, tup, tup2, tup], model):
+        assert all(x.is_cuda for x in d if torch.is_tensor(x) and x.numel())
+        assert torch.equal(model.evaluate_scene(d)["scene_features"], bres["scene_features"])
+        n_seen += 1
+    assert n_seen == 4 and model._ahead is None and model._offered is None
+    # an offered scene that is NOT the next one evaluated is dropped, not confused with it
+    model.offer_next(tup2)
+    assert torch.equal(model.evaluate_scene(tup)["scene_features"], bres["scene_features"])      # (lifts tup2 ahead ...)
+    assert torch.equal(model.evaluate_scene(tup)["scene_features"], bres["scene_features"])      # (... which this call ignores)
+    assert model._ahead is None
 
 
 def test_dataset_sampler_collate_drive_evaluate_scene():
