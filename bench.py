@@ -65,6 +65,7 @@ def parse():
                          "one beside scene i's convolutions and joined before its pooling; alternate: whole scenes alternate "
                          "over --streams streams (3 %% more scenes/s, but the pooling launches then share the chip with the "
                          "other scene's kernels: 0.40 instead of 0.26 ms per launch)")
+    ap.add_argument("--selftest-hang", default=None, help=argparse.SUPPRESS)      # rank id or "all": the launcher watchdog's test
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step rate (extra object `training_step`)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the bounded CPU-baseline sample")
@@ -75,6 +76,11 @@ def parse():
         # 6 steps the edges cost 1 % of the rate (25.9 vs 25.65 ms per scene at 24 or 64 steps, profiles/r04_steps_sweep.log)
         a.steps = 0 if a.config == "V" else 24           # 0 = resolved to the rank's scene count below
     return a
+
+
+def _lib_path():
+    from geopurify_amd import _lib
+    return _lib.LIB_PATH
 
 
 def log(*a):
@@ -206,7 +212,7 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
                                                            "grid+kernel_map": "lattice grid + 27-offset kernel map: index work, no SURVEY 8(d) figure",
                                                            "student": "the nine 3x3x3 layers, matrix-core bound: see roofline_conv (the 1x1x1 output layer is the `embed head` line)",
                                                            "pool plan+split": "once per scene, needs the kNN lists only: the pooling operator's union sizes and structure (union rows, fragment masks, the element of every (row, neighbour) weight) + the f16 hi/lo splits of X",
-                                                           "pool operator fill": "empty since round 4: the affinity kernel writes the weights straight into fragment order (GP_POOL_STRUCTURE_AHEAD=0: the separate fill pass)"}[name]}
+                                                           "pool operator fill": "empty since round 4: the affinity kernel writes the weights straight into fragment order (HotPath(pool_structure_ahead=False): the separate fill pass)"}[name]}
     out["note"] = ("one-stream side pass after the timed region, HIP events at stage boundaries, mean over the side scenes; "
                    "achieved = SURVEY 8(d) algorithmic bytes / stage time; peak 8000 GB/s")
     return out
@@ -646,7 +652,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, args.rank_timeout)        # does not return
     rank = int(os.environ.get("RANK", "0"))
-    if os.environ.get("GP_BENCH_SELFTEST_HANG") in (str(rank), "all"):   # tests/test_host_logic.py: ranks that never come back
+    if args.selftest_hang in (str(rank), "all"):      # tests/test_host_logic.py (hidden flag): ranks that never come back, before any GPU call
         time.sleep(3600)
     if args.val_scenes is None:
         args.val_scenes = default_val_scenes(args.gpus)
@@ -885,6 +891,7 @@ def main():
         host_t["step"] += time.perf_counter() - t_s
     host_t["blocked"], host_t["readbacks"] = ops.READBACK["seconds"], ops.READBACK["calls"]
     join_streams()                                    # every scene's histogram atomics precede the collective
+    hp.pool_chain_check()                             # (--pool-mode mfma_chain: the abort words of every timed scene's launch; else nothing pending)
     busy_ev = torch.cuda.Event(enable_timing=False)
     busy_ev.record()
     if world > 1:
@@ -939,11 +946,13 @@ def main():
         # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth): one warm pass
         # (operator build, allocator, clocks), then three timed passes; the median pass is reported
         hp._pool(*hp._last_pool_inputs)
+        hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
         torch.cuda.synchronize()
         alone = []
         for _ in range(3):
             pool_timer.events, pool_timer.enabled = [], True
             hp._pool(*hp._last_pool_inputs)
+            hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
             torch.cuda.synchronize()
             pool_timer.enabled = False
             alone.append(pool_timer.mean_ms())
@@ -960,11 +969,13 @@ def main():
             lib.gp_debug_set(4, 9)
             try:
                 hp._pool(*hp._last_pool_inputs)
+                hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
                 torch.cuda.synchronize()
                 cl = []
                 for _ in range(3):
                     pool_timer.events, pool_timer.enabled = [], True
                     hp._pool(*hp._last_pool_inputs)
+                    hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
                     torch.cuda.synchronize()
                     pool_timer.enabled = False
                     cl.append(pool_timer.mean_ms())
@@ -1016,7 +1027,9 @@ def main():
             "config": {"workload": workload,
                        "sharding": (f"{shard['policy']} assignment of {shard['scenes_total']} scenes to {world} rank(s), " if val_mode else
                                     f"1 scene per GPU x {world}, ") + "one int64 all-reduce of IoU counts",
-                       "streams": len(streams), "schedule": "split" if split else "alternate"},
+                       "streams": len(streams), "schedule": "split" if split else "alternate",
+                       "pool_mode": args.pool_mode, "library": os.path.relpath(_lib_path(), ROOT),
+                       "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GP_")}},
             "roofline": {"kernel": hp.stats["pool_kernel"] + (f" (affinity pooling, all {args.pool_iters} applications of A in one launch)"
                                                               if hp.stats["pool_kernel"] == "cs_chain_kernel" else " (affinity pooling, one application of A)"),
                          "bound": "hbm",

@@ -278,6 +278,8 @@ class SonataXAffinityTrainer(nn.Module):
                 self._ahead = (nxt,) + self._look_ahead(hp, nxt, nvlm if nvlm is not None else self.vlm, started, ready)
                 cur.wait_event(self._ahead[-1])                  # the pooling below has the chip to itself
         feats = hp.refine(batch, F, after_student=hook, prepared=prep)
+        if hp._chain_ops:
+            hp.pool_chain_check()                                    # (chained pooling only: its abort word, before the features leave)
         self.last_scene_done = torch.cuda.Event()                    # (a loader that copies ahead orders its copies behind this)
         self.last_scene_done.record(cur)
         return {"scene_features": feats, "text_features": text, "logit_scale": scale}

@@ -15,7 +15,8 @@
 // (shared by the builder in pool_mfma_cs.hip and the affinity kernels that write fragments directly, pool.hip)
 #define GP_POOL_CS_WSCALE 1024.f
 
-extern "C" void gp_set_error(const char *fmt, ...);
+// (internal to the library: hidden, not part of the C-ABI of include/geopurify_hip.h -- the message is read with gp_last_error)
+extern "C" __attribute__((visibility("hidden"))) void gp_set_error(const char *fmt, ...);
 
 #define GP_CHECK_ARG(cond, ...)                \
     do {                                       \

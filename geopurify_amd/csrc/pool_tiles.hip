@@ -214,6 +214,82 @@ pool_tiles_kernel(const float *__restrict__ x, int64_t ld_x, const int64_t *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// D = 64 (BASELINE configs[0], the dense-feature lift): a row is 256 bytes = 16 lanes x float4.  One wave per tile of R rows; its four
+// 16-lane quarters take every fourth union entry (four in flight per quarter: 16 union rows per wave and round trip, the next round's row
+// ids prefetched under this round's rows), row id and the R weights of an entry are one address per quarter, the union row is one
+// coalesced 256-byte read; the quarters' partial sums meet through two DPP-free shuffles per accumulator at the end (a fixed order: the
+// result is reproducible).  The generic ELL kernel moves K x 256 B per output row through L2 (1.1 GB per application at 45k voxels: 0.045
+// of 8 TB/s on config P); a tile of R = 8 rows moves its ~150 union rows once.  (First form, a tile per QUARTER: 1.4 waves per SIMD, each
+// walking ~40 dependent round trips -- 0.137 ms per application, no better than ELL.)
+template <int R>
+__global__ void __launch_bounds__(256)
+pool_tiles64_kernel(const float *__restrict__ x, int64_t ld_x, const int64_t *__restrict__ off, const int32_t *__restrict__ u_row,
+                    const float *__restrict__ u_w, int64_t nv, int64_t ntiles, float *__restrict__ y, int64_t ld_y) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = (lane & 15) * 4;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;                                   // (wave-uniform)
+    const int64_t beg = off[t], end = off[t + 1];
+    const int len = (int)(end - beg);
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int UN = 8;                                      // entries in flight per quarter; a round covers 4 * UN entries (UN = 4: 0.045 ms on config P)
+    int rows[UN], rows_next[UN];
+    auto load_ids = [&](int e0, int (&dst)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * 4 + q;
+            dst[u] = e < len ? u_row[beg + e] : -1;
+        }
+    };
+    load_ids(0, rows);
+    for (int e0 = 0; e0 < len; e0 += 4 * UN) {
+        float4 xv[UN], w0[UN], w1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = rows[u] >= 0;
+            const int64_t e = beg + e0 + u * 4 + q;
+            xv[u] = ok ? *reinterpret_cast<const float4 *>(x + (int64_t)rows[u] * ld_x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 *wp = reinterpret_cast<const float4 *>(u_w + e * R);
+            w0[u] = ok ? wp[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            w1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (R == 8) { if (ok) w1[u] = wp[1]; }
+        }
+        if (e0 + 4 * UN < len) load_ids(e0 + 4 * UN, rows_next);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float ww[8] = {w0[u].x, w0[u].y, w0[u].z, w0[u].w, w1[u].x, w1[u].y, w1[u].z, w1[u].w};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r].x = fmaf(ww[r], xv[u].x, acc[r].x);
+                acc[r].y = fmaf(ww[r], xv[u].y, acc[r].y);
+                acc[r].z = fmaf(ww[r], xv[u].z, acc[r].z);
+                acc[r].w = fmaf(ww[r], xv[u].w, acc[r].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) rows[u] = rows_next[u];
+    }
+    // quarters 0 + 1 and 2 + 3, then the two halves: every lane ends with the tile's sums of its four columns
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            acc[r].x += __shfl_xor(acc[r].x, o, 64);
+            acc[r].y += __shfl_xor(acc[r].y, o, 64);
+            acc[r].z += __shfl_xor(acc[r].z, o, 64);
+            acc[r].w += __shfl_xor(acc[r].w, o, 64);
+        }
+    }
+    // quarter q stores rows q, q + 4 (R = 8) -- 256-byte runs
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = t * R + r;
+        if ((r & 3) == q && row < nv) *reinterpret_cast<float4 *>(y + row * ld_y + c) = acc[r];
+    }
+}
+
 size_t scan64_tmp(int64_t n) {
     size_t t = 0;
     (void)rocprim::exclusive_scan(nullptr, t, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0);
@@ -276,6 +352,15 @@ extern "C" int gp_pool_tiles_apply(const float *x, int64_t ld_x, const int64_t *
     int64_t nt = (nv + r - 1) / r;
     hipStream_t s = gp_stream(stream_);
     // R=16 keeps 256 columns per wave (64 accumulator registers); R<=8 keeps 512 (tunable: gp_debug_set)
+    if (d == 64) {
+        // config P's width: one tile per wave, its union dealt over the four 16-lane quarters (pool_tiles64_kernel)
+        GP_CHECK_ARG(r == 8 || r == 4, "gp_pool_tiles_apply: d=64 takes r=4 or r=8 tiles (r=%d)", r);
+        const unsigned g64 = (unsigned)((nt + 3) / 4);
+        if (r == 8) pool_tiles64_kernel<8><<<g64, 256, 0, s>>>(x, ld_x, tile_off, u_row, u_w, nv, nt, y, ld_y);
+        else pool_tiles64_kernel<4><<<g64, 256, 0, s>>>(x, ld_x, tile_off, u_row, u_w, nv, nt, y, ld_y);
+        GP_CHECK_LAUNCH();
+        return GP_OK;
+    }
     int nf4 = g_pool_nf4 ? g_pool_nf4 : ((r == 4) ? 2 : 1);   // measured best: 256 columns per wave for r=8,16
     GP_CHECK_ARG(d % (nf4 * 256) == 0, "gp_pool_tiles_apply: d=%d must be a multiple of %d (use gp_pool_ell otherwise)", d, nf4 * 256);
     int slabs = d / (nf4 * 256);

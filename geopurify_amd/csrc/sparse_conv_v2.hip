@@ -1328,7 +1328,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
                                     const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, int32_t w_blocked,
                                     int32_t plane_flags, void *stream_) {
-    GP_CHECK_ARG(plane_flags >= 0 && plane_flags < 8, "gp_sparse_conv_f16x3: plane_flags is a mask of 1 (x interleaved), 2 (y interleaved), 4 (residual interleaved)");
+    GP_CHECK_ARG(plane_flags >= 0 && plane_flags < 16, "gp_sparse_conv_f16x3: plane_flags is a mask of 1 (x interleaved), 2 (y interleaved), 4 (residual interleaved), 8 (fp32 partial rows)");
     GP_CHECK_ARG(!(plane_flags & 1) || (x_hi && ld_xh % 64 == 0 && cin % 32 == 0), "gp_sparse_conv_f16x3: interleaved x rows come as ONE tensor (x_hi) of 2 x cin halfs per row");
     GP_CHECK_ARG(!(plane_flags & 2) || (y_hi && ld_yh % 64 == 0 && (uintptr_t)y_hi % 16 == 0), "gp_sparse_conv_f16x3: interleaved y rows go to ONE tensor (y_hi) of 2 x cout halfs per row");
     GP_CHECK_ARG(!(plane_flags & 4) || (res_hi && ld_rh % 64 == 0), "gp_sparse_conv_f16x3: interleaved residual rows come as ONE tensor (res_hi)");
@@ -1384,13 +1384,21 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     }
     const bool chunked = num_chunks >= 1;
     const int nchunk = chunked ? num_chunks : 1;
-    static const int p2_wg_per_cu = [] { const char *e = getenv("GP_CONV_P2_WG_PER_CU"); return e ? atoi(e) : 6; }();
+    constexpr int p2_wg_per_cu = 6;                       // (rounds 4-5: GP_CONV_P2_WG_PER_CU for the sweep -- 4 / 5 / 6 / 8: 1.954 / 1.935 / 1.946 / 1.967 ms per layer)
     // Measured and left out (round 2): a persistent phase 1 (one workgroup per CU, 3-deep ring for the gathered rows issued two
     // steps ahead, weight tiles one step ahead, split staging roles, rings and epilogue stores running through tile boundaries,
     // swapped MFMA operands for 16-byte partial stores): bit-identical results, 1.99 vs 1.96 ms per 512->512 layer.  Its
     // ablations say why: matrix work alone 0.86 ms, loads alone 0.50 ms, loads + partial stores 0.97 ms, all three 1.45 ms,
     // loop skeleton 0.08 ms -- phase 1 is co-limited by its 9.7 GB of L2 / Infinity-Cache traffic per layer (3.9 GB gathered
     // rows + 3.8 GB weight tiles + 2 GB partial rows), which scheduling does not change.
+    // The 24-bit partial rows are addressed with 32-bit byte offsets: every chunk is checked BEFORE the first launch, and a call with an
+    // oversized chunk (an unchunked call with > ~2.7 M pairs at 512 columns) runs on the fp32 partial rows of rounds 1-4 instead -- 64-bit
+    // offsets, the tuning twin's stores + conv_phase2_kernel -- rather than failing half way with y partly written.
+    bool q24_fits = !(plane_flags & 8);                   // (bit 3 of plane_flags ASKS for the fp32 rows: the reference form of the 24-bit format)
+    for (int c = 0; c < nchunk; ++c) {
+        const int64_t cp = chunked ? (int64_t)chunk_pair_off_host[c + 1] - chunk_pair_off_host[c] : num_pairs;
+        if (cp * cout * 3 + 32 >= ((int64_t)1 << 32)) q24_fits = false;
+    }
     for (int c = 0; c < nchunk; ++c) {
         int tile_begin = chunked ? chunk_tile_off_host[c] : 0;
         int tile_count = chunked ? chunk_tile_off_host[c + 1] - tile_begin : (int)(num_pairs / TM + nseg);
@@ -1402,13 +1410,10 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         const int64_t chunk_pairs = chunked ? (int64_t)chunk_pair_off_host[c + 1] - pair_base : num_pairs;
         const int64_t q_e_off = (chunk_pairs * cout * 3 + 15) & ~(int64_t)15;
         const bool dma_path = x_hi && !(g_conv_ablate & 16);
-        const bool q24 = dma_path && !(g_conv_ablate & 32);   // tuning bit 5: the fp32 partial rows of rounds 1-4, same kernels otherwise
-        GP_CHECK_ARG(!q24 || chunk_pairs * cout * 3 + 32 < ((int64_t)1 << 32),
-                     "gp_sparse_conv_f16x3: %lld pairs x %d columns in one chunk: the 24-bit partial rows must stay below 4 GiB (use chunks)",
-                     (long long)chunk_pairs, cout);
+        const bool q24 = dma_path && !(g_conv_ablate & 32) && q24_fits;   // tuning bit 5: the fp32 partial rows of rounds 1-4, same kernels otherwise
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            const int tune = g_conv_ablate & ~16;          // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            const int tune = (g_conv_ablate & ~16) | ((dma_path && !q24_fits) ? 32 : 0);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off, w_blocked, plane_flags & 1
@@ -1430,7 +1435,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
             }
 #undef P1_ARGS
         }
-        // one resident round: 6 workgroups of 4 waves per CU (80 registers per lane); GP_CONV_P2_WG_PER_CU for the sweep
+        // one resident round: 6 workgroups of 4 waves per CU (80 registers per lane)
         const int64_t p2_full = (row_count * 64 + 255) / 256;
         int64_t p2_res = (int64_t)gp_cu_count() * p2_wg_per_cu;
         // (the 24-bit kernel: 4 waves per SIMD at 128 registers -- 4 workgroups per CU are one resident round)

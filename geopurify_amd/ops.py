@@ -4,7 +4,6 @@ Every function takes/returns torch CUDA tensors but hands the library raw device
 and the current HIP stream.  PyTorch is plumbing here: allocation and stream ownership only.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -242,7 +241,7 @@ class ConvPairs:
 # phase-1 tiles per chunk launch of the balanced chunking: None = three rounds of one-tile workgroups less 16 = 3 x the CU count - 16
 # (752 on MI355X).  Rounds 3-4, fp32 partial rows: two rounds (512; 768 was slower -- 200 MB of partial rows per chunk).  Round 5, 24-bit
 # partial rows (150 MB per 768 tiles): 752 / 768 beat 512 by 1.1 % of the scene, 640 (2.5 rounds) loses 4 %, 1024 is 0.5 % behind 768
-CONV_TARGET_TILES = int(os.environ["GP_CONV_TARGET_TILES"]) if os.environ.get("GP_CONV_TARGET_TILES") else None
+CONV_TARGET_TILES = None       # (a tuning script may set it: scripts/conv_layer_time.py)
 
 
 def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
@@ -261,8 +260,6 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
     if isinstance(chunk_rows, str):
         if chunk_rows != "balanced":
             raise ValueError(f"conv_pairs_build: chunk_rows={chunk_rows!r}")
-        if os.environ.get("GP_CONV_CHUNK_ROWS"):                      # A/B timing: equal heights instead (8192 = rounds 3-4)
-            chunk_rows = int(os.environ["GP_CONV_CHUNK_ROWS"])
     if isinstance(chunk_rows, str):
         granule = 256
         max_chunks = (nv + granule - 1) // granule
@@ -306,7 +303,7 @@ def conv_weights_split(w, scale_pow2, blocked=None):
     lib = _lib.load()
     kv, cin, cout = w.shape
     if blocked is None:
-        blocked = cin % 32 == 0 and cout % 256 == 0 and os.environ.get("GP_CONV_WEIGHTS_BLOCKED", "1") != "0"   # (0: A/B against [kv,cout,cin])
+        blocked = cin % 32 == 0 and cout % 256 == 0
     if blocked:
         hi = torch.empty((kv, cout // 256, cin // 32, 256, 32), dtype=torch.float16, device=w.device)
         lo = torch.empty_like(hi)
@@ -364,7 +361,7 @@ def pow2_scale(x, d=None):
 
 
 def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=None, relu=False, out=None,
-                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None, want_f32=True):
+                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None, want_f32=True, fp32_partials=False):
     """x fp32 [nv, >=cin] and/or x_split=(hi, lo) f16 (pre-split operand -> LDS-DMA path);
     out_split=(hi, lo) f16 buffers to also receive the split output.  x_row_inv fp32 [nv]: the per-row inverse scales of
     a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled).
@@ -372,7 +369,10 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     needs no fp32 copy.
     INTERLEAVED rows: any of x_split / out_split / residual may be (t, None[, row_inv]) with t f16 [nv, 2 * channels] holding per 32-channel
     step [hi 32 | lo 32]: the LDS-DMA kernel stages a row and step as one full 128-byte line (interleave_planes / deinterleave_planes
-    convert)."""
+    convert).
+    fp32_partials=True: the partial rows between the two phases as fp32 (the format of rounds 1-4, which the 24-bit block-floating rows
+    are checked against; also what a call takes by itself when a chunk's 24-bit rows would pass 4 GiB) -- an explicit argument of the
+    call (plane_flags bit 3), not a process-wide switch."""
     lib = _lib.load()
     res_planes = residual if isinstance(residual, (tuple, list)) else None
     if res_planes is not None:
@@ -390,7 +390,7 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     yh, yl = out_split if out_split is not None else (None, None)
     # interleaved rows ([K step][hi 32 | lo 32], ONE tensor of 2 x channels halfs per row): given as (tensor, None)
     plane_flags = (1 if (xh is not None and xl is None) else 0) | (2 if (yh is not None and yl is None) else 0) | \
-                  (4 if (rh is not None and rl is None) else 0)
+                  (4 if (rh is not None and rl is None) else 0) | (8 if fp32_partials else 0)
     check(lib.gp_sparse_conv_f16x3(_ptr(x), x.stride(0) if x is not None else 0, _ptr(xh), _ptr(xl),
                                    xh.stride(0) if xh is not None else 0, _ptr(pairs.pair_in), _ptr(pairs.pair_pos),
                                    _ptr(pairs.pair_off), _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
@@ -729,12 +729,20 @@ def pool_cs_apply_chain(x_split, pong, op, d, applications, out_f32, out_scale=N
                                      int(applications), _ptr(out_f32), out_f32.stride(0), _ptr(out_scale), _ptr(op.dep), _ptr(op.flags),
                                      op.epoch & 0xFFFFFFFF, _stream()), "gp_pool_cs_apply_chain")
     op.epoch += int(applications)
+    op.chain_done = torch.cuda.Event()                    # recorded on the LAUNCHING stream: pool_cs_chain_check waits for it
+    op.chain_done.record(torch.cuda.current_stream(xh.device))
     return out_f32
 
 
 def pool_cs_chain_check(op):
-    """Host side of the chained launch's contract: raise if the abort word is set (synchronises)."""
-    if getattr(op, "flags", None) is not None and int(op.flags[0].item()) != 0:
+    """Host side of the chained launch's contract: wait for the op's last chained launch (the event recorded on the stream that
+    launched it -- the caller may be on another stream) and raise if the abort word is set."""
+    if getattr(op, "flags", None) is None:
+        return
+    ev = getattr(op, "chain_done", None)
+    if ev is not None:
+        ev.synchronize()
+    if int(op.flags[0].item()) != 0:
         raise _lib.GeoPurifyHipError("gp_pool_cs_apply_chain: a workgroup waited 2 s for a dependency; the pooled features are invalid")
 
 

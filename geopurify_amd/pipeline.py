@@ -13,8 +13,6 @@ per-view visible counts (one readback).
 from dataclasses import dataclass, field
 from typing import List, Optional
 
-import os
-
 import numpy as np
 import torch
 
@@ -38,14 +36,18 @@ class StudentWeights:
     (gp_sparse_conv_f16x3: operands split hi+lo, weights pre-scaled by a power of two whose inverse
     is folded into the BN scale).  mode "f32": every layer on the exact-fp32 MFMA kernel."""
 
-    def __init__(self, state_dict, device, eps=1e-5, mode="f16x3"):
+    def __init__(self, state_dict, device, eps=1e-5, mode="f16x3", residual_from_planes=True, interleaved_rows=True, blocked_weights=True,
+                 head="f16x3"):
+        """The four options are explicit arguments since round 6 (rounds 4-5: environment switches, retired with their last same-box A/B --
+        DESIGN.md section 0): residual_from_planes (a residual block's input added back from the split planes its first convolution reads
+        instead of fp32 rows the producer writes as well: 43.05 -> 43.47 scenes/s), interleaved_rows (the layers hand each other
+        [K step][hi 32 | lo 32] rows, one full line per row and step: 44.0 -> 45.1), blocked_weights (step-blocked weight tiles:
+        43.72 -> 44.68), head ("f16x3": the 1x1x1 output layer on the matrix cores fused with F.normalize, 276 -> 98 us; "f32")."""
         sd = {k: v.detach() for k, v in state_dict.items()}
         self.mode = mode
-        # fast path: a residual block's input is added back from the split planes its first convolution reads (GP_RESIDUAL_PLANES=0: from
-        # fp32 rows, which the producing layer then writes as well -- rounds 1-5a)
-        self.residual_from_planes = os.environ.get("GP_RESIDUAL_PLANES", "1") != "0"
-        # ... and the layers hand each other INTERLEAVED rows, [K step][hi 32 | lo 32] (GP_ROWS_INTERLEAVED=0: separate hi / lo planes)
-        self.interleaved_rows = os.environ.get("GP_ROWS_INTERLEAVED", "1") != "0"
+        self.residual_from_planes = bool(residual_from_planes)
+        self.interleaved_rows = bool(interleaved_rows)
+        self.blocked_weights = bool(blocked_weights)
         w0 = sd["input_layer.0.kernel"].float()
         self.cin = w0.shape[1]
         self.cin_pad = _pad_to(self.cin, CONV_PAD)
@@ -64,9 +66,9 @@ class StudentWeights:
         self.embed = self.w_out.shape[1]
         # the 1x1x1 output layer on the same f16 hi/lo operator as the 3x3x3 layers, fused with F.normalize (gp_embed_head_f16x3)
         self.head = None
-        # (GP_EMBED_HEAD=f32: the exact-fp32 kernel + l2norm_rows_ of rounds 1-3, for A/B timing)
+        # (head="f32": the exact-fp32 kernel + l2norm_rows_ of rounds 1-3)
         if (mode == "f16x3" and self.embed == 128 and self.hidden % 64 == 0 and all(l[0] == "f16x3" for l in self.layers)
-                and os.environ.get("GP_EMBED_HEAD", "f16x3") != "f32"):
+                and head != "f32"):
             amax = float(self.w_out.abs().max().item())
             p2 = 2.0 ** int(np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
             hi, lo = ops.conv_weights_split(self.w_out.reshape(1, self.hidden, self.embed), p2, blocked=False)   # the dense head's operand
@@ -87,7 +89,7 @@ class StudentWeights:
             # half (the inverse goes into the BatchNorm scale; powers of two, exact)
             amax = float(w.abs().max().item())
             p2 = 2.0 ** int(np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
-            hi, lo = ops.conv_weights_split(w, p2)
+            hi, lo = ops.conv_weights_split(w, p2, blocked=None if self.blocked_weights else False)
             self.layers.append(("f16x3", (hi, lo), (scale / p2).contiguous(), shift))
         else:
             self.layers.append(("f32", w, scale, shift))
@@ -364,21 +366,22 @@ class HotPath:
     constants (affinity_module.py:1492-1493,1584-1587) exposed as options."""
 
     def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda",
-                 pool_mode="auto", pool_tile_rows=8, pool_block_rows=64, batch_views=True):
+                 pool_mode="auto", pool_tile_rows=8, pool_block_rows=64, batch_views=True, pool_structure_ahead=True, affinity_mfma=True,
+                 all_views_max_pairs=2e11):
         self.student = student
         self.batch_views = batch_views                 # lift all views of a scene in one set of launches when the inputs allow it
         # the all-views in-view fill is a brute-force search per view: sum over views of (queries x references) <= sum n_v^2 / 4
         # pair tests in fp64.  The limit is that COST (ADVICE r2; round 3 had a fixed 131 072 visible points per view): config M
         # (80 views of 30-60k visible points) is 4e10 pair tests and takes the lift from 23.6 to 14.4 ms against the view-by-view
         # grid search; beyond 2e11 (a scene with views of several hundred thousand visible points) the view-by-view path is taken.
-        self.all_views_max_pairs = float(os.environ.get("GP_ALL_VIEWS_MAX_PAIRS", "2e11"))
+        self.all_views_max_pairs = float(all_views_max_pairs)
         self.pool_mode, self.pool_tile_rows, self.pool_block_rows = pool_mode, pool_tile_rows, pool_block_rows
         # `prepare` also builds the pooling operator's structure (gp_pool_cs_structure) so that the affinity kernel writes the
-        # weights in fragment order and no fill pass sits between the student and the pooling (GP_POOL_STRUCTURE_AHEAD=0: the
-        # two-pass form of rounds 3-4, for A/B timing)
-        self.pool_structure_ahead = os.environ.get("GP_POOL_STRUCTURE_AHEAD", "1") != "0"
-        # rows 11 + operator fill as one matrix-core kernel (GP_AFFINITY_MFMA=0: affinity_block_kernel + dst table, for A/B timing)
-        self.affinity_mfma = os.environ.get("GP_AFFINITY_MFMA", "1") != "0"
+        # weights in fragment order and no fill pass sits between the student and the pooling (pool_structure_ahead=False: the
+        # two-pass form of rounds 3-4; last A/B 25.61 = 25.61 ms per scene: the pass left the critical path, the work stayed)
+        self.pool_structure_ahead = bool(pool_structure_ahead)
+        # rows 11 + operator fill as one matrix-core kernel (affinity_mfma=False: affinity_block_kernel + dst table; last A/B 26.08 -> 25.72 ms)
+        self.affinity_mfma = bool(affinity_mfma)
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
         self.device = torch.device(device)
@@ -441,7 +444,7 @@ class HotPath:
         all_views = (self.batch_views and batched and scores_all is not None and ent is not None and ent["total"] > 0
                      and ent["num_views"] <= 128 and ent.get("sum_nv2", float(ent["max_nv"]) ** 2 * ent["num_views"]) / 4 <= self.all_views_max_pairs
                      and torch.is_tensor(pm_all) and pm_all.dim() == 4 and pm_all.is_contiguous()
-                     and pm_all.shape[0] >= ent["num_views"])
+                     and pm_all.shape[0] >= ent["num_views"] and pm_all.shape[1] <= 1024)        # (Q <= 1024: the score sort's LDS table; else view by view)
         if all_views:
             # every view of the scene in one set of launches: segments, in-view fill and the point -> (view, segment) lists
             _, start, pvv, pvs = ops.lift_masks_views(pm_all, scores_all, self._tap_tables(pm_all.shape[2], pm_all.shape[3]),
@@ -573,7 +576,6 @@ class HotPath:
                              "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
             if mode == "mfma_chain" and (state["pool"]["op"].dst is not None or state["pool"]["op"].valid is not None):   # (the lists need bu_row only)
                 ops.pool_cs_deps(state["pool"]["op"])
-            self.pool_chain_check()                         # this host is synchronised here anyway: earlier scenes' abort words
             mark("pool plan+split")
         return state
 
@@ -615,7 +617,7 @@ class HotPath:
         mode = self.pool_mode
         mfma_ok = D == 512 and self.pool_block_rows * self.K <= 16384 and self.num_iters >= 1
         cs_ok = D == 512 and 128 * self.K <= 12288 and self.num_iters >= 1
-        tiles_ok = self.num_iters > 1 and self.pool_tile_rows * self.K <= 1536 and D % 512 == 0
+        tiles_ok = self.num_iters > 1 and self.pool_tile_rows * self.K <= 1536 and (D % 512 == 0 or D == 64)     # (D = 64: pool_tiles64_kernel, config P)
         if mode == "auto":
             mode = ("mfma_cs" if cs_ok else "mfma") if ((cs_ok or mfma_ok) and self.num_iters >= 3) else ("tiles" if tiles_ok else "ell")
         if mode in ("mfma", "mfma_persist") and not mfma_ok:
@@ -631,7 +633,7 @@ class HotPath:
         dev = X.device
         mode = self._pool_mode(D)
         R = self.pool_tile_rows
-        tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and D % 512 == 0
+        tiles_ok = self.num_iters > 1 and R * self.K <= 1536 and (D % 512 == 0 or D == 64)
         if w is None and (plan is None or not plan["op"].filled):
             # (isolated calls after a scene whose weights went straight into fragments: the [Nv, K] weights from the embedding planes)
             E = self._last_E
@@ -663,7 +665,8 @@ class HotPath:
                 if op.dep is None:
                     ops.pool_cs_deps(op)
                 ops.pool_cs_apply_chain(sp[0], sp[1], op, D, self.num_iters, out, out_scale=sc[1:2])
-                self._chain_ops.append(op)
+                if op not in self._chain_ops:            # (an operator re-applied by isolated timing passes is pending once)
+                    self._chain_ops.append(op)
                 self._pool_kernel = "cs_chain_kernel"
                 return out
             src = sp[0]
@@ -710,7 +713,7 @@ class HotPath:
             else:
                 ops.pool_ell(cur, nbr, w, D, bufs[t % 2])
             cur = bufs[t % 2]
-        self._pool_kernel = "pool_tiles_kernel" if use_tiles else "pool_ell_kernel"
+        self._pool_kernel = ("pool_tiles64_kernel" if D == 64 else "pool_tiles_kernel") if use_tiles else "pool_ell_kernel"
         return cur
 
     def evaluate_scene(self, batch: SceneBatch, vlm):
@@ -722,13 +725,27 @@ class HotPath:
             F, text, scale = self.lift_masks(batch, vlm)
         if self.keep_lifted:                 # (parity tests compare the lift stage too; off by default: the tensor is 300 MB at S)
             self.last_lifted = F
-        return {"scene_features": self.refine(batch, F), "text_features": text, "logit_scale": scale}
+        feats = self.refine(batch, F)
+        if self._chain_ops:
+            self.pool_chain_check()                        # (chained pooling only: never hand out features of a launch that gave up)
+        return {"scene_features": feats, "text_features": text, "logit_scale": scale}
 
-    def pool_chain_check(self):
-        """Host side of gp_pool_cs_apply_chain's contract: raise if a chained pooling launch gave up (synchronises on the words)."""
-        pending, self._chain_ops = self._chain_ops, []
-        for op in pending:
+    def pool_chain_check(self, block=True):
+        """Host side of gp_pool_cs_apply_chain's contract: raise if a chained pooling launch gave up.  Waits for each pending operator's
+        launch (the event recorded on the launching stream) before it reads the abort word, and forgets an operator only after the read.
+        block=False reads only the operators whose launch has already finished (no stall: classify_and_count of the next scenes);
+        the blocking form runs where the consumer synchronises anyway: HotPath.evaluate_scene / the trainer's evaluate_scene before they
+        return features of a chained launch, the end of bench.py's timed region, the tests."""
+        keep = []
+        while self._chain_ops:
+            op = self._chain_ops[0]
+            ev = getattr(op, "chain_done", None)
+            if not block and ev is not None and not ev.query():        # still running: a later call (or the blocking one) reads it
+                keep.append(self._chain_ops.pop(0))
+                continue
             ops.pool_cs_chain_check(op)
+            self._chain_ops.pop(0)
+        self._chain_ops = keep
 
     # ---- row 13 + caller tail --------------------------------------------------------------------
     def classify_and_count(self, result, labels, num_classes, ignore_ids, counts):
@@ -739,6 +756,8 @@ class HotPath:
         else:
             pred, zero = ops.classify_argmax(feats, text_norm, result["logit_scale"])
         ops.iou_hist(pred, labels, num_classes, ignore_ids, counts)
+        if self._chain_ops:
+            self.pool_chain_check(block=False)             # (chained pooling only: abort words of launches that have finished)
         return pred, zero
 
 

@@ -132,7 +132,11 @@ int gp_sparse_conv(const float *x, int64_t ld_x, const int32_t *nbr_map, int64_t
 /* (x fp32), 24-bit block floating point on the LDS-DMA path (x_hi / x_lo; 3 bytes per element + one    */
 /* exponent byte per (pair row, 128 columns): rounded within 2^-22 of the quarter's largest magnitude,   */
 /* the rounding of the f16 hi + lo split that follows; an Inf / NaN activation row makes the output      */
-/* rows that gather it NaN); its contents are private to the call.  Epilogue as gp_sparse_conv (the     */
+/* rows that gather it NaN -- so does ONE overflowing element of a partial row: its whole 128-column    */
+/* quarter is marked, where fp32 rows kept Inf in that element and finite neighbours.  The 24-bit rows   */
+/* use 32-bit byte offsets: a call whose largest chunk holds pairs * cout * 3 >= 4 GiB runs on fp32     */
+/* partial rows instead, decided before the first launch); its contents are private to the call.        */
+/* Epilogue as gp_sparse_conv (the                                                                       */
 /* caller folds 1/scale_pow2 into `scale`).  cin % 32 == 0, cout % 256 == 0, |x| < 65504.              */
 size_t gp_conv_pairs_workspace_bytes(int64_t nv, int32_t kv);
 int gp_conv_pairs_build(const int32_t *nbr_map, int64_t nv, int32_t kv, int32_t num_chunks, const int32_t *chunk_row_off,
@@ -237,6 +241,7 @@ int gp_pool_ell(const float *x, int64_t ld_x, const int32_t *nbr, const float *w
 /* Morton-adjacent rows (r in {4,8,16}); per tile the union of its rows' neighbours and a dense        */
 /* [union, r] weight block.  count: tile_off i64 [ntiles+1] (exclusive scan; last = total entries,     */
 /* read it back to size u_row i32 [total] and u_w f32 [total, r]); fill; apply = one application.       */
+/* apply: d a multiple of 256 (r = 4, 8, 16), or d = 64 with r = 4 or 8 (a tile per wave).               */
 size_t gp_pool_tiles_workspace_bytes(int64_t nv, int32_t r);
 int gp_pool_tiles_count(const int32_t *nbr, int64_t nv, int32_t k, int32_t r, int64_t *tile_off,
                         void *workspace, size_t workspace_bytes, void *stream);
@@ -389,6 +394,10 @@ int gp_lift_masks_view(const float *pred_masks, int32_t q, int32_t h, int32_t w,
 /* partial-result arrays: 1..total, or 0 = total.  ANY value gives the same results -- queries beyond the capacity are     */
 /* answered by one block per 256 of them sweeping the view's whole reference range -- a capacity near the expected query   */
 /* count keeps the fill fully parallel and the workspace small (192 B per unit of capacity).                               */
+/* Preconditions: Q <= 1024 (a view's scores are sorted in LDS; more: GP_EINVAL -- lift view by view with                  */
+/* gp_lift_masks_view, which takes any Q), and scores >= 0 (they are softmax maxima in the reference, :544): the kernel      */
+/* visits a pixel's queries in descending score order and stops once the next 64 scores lie below the best                   */
+/* score x sigmoid(logit) found, which bounds a candidate only while sigmoid <= 1 multiplies a non-negative score.            */
 size_t gp_lift_masks_views_workspace_bytes(int32_t nsrc, int32_t q, int32_t h, int32_t w, int64_t total, int64_t n,
                                            int64_t fill_cap);
 int gp_lift_masks_views(const float *pred_masks, int32_t nsrc, int32_t q, int32_t h, int32_t w, const float *scores,

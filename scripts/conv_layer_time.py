@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One 512->512 layer of the S scene (pre-split operands in, split planes out), median of 5 x 12 launches after 30 warm ones.
-usage: conv_layer_time.py [chunk_rows | balanced ...]     (environment switches apply: GP_CONV_P2_WG_PER_CU, GP_CONV_TARGET_TILES, GP_SCENE_SEED)"""
+usage: conv_layer_time.py [chunk_rows | balanced ...]     (environment: GP_CONV_TARGET_TILES sets ops.CONV_TARGET_TILES for this script, GP_SCENE_SEED the scene)"""
 import os
 import sys
 import dataclasses
@@ -10,6 +10,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geopurify_amd import ops, pipeline as pl, synthetic as syn  # noqa: E402
+
+if os.environ.get("GP_CONV_TARGET_TILES"):
+    ops.CONV_TARGET_TILES = int(os.environ["GP_CONV_TARGET_TILES"])
 
 cfg = dataclasses.replace(syn.CONFIGS["S"], num_views=1)
 SEED = int(os.environ.get("GP_SCENE_SEED", "5557"))
@@ -47,5 +50,5 @@ for chunk_rows in [a if a == "balanced" else int(a) for a in sys.argv[1:]] or ["
     to = np.array(list(pairs.chunk_tile_off))
     tiles = np.diff(to) * 2
     print(f"      seed {SEED}: Nv {Nv}, {pairs.num_chunks} launches, tiles per launch {tiles.min()}..{tiles.max()}, rounds of 256: {int(np.ceil(tiles / 256).sum())}", flush=True)
-    print(f"{os.environ.get('GP_CONV_P2_WG_PER_CU', 'default'):>8s} workgroups per CU in phase 2, chunk {str(chunk_rows):>8s} (target {ops.CONV_TARGET_TILES or 'auto'}): layer {np.median(ts):6.3f} ms "
+    print(f"chunk {str(chunk_rows):>8s} (target {ops.CONV_TARGET_TILES or 'auto'}): layer {np.median(ts):6.3f} ms "
           f"(min {min(ts):6.3f}, max {max(ts):6.3f}); checksum {chk:.6e}", flush=True)

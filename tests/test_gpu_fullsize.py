@@ -186,16 +186,12 @@ def test_conv_paths_agree_full_size(big):
     assert (a - b).abs().max() < 2e-5 * max(1.0, float(b.abs().max()))               # f16x3 == exact fp32 MFMA
     xs = ops.split_f16(X)
     # the LDS-DMA path keeps its partial rows as 24-bit block floating point (within 2^-22 of a 128-column quarter's largest magnitude per
-    # partial row, <= 27 partial rows per output row); with the fp32 rows of the tuning twin (knob 3, bit 5) it is the register
+    # partial row, <= 27 partial rows per output row); with the fp32 rows of the tuning twin (fp32_partials=True: plane_flags bit 3) it is the register
     # path's arithmetic bit for bit
     c = ops.sparse_conv_f16x3(None, pairs, hi, lo, sc, None, x_split=xs)
     from geopurify_amd._lib import load
     lib = load()
-    assert lib.gp_debug_set(3, 32) == 0
-    try:
-        c32 = ops.sparse_conv_f16x3(None, pairs, hi, lo, sc, None, x_split=xs)
-    finally:
-        assert lib.gp_debug_set(3, 0) == 0
+    c32 = ops.sparse_conv_f16x3(None, pairs, hi, lo, sc, None, x_split=xs, fp32_partials=True)
     assert torch.equal(a, c32)                                                        # register path == LDS-DMA path (fp32 partial rows)
     pmax = float((b.abs().max() * 32.0))                                              # (partial rows carry the weights' 2^5)
     assert (c - a).abs().max().item() <= 27 * 2.0 ** -22 * pmax / 32.0
@@ -379,9 +375,35 @@ def test_config_m_full_size_properties():
     assert torch.equal(F_one, r["F"])
 
 
+def test_config_s_full_size_properties():
+    """BASELINE configs[1] -- the HEADLINE workload of bench.py -- at its full size under pytest: 150k points, all 25 views (648 x 484
+    images, Q = 200 masks each), D = 512, K = 96, T = 19, student 518 -> 512 x 9 -> 128, through the default kernels; checked by the
+    size-independent properties, and a second run from the same inputs must give the same bits (every kernel on the path is
+    deterministic).  The all-views lift equals the view-by-view lift at 25 views."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _scene_run("S", 5557, 19)
+    cfg, hp, batch, pl = r["cfg"], r["hp"], r["batch"], r["pl"]
+    assert cfg.num_points == 150_000 and cfg.num_views == 25 and cfg.feat_dim == 512 and not cfg.dense_features
+    nv = _check_scene_properties(r)
+    assert 0.7 * cfg.num_points < nv < cfg.num_points and hp.stats["pool_kernel"] == "cs_pool_kernel"
+    assert 20 <= len(batch.views) <= 25 and batch.ent is not None and batch.ent["num_views"] == 25
+    assert batch.ent["sum_nv2"] / 4 <= hp.all_views_max_pairs                                         # the all-views path ran
+    assert hp.student.fast and hp.student.interleaved_rows and hp.student.residual_from_planes          # the layers bench.py times
+    again = hp.refine(batch, r["F"])
+    assert torch.equal(again, r["feats"])
+    b_one = pl.build_scene_batch(pl.upload_scene(r["scene"], "cuda"), r["rigid"], "cuda", batch_views=False)
+    hp1 = pl.HotPath(hp.student, cfg.mask_shape, K=96, num_iters=1, device="cuda", batch_views=False)
+    F_one, _, _ = hp1.lift_masks(b_one, r["vlm"])
+    assert torch.equal(F_one, r["F"])
+    # a lifted row is a convex combination of unit-norm segment embeddings (or a nearest-point copy of one)
+    nrm = r["F"].norm(dim=1)
+    assert bool((nrm > 0).all()) and bool((nrm < 1 + 1e-4).all())
+
+
 def test_config_p_full_size_properties():
-    """BASELINE configs[0] at its full size: 50k points, ONE view, 64-d dense features (lift a5), T = 19; the generic ELL
-    pooling kernel (D = 64) and the f16x3 student with a 70-channel input layer."""
+    """BASELINE configs[0] at its full size: 50k points, ONE view, 64-d dense features (lift a5), T = 19; the D = 64 tiled
+    pooling kernel (pool_tiles64_kernel, round 6; rounds 1-5: the generic ELL kernel) and the f16x3 student with a 70-channel input layer."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     r = _scene_run("P", 7, 19)
@@ -389,7 +411,18 @@ def test_config_p_full_size_properties():
     assert cfg.num_points == 50_000 and cfg.num_views == 1 and cfg.feat_dim == 64 and cfg.dense_features
     nv = _check_scene_properties(r)
     assert 0.7 * cfg.num_points < nv < cfg.num_points
-    assert r["hp"].stats["pool_kernel"] == "pool_ell_kernel"
+    assert r["hp"].stats["pool_kernel"] == "pool_tiles64_kernel"
+    # the tiled kernel against the generic one on this scene's operator: same sums in another fp32 order
+    from geopurify_amd import ops
+    X, nbr, w, Nv, D = r["hp"]._last_pool_inputs
+    if w is None:
+        E = r["hp"]._last_E
+        E = (E[0].float() + E[1].float()) / ops.AFFINITY_PLANE_SCALE if isinstance(E, tuple) else E
+        w = ops.affinity_softmax(E.contiguous(), nbr, r["hp"].sharpen)
+    y_t, y_e = torch.empty((Nv, D), device="cuda"), torch.empty((Nv, D), device="cuda")
+    ops.pool_tiles_apply(X, ops.pool_tiles_build(nbr, w, 8), D, y_t)
+    ops.pool_ell(X, nbr, w, D, y_e)
+    assert (y_t - y_e).abs().max() < 1e-5
     # dense lift: a seen point's feature is the mean of its pixels' columns; every point has one (nearest-seen fill): no zero rows
     assert bool((r["F"].abs().sum(1) > 0).all())
 

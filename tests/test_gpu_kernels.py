@@ -688,15 +688,11 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     ys = tuple(torch.empty((Nv, 256), dtype=torch.float16, device="cuda") for _ in range(2))
     y2 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs,
                                out_split=ys)
-    # ... with fp32 partial rows (tuning twin, knob 3 bit 5); the product kernel stores them as 24-bit block floating point: a
+    # ... with fp32 partial rows (fp32_partials=True); the product kernel stores them as 24-bit block floating point: a
     # partial row is rounded within 2^-22 of the largest magnitude of its 128-column quarter, an output row sums at most 27 of them
     from geopurify_amd._lib import load
     lib = load()
-    assert lib.gp_debug_set(3, 32) == 0
-    try:
-        y2f = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs)
-    finally:
-        assert lib.gp_debug_set(3, 0) == 0
+    y2f = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=dev(res), relu=True, x_split=xs, fp32_partials=True)
     assert torch.equal(y2f, y)
     part_max = float((ref - sh.double() - res.double()).abs().max() / sc.min())      # bound on any partial sum's magnitude
     assert (y2 - y).abs().max().item() <= 27 * 2.0 ** -22 * part_max * float(sc.max())
@@ -720,16 +716,12 @@ def test_sparse_conv_f16x3_matches_fp32_accuracy(ops):
     assert torch.equal(y4, y3)
     h4, l4 = ops.deinterleave_planes(y_il)
     assert torch.equal(h4, ys3[0]) and torch.equal(l4, ys3[1])
-    # ... and through the fp32-partial twin (knob 3 bit 5: the round 1-4 phase-2 kernel, four columns per lane) the same equality
-    assert lib.gp_debug_set(3, 32) == 0
-    try:
-        ys5 = tuple(torch.empty((Nv, 256), dtype=torch.float16, device="cuda") for _ in range(2))
-        y5 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(rh, rl, rinv), relu=True, x_split=xs, out_split=ys5)
-        y_il5 = torch.full((Nv, 512), float("nan"), dtype=torch.float16, device="cuda")
-        y6 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(ops.interleave_planes(rh, rl), None, rinv), relu=True,
-                                   x_split=(ops.interleave_planes(*xs), None), out_split=(y_il5, None))
-    finally:
-        assert lib.gp_debug_set(3, 0) == 0
+    # ... and through the fp32-partial twin (fp32_partials=True: the round 1-4 phase-2 kernel, four columns per lane) the same equality
+    ys5 = tuple(torch.empty((Nv, 256), dtype=torch.float16, device="cuda") for _ in range(2))
+    y5 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(rh, rl, rinv), relu=True, x_split=xs, out_split=ys5, fp32_partials=True)
+    y_il5 = torch.full((Nv, 512), float("nan"), dtype=torch.float16, device="cuda")
+    y6 = ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc / p2), dev(sh), residual=(ops.interleave_planes(rh, rl), None, rinv), relu=True,
+                               x_split=(ops.interleave_planes(*xs), None), out_split=(y_il5, None), fp32_partials=True)
     h6, l6 = ops.deinterleave_planes(y_il5)
     assert torch.equal(y6, y5) and torch.equal(h6, ys5[0]) and torch.equal(l6, ys5[1])
     # the split kernel writes that form itself (lo = NULL): the same halves as its planes
@@ -797,7 +789,7 @@ def test_conv_partial_rows_24bit_encoding_byte_for_byte(ops):
     """The partial rows between the two phases are BYTES with a stated format (include/geopurify_hip.h): per pair
     row and 128-column quarter an exponent byte E = the exponent field of (largest |v| + 1 ulp) and per element u = rint(v 2^(148 - E)) +
     2^22 in three little-endian bytes; a quarter's 384 bytes = its 16 lanes' first 16 bytes, then their last 8; the exponent bytes follow
-    the rows.  Restated in numpy (oracle/conv_partial.py) from the fp32 partial rows the tuning twin leaves in the same buffer (knob 3, bit 5) and compared
+    the rows.  Restated in numpy (oracle/conv_partial.py) from the fp32 partial rows the tuning twin leaves in the same buffer (fp32_partials=True: plane_flags bit 3) and compared
     byte for byte; the decoded values are within half a unit 2^(E - 149) <= 2^-22 of the quarter's maximum of the fp32 rows."""
     from geopurify_amd._lib import load
     lib = load()
@@ -814,12 +806,8 @@ def test_conv_partial_rows_24bit_encoding_byte_for_byte(ops):
     hi, lo = ops.conv_weights_split(dev(W), 16.0)
     xh, xl, inv = ops.split_f16(dev(X), per_row=True)
     sc = torch.full((cout,), 1.0 / 16.0)
-    assert lib.gp_debug_set(3, 32) == 0
-    try:
-        ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc), None, x_split=(xh, xl), x_row_inv=inv)
-        P32 = pairs.partial[:pairs.num_pairs, :cout].clone().cpu().numpy()
-    finally:
-        assert lib.gp_debug_set(3, 0) == 0
+    ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc), None, x_split=(xh, xl), x_row_inv=inv, fp32_partials=True)
+    P32 = pairs.partial[:pairs.num_pairs, :cout].clone().cpu().numpy()
     ops.sparse_conv_f16x3(None, pairs, hi, lo, dev(sc), None, x_split=(xh, xl), x_row_inv=inv)
     raw = pairs.partial.view(torch.uint8).flatten().cpu().numpy()
     P = pairs.num_pairs
@@ -963,6 +951,22 @@ def test_pool_tiles_matches_ell_and_oracle(ops, R):
     assert (ca - cb).abs().max() < 1e-5                                # same operator, different fp32 order
     ref = o_aff.pool_gather(X[:, :D], nbr.cpu().long(), w.cpu(), T)
     assert (ca.cpu().double() - ref).abs().max() < 1e-5
+    if R in (4, 8):
+        # the same operator at D = 64 (config P's width): one tile per wave, its union dealt over the four 16-lane quarters (pool_tiles64_kernel); rows of a
+        # wider matrix (ld 96), unions that are no multiple of 16
+        X6 = dev(torch.randn(Nv, 96))
+        a6 = [torch.empty((Nv, 64), device="cuda") for _ in range(2)]
+        b6 = [torch.empty((Nv, 64), device="cuda") for _ in range(2)]
+        ca, cb = X6, X6
+        for t in range(T):
+            ops.pool_tiles_apply(ca, tiles, 64, a6[t % 2]); ca = a6[t % 2]
+            ops.pool_ell(cb, nbr, w, 64, b6[t % 2]); cb = b6[t % 2]
+        assert (ca - cb).abs().max() < 1e-5
+        ref6 = o_aff.pool_gather(X6[:, :64].cpu(), nbr.cpu().long(), w.cpu(), T)
+        assert (ca.cpu().double() - ref6).abs().max() < 1e-5
+    else:
+        with pytest.raises(Exception, match="d=64"):
+            ops.pool_tiles_apply(dev(torch.randn(Nv, 64)), tiles, 64, torch.empty((Nv, 64), device="cuda"))
 
 
 @pytest.mark.parametrize("n_vox,K,BR", [(130, 96, 64), (70, 32, 64), (130, 32, 128), (65, 8, 64)])

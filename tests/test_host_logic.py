@@ -302,13 +302,13 @@ def test_bench_rank_watchdog_and_config_v_default():
         per = bench.default_val_scenes(n)
         assert per == -(-312 // n) and len(bench.val_scene_sizes(per, n)) == 312      # the whole list, every scene once
     assert sorted(bench.val_scene_sizes(39, 8)) == sorted(bench.val_scene_sizes(312, 1))
-    if torch.cuda.is_available():
-        return                                                                        # (the hang below is staged before the GPU assertion)
+    # (runs on GPU boxes too: the ranks sleep BEFORE their first GPU call -- the hidden --selftest-hang flag -- and the parent, which never
+    # touches the GPU, kills the child's process group)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["GP_BENCH_SELFTEST_HANG"] = "all"            # every rank sleeps instead of running (a lone sleeper is reaped by the launcher)
     t0 = time.time()
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "T", "--no-cpu-baseline",
-                          "--rank-timeout", "45"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+                          "--rank-timeout", "45", "--selftest-hang", "all"],     # every rank sleeps (a lone sleeper is reaped by the launcher)
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 124, (out.returncode, out.stderr[-2000:])
     assert time.time() - t0 < 200
     assert "still running after 45 s" in out.stderr and "last stderr lines of the ranks" in out.stderr
