@@ -51,6 +51,9 @@ def parse():
                          "bounded sub-sampled scene extrapolated per stage")
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
     ap.add_argument("--pool-mode", default=os.environ.get("GP_POOL_MODE", "auto"), choices=["auto", "mfma_cs", "mfma_chain", "mfma_engine", "mfma", "mfma_persist", "tiles", "ell"])
+    ap.add_argument("--pool-row-order", default="rcb", choices=["rcb", "morton"],
+                    help="row order of the pooling operator: rcb (default: recursive coordinate bisection inside 2048-row Morton chunks into the "
+                         "operator's 128-row blocks, smaller neighbour unions) or morton (the voxel order itself: rounds 1-5)")
     ap.add_argument("--api", default="both", choices=["device", "both"],
                     help="both: after the headline run also time the DROP-IN call SonataXAffinityTrainer.evaluate_scene(20-tuple of "
                          "CPU tensors) (run/validation.py:408), reported as the extra object `api_tuple` -- never as `value`")
@@ -720,7 +723,8 @@ def main():
         args.steps = max(len(todo), 1)
     sd = pl.random_student_state_dict(cfg.feat_dim + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
     student = pl.StudentWeights(sd, dev)
-    hp = pl.HotPath(student, cfg.mask_shape, K=96, sharpen=20.0, num_iters=args.pool_iters, device=dev, pool_mode=args.pool_mode)
+    hp = pl.HotPath(student, cfg.mask_shape, K=96, sharpen=20.0, num_iters=args.pool_iters, device=dev, pool_mode=args.pool_mode,
+                    pool_row_order=args.pool_row_order)
     counts = torch.zeros((3, cfg.num_classes), dtype=torch.int64, device=dev)
     pool_timer = PoolTimer()
     pool_timer.wrap(ops)
@@ -945,13 +949,13 @@ def main():
         # the same launches with nothing else on the GPU (with --streams 2 the timed region overlaps the pooling
         # of one scene with the loader/lift kernels of the next, which share its L2 and HBM bandwidth): one warm pass
         # (operator build, allocator, clocks), then three timed passes; the median pass is reported
-        hp._pool(*hp._last_pool_inputs)
+        hp._pool(*hp._last_pool_inputs, plan=hp._last_pool_plan)
         hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
         torch.cuda.synchronize()
         alone = []
         for _ in range(3):
             pool_timer.events, pool_timer.enabled = [], True
-            hp._pool(*hp._last_pool_inputs)
+            hp._pool(*hp._last_pool_inputs, plan=hp._last_pool_plan)
             hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
             torch.cuda.synchronize()
             pool_timer.enabled = False
@@ -968,13 +972,13 @@ def main():
             lib = _lib.load()
             lib.gp_debug_set(4, 9)
             try:
-                hp._pool(*hp._last_pool_inputs)
+                hp._pool(*hp._last_pool_inputs, plan=hp._last_pool_plan)
                 hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
                 torch.cuda.synchronize()
                 cl = []
                 for _ in range(3):
                     pool_timer.events, pool_timer.enabled = [], True
-                    hp._pool(*hp._last_pool_inputs)
+                    hp._pool(*hp._last_pool_inputs, plan=hp._last_pool_plan)
                     hp.pool_chain_check()                    # (chained launches of these isolated passes: read and forget their operators)
                     torch.cuda.synchronize()
                     pool_timer.enabled = False
@@ -1028,7 +1032,7 @@ def main():
                        "sharding": (f"{shard['policy']} assignment of {shard['scenes_total']} scenes to {world} rank(s), " if val_mode else
                                     f"1 scene per GPU x {world}, ") + "one int64 all-reduce of IoU counts",
                        "streams": len(streams), "schedule": "split" if split else "alternate",
-                       "pool_mode": args.pool_mode, "library": os.path.relpath(_lib_path(), ROOT),
+                       "pool_mode": args.pool_mode, "pool_row_order": args.pool_row_order, "library": os.path.relpath(_lib_path(), ROOT),
                        "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GP_")}},
             "roofline": {"kernel": hp.stats["pool_kernel"] + (f" (affinity pooling, all {args.pool_iters} applications of A in one launch)"
                                                               if hp.stats["pool_kernel"] == "cs_chain_kernel" else " (affinity pooling, one application of A)"),

@@ -48,9 +48,11 @@ SIGNATURES = {
                                        _P, _P, c_int64, _P, c_int32, c_int32, _P]),
     "gp_conv_weights_split_blocked": (c_int32, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
     "gp_pow2_scale": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_size_t, _P]),
-    "gp_split_f16_scaled": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P]),
+    "gp_split_f16_scaled": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P, _P]),
+    "gp_rcb_order": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    "gp_rows_renumber_i32": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "gp_l2norm_rows": (c_int32, [_P, c_int64, c_int32, c_int64, _P]),
-    "gp_embed_head_f16x3": (c_int32, [_P, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P, c_int64, _P, _P, c_float, _P]),
+    "gp_embed_head_f16x3": (c_int32, [_P, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P, c_int64, _P, _P, c_float, _P, _P]),
     "gp_knn_workspace_bytes": (c_size_t, [c_int64]),
     "gp_knn_lattice": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "gp_affinity_softmax": (c_int32, [_P, c_int64, c_int32, _P, c_int32, c_int64, c_float, _P, _P]),

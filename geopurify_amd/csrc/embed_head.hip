@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(EH_NT)
 embed_head_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_x, const float *__restrict__ x_row_inv,
                   const _Float16 *__restrict__ w_hi /*[128][cin]*/, const _Float16 *__restrict__ w_lo, int64_t nv, int cin, float out_scale,
                   int normalize, float *__restrict__ y, int64_t ld_y, _Float16 *__restrict__ e_hi, _Float16 *__restrict__ e_lo,
-                  float plane_scale) {
+                  float plane_scale, const int32_t *__restrict__ e_dst_row) {
     __shared__ EhSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fq = lane >> 4;
@@ -162,8 +162,9 @@ embed_head_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict_
             const int id = lane + 64 * t, lrow = id >> 4, piece = id & 15;
             const int64_t row = r0 + lrow;
             if (row < nv) {
-                *reinterpret_cast<f16x8 *>(e_hi + row * EH_COLS + piece * 8) = *reinterpret_cast<const f16x8 *>(st + lrow * EH_EP + piece * 8);
-                *reinterpret_cast<f16x8 *>(e_lo + row * EH_COLS + piece * 8) = *reinterpret_cast<const f16x8 *>(st + 32 * EH_EP + lrow * EH_EP + piece * 8);
+                const int64_t ro = e_dst_row ? (int64_t)e_dst_row[row] : row;          // (the plane row: gp_rcb_order's map when the operator is re-ordered)
+                *reinterpret_cast<f16x8 *>(e_hi + ro * EH_COLS + piece * 8) = *reinterpret_cast<const f16x8 *>(st + lrow * EH_EP + piece * 8);
+                *reinterpret_cast<f16x8 *>(e_lo + ro * EH_COLS + piece * 8) = *reinterpret_cast<const f16x8 *>(st + 32 * EH_EP + lrow * EH_EP + piece * 8);
             }
         }
     }
@@ -172,8 +173,9 @@ embed_head_kernel(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict_
 
 extern "C" int gp_embed_head_f16x3(const void *x_hi, const void *x_lo, int64_t ld_x, const float *x_row_inv_scale, const void *w_hi,
                                    const void *w_lo, int64_t nv, int32_t cin, int32_t cout, float out_scale, int32_t l2_normalize,
-                                   float *y, int64_t ld_y, void *e_hi, void *e_lo, float plane_scale, void *stream_) {
+                                   float *y, int64_t ld_y, void *e_hi, void *e_lo, float plane_scale, const int32_t *e_dst_row, void *stream_) {
     GP_CHECK_ARG(x_hi && x_lo && w_hi && w_lo && (y || e_hi) && nv > 0, "gp_embed_head_f16x3: null/empty argument");
+    GP_CHECK_ARG(!e_dst_row || e_hi, "gp_embed_head_f16x3: e_dst_row maps the rows of the output planes (e_hi / e_lo)");
     GP_CHECK_ARG((e_hi != nullptr) == (e_lo != nullptr) && (!e_hi || ((uintptr_t)e_hi % 16 == 0 && (uintptr_t)e_lo % 16 == 0 && plane_scale > 0.f)),
                  "gp_embed_head_f16x3: the output planes come as a 16-byte aligned pair with a positive scale");
     GP_CHECK_ARG(cout == EH_COLS, "gp_embed_head_f16x3: cout=%d, this kernel writes %d embedding channels", cout, EH_COLS);
@@ -186,7 +188,7 @@ extern "C" int gp_embed_head_f16x3(const void *x_hi, const void *x_lo, int64_t l
     embed_head_kernel<<<(unsigned)blocks, EH_NT, 0, gp_stream(stream_)>>>(
         static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_x, x_row_inv_scale, static_cast<const _Float16 *>(w_hi),
         static_cast<const _Float16 *>(w_lo), nv, cin, out_scale, l2_normalize, y, ld_y, static_cast<_Float16 *>(e_hi), static_cast<_Float16 *>(e_lo),
-        plane_scale);
+        plane_scale, e_dst_row);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

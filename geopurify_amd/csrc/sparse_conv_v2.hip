@@ -1088,11 +1088,12 @@ conv_phase2_q24_kernel(const unsigned char *__restrict__ pb, int64_t e_off, cons
 // (row_inv receives 2^-e(row)).  One wave per row in the per-row mode (d <= 1024... any d: two sweeps).
 __global__ void split_rows_scaled_kernel(const float *__restrict__ x, int64_t ld_x, int d, int64_t n, _Float16 *__restrict__ hi,
                                          _Float16 *__restrict__ lo, int64_t ld_h, const float *__restrict__ scale,
-                                         float *__restrict__ row_inv) {
+                                         float *__restrict__ row_inv, const int32_t *__restrict__ dst_row) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int lane = gp_lane();
     for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < n; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
         float s = scale ? scale[0] : 1.f;
+        const int64_t ro = dst_row ? (int64_t)dst_row[r] : r;            // (the row the halves are written to: gp_rcb_order's map)
         if (row_inv) {
             float amax = 0.f;
             for (int c = lane * 4; c < d; c += 256) {
@@ -1100,7 +1101,7 @@ __global__ void split_rows_scaled_kernel(const float *__restrict__ x, int64_t ld
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
             }
             s = gp_pow2_for(gp_wave_max(amax));
-            if (lane == 0) row_inv[r] = 1.f / s;
+            if (lane == 0) row_inv[ro] = 1.f / s;
         }
         for (int c = lane * 4; c < d; c += 256) {
             float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
@@ -1109,10 +1110,10 @@ __global__ void split_rows_scaled_kernel(const float *__restrict__ x, int64_t ld
 #pragma unroll
             for (int k = 0; k < 4; ++k) { h[k] = (_Float16)v[k]; l[k] = (_Float16)(v[k] - (float)h[k]); }
             if (lo) {
-                *reinterpret_cast<f16x4 *>(hi + r * ld_h + c) = h;
-                *reinterpret_cast<f16x4 *>(lo + r * ld_h + c) = l;
+                *reinterpret_cast<f16x4 *>(hi + ro * ld_h + c) = h;
+                *reinterpret_cast<f16x4 *>(lo + ro * ld_h + c) = l;
             } else {                                                   // interleaved rows: [32-column step][hi 32 | lo 32] in ONE tensor
-                _Float16 *ph = hi + r * ld_h + ((c >> 5) << 6) + (c & 31);
+                _Float16 *ph = hi + ro * ld_h + ((c >> 5) << 6) + (c & 31);
                 *reinterpret_cast<f16x4 *>(ph) = h;
                 *reinterpret_cast<f16x4 *>(ph + 32) = l;
             }
@@ -1306,13 +1307,13 @@ extern "C" int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n,
 }
 
 extern "C" int gp_split_f16_scaled(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
-                                   const float *scale, float *row_inv_scale, void *stream_) {
+                                   const float *scale, float *row_inv_scale, const int32_t *dst_row, void *stream_) {
     GP_CHECK_ARG(x && hi && n > 0 && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0, "gp_split_f16_scaled: bad argument");
     GP_CHECK_ARG(lo || (d % 32 == 0 && ld_h >= 2 * (int64_t)d), "gp_split_f16_scaled: lo = NULL asks for interleaved rows in hi: d %% 32 == 0 and ld_h >= 2 d");
     GP_CHECK_ARG(!(scale && row_inv_scale), "gp_split_f16_scaled: one global scale OR per-row scales");
     int64_t waves = n < 16384 ? n : 16384;
     split_rows_scaled_kernel<<<(unsigned)((waves * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(
-        x, ld_x, d, n, static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), ld_h, scale, row_inv_scale);
+        x, ld_x, d, n, static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), ld_h, scale, row_inv_scale, dst_row);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

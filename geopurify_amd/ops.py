@@ -324,10 +324,11 @@ def conv_weights_shape(w_hi):
     return tuple(int(v) for v in w_hi.shape)
 
 
-def split_f16(x, d=None, scale=None, per_row=False, interleaved=False):
+def split_f16(x, d=None, scale=None, per_row=False, interleaved=False, dst_row=None):
     """fp32 rows -> (hi, lo) f16 rows with x * s = hi + lo.  Unscaled (s = 1): exact to 2^-22 relative only for |x| >= 2^-3
     (below that the lo half is a subnormal f16: absolute error 2^-25).  scale = device scalar from pow2_scale(): one power of
-    two for the whole block; per_row=True: a power of two per row, returns (hi, lo, row_inv_scale)."""
+    two for the whole block; per_row=True: a power of two per row, returns (hi, lo, row_inv_scale).
+    dst_row (i32 [n], a permutation; scaled forms only): row r is written to row dst_row[r] of the outputs (rcb_order's map)."""
     lib = _lib.load()
     d = x.shape[1] if d is None else d
     if interleaved:
@@ -335,19 +336,43 @@ def split_f16(x, d=None, scale=None, per_row=False, interleaved=False):
         assert per_row and d % 32 == 0, "interleaved rows are the row-scaled operand of the convolution"
         rows = torch.empty((x.shape[0], 2 * d), dtype=torch.float16, device=x.device)
         rinv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-        check(lib.gp_split_f16_scaled(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(rows), None, rows.stride(0), None, _ptr(rinv), _stream()),
-              "gp_split_f16_scaled")
+        check(lib.gp_split_f16_scaled(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(rows), None, rows.stride(0), None, _ptr(rinv),
+                                      _ptr(dst_row), _stream()), "gp_split_f16_scaled")
         return rows, None, rinv
     hi = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
     lo = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
     if scale is None and not per_row:
+        if dst_row is not None:
+            raise ValueError("split_f16: dst_row needs a scaled form (scale= or per_row=True)")
         check(lib.gp_split_f16(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(hi), _ptr(lo), hi.stride(0), _stream()),
               "gp_split_f16")
         return hi, lo
     rinv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if per_row else None
     check(lib.gp_split_f16_scaled(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(hi), _ptr(lo), hi.stride(0), _ptr(scale),
-                                  _ptr(rinv), _stream()), "gp_split_f16_scaled")
+                                  _ptr(rinv), _ptr(dst_row), _stream()), "gp_split_f16_scaled")
     return (hi, lo, rinv) if per_row else (hi, lo)
+
+
+def rcb_order(coords_sorted, chunk_rows=2048, leaf_rows=128):
+    """Row order for the pooling operator (gp_rcb_order): recursive coordinate bisection of the Morton-ordered integer coords
+    [nv, 3] inside chunks of chunk_rows rows into leaves of leaf_rows rows.  Returns (sigma, rho) i32 [nv]: new position -> row,
+    row -> new position."""
+    lib = _lib.load()
+    _chk(coords_sorted, torch.int32, "coords")
+    nv = coords_sorted.shape[0]
+    sigma = torch.empty(nv, dtype=torch.int32, device=coords_sorted.device)
+    rho = torch.empty(nv, dtype=torch.int32, device=coords_sorted.device)
+    check(lib.gp_rcb_order(_ptr(coords_sorted), nv, int(chunk_rows), int(leaf_rows), _ptr(sigma), _ptr(rho), _stream()), "gp_rcb_order")
+    return sigma, rho
+
+
+def rows_renumber(nbr, sigma, rho):
+    """out[p, j] = rho[nbr[sigma[p], j]]: neighbour lists i32 [nv, k] in the order / numbering of rcb_order"""
+    lib = _lib.load()
+    nv, k = nbr.shape
+    out = torch.empty_like(nbr)
+    check(lib.gp_rows_renumber_i32(_ptr(nbr), nv, int(k), _ptr(sigma), _ptr(rho), _ptr(out), _stream()), "gp_rows_renumber_i32")
+    return out
 
 
 def pow2_scale(x, d=None):
@@ -424,12 +449,13 @@ def l2norm_rows_(x, d=None):
     return x
 
 
-def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=True, out=None, planes=False, want_f32=True):
+def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=True, out=None, planes=False, want_f32=True, plane_rows=None):
     """The student's 1x1x1 output layer on pre-split rows, fused with F.normalize (affinity_module.py:66,71,1547).
     x_split = (hi, lo) f16 [nv, >=cin]; w_hi / w_lo f16 [1, cout, cin] or [cout, cin] (conv_weights_split of the [1, cin, cout]
     kernel with a power-of-two pre-scale whose inverse is out_scale).
     planes=True: also returns the rows x 2^10 as f16 (hi, lo) planes -- the operand of affinity_cs_fragments -- written by the same
-    epilogue; want_f32=False then skips the fp32 rows.  Returns out, or (out_or_None, (e_hi, e_lo))."""
+    epilogue; want_f32=False then skips the fp32 rows.  plane_rows (i32 [nv]): the plane row of input row r (rcb_order's rho).
+    Returns out, or (out_or_None, (e_hi, e_lo))."""
     lib = _lib.load()
     hi, lo = x_split
     cout, cin = w_hi.shape[-2:]
@@ -445,7 +471,7 @@ def embed_head_f16x3(x_split, w_hi, w_lo, out_scale, x_row_inv=None, normalize=T
         el = torch.empty((nv, cout), dtype=torch.float16, device=hi.device)
     check(lib.gp_embed_head_f16x3(_ptr(hi), _ptr(lo), hi.stride(0), _ptr(x_row_inv), _ptr(w_hi), _ptr(w_lo), nv, int(cin), int(cout),
                                   float(out_scale), int(bool(normalize)), _ptr(out), out.stride(0) if out is not None else 0, _ptr(eh), _ptr(el),
-                                  AFFINITY_PLANE_SCALE, _stream()), "gp_embed_head_f16x3")
+                                  AFFINITY_PLANE_SCALE, _ptr(plane_rows) if planes else None, _stream()), "gp_embed_head_f16x3")
     return (out, (eh, el)) if planes else out
 
 

@@ -129,12 +129,13 @@ class StudentWeights:
             return None
         return ops.split_f16(x, self.cin_pad, per_row=True, interleaved=self.residual_from_planes and self.interleaved_rows)
 
-    def forward(self, x, nbr_map, pairs=None, x_split=None, mark=None, planes=False):
+    def forward(self, x, nbr_map, pairs=None, x_split=None, mark=None, planes=False, plane_rows=None):
         """x fp32 [Nv, >=cin_pad] (internal order).  Returns L2-normalised embeddings [Nv, embed].
         On the f16x3 path every layer also emits its output pre-split (hi/lo f16) so that the next
         layer stages both operands by LDS-DMA.  x_split: split_input(x) when it was made ahead.
         planes=True (only with the fused output layer): returns the embeddings x 2^10 as f16 (hi, lo) planes INSTEAD -- the operand
-        of the matrix-core affinity kernel, written by the output layer's epilogue (no fp32 rows, no split pass)."""
+        of the matrix-core affinity kernel, written by the output layer's epilogue (no fp32 rows, no split pass); plane_rows (i32 [Nv]):
+        the plane row of voxel row r (the pooling operator's own row order, ops.rcb_order)."""
         ctx = {"nbr_map": nbr_map, "pairs": pairs}
         fast = self.fast
         if pairs is None and any(l[0] == "f16x3" for l in self.layers):
@@ -158,11 +159,12 @@ class StudentWeights:
         if fast and self.head is not None and hs is not None:
             if planes:
                 return ops.embed_head_f16x3(hs[:2], self.head[0], self.head[1], self.head[2], x_row_inv=hs[2], normalize=True,
-                                            planes=True, want_f32=False)[1]
+                                            planes=True, want_f32=False, plane_rows=plane_rows)[1]
             return ops.embed_head_f16x3(hs[:2], self.head[0], self.head[1], self.head[2], x_row_inv=hs[2], normalize=True)
         e = ops.l2norm_rows_(ops.sparse_conv(h, None, self.w_out))
         if planes:
-            return ops.split_f16(e, self.embed, scale=torch.tensor([ops.AFFINITY_PLANE_SCALE], dtype=torch.float32, device=e.device))
+            return ops.split_f16(e, self.embed, scale=torch.tensor([ops.AFFINITY_PLANE_SCALE], dtype=torch.float32, device=e.device),
+                                 dst_row=plane_rows)
         return e
 
     def flops(self, num_pairs, nv):
@@ -367,7 +369,7 @@ class HotPath:
 
     def __init__(self, student: StudentWeights, mask_shape, K=96, sharpen=20.0, num_iters=19, device="cuda",
                  pool_mode="auto", pool_tile_rows=8, pool_block_rows=64, batch_views=True, pool_structure_ahead=True, affinity_mfma=True,
-                 all_views_max_pairs=2e11):
+                 all_views_max_pairs=2e11, pool_row_order="rcb"):
         self.student = student
         self.batch_views = batch_views                 # lift all views of a scene in one set of launches when the inputs allow it
         # the all-views in-view fill is a brute-force search per view: sum over views of (queries x references) <= sum n_v^2 / 4
@@ -382,6 +384,10 @@ class HotPath:
         self.pool_structure_ahead = bool(pool_structure_ahead)
         # rows 11 + operator fill as one matrix-core kernel (affinity_mfma=False: affinity_block_kernel + dst table; last A/B 26.08 -> 25.72 ms)
         self.affinity_mfma = bool(affinity_mfma)
+        # row order of the POOLING operator (round 6): "rcb" = recursive coordinate bisection inside 2048-row Morton chunks into the
+        # operator's 128-row blocks (ops.rcb_order: block unions 4.75 -> 4.2 rows per row, a launch -4 %; only where the matrix-core
+        # affinity kernel fills the operator -- it reads the embedding planes by pooling row), "morton" = the voxel order itself
+        self.pool_row_order = pool_row_order
         self.mask_shape = tuple(mask_shape)
         self.K, self.sharpen, self.num_iters = K, sharpen, num_iters
         self.device = torch.device(device)
@@ -571,8 +577,17 @@ class HotPath:
             how = self.pool_structure_ahead
             if how and self.affinity_mfma and self.K <= 96 and self.student is not None and self.student.embed == 128:
                 how = "valid"
-            state["pool"] = {"op": ops.pool_cs_plan(nbr, structure=how), "sc": sc,
-                             "x_split": ops.split_f16(X, D, scale=sc[0:1]),
+            rho = None
+            nbr_op = nbr
+            if how == "valid" and self.pool_row_order == "rcb" and Nv > 2048:
+                # the operator's own row order: compact 128-row blocks (smaller neighbour unions).  Everything that enters the pooling by row
+                # is written through `rho` (the feature planes here, the embedding planes by the output layer), the lists are renumbered,
+                # and the final voxel -> point gather composes rho with the Morton rank; nothing else sees the order
+                sigma, rho = ops.rcb_order(cs, 2048, 128)
+                nbr_op = ops.rows_renumber(nbr, sigma, rho)
+                state["rank_pool"] = rho[rank.long()].contiguous()
+            state["pool"] = {"op": ops.pool_cs_plan(nbr_op, structure=how), "sc": sc, "rho": rho, "nbr": nbr_op,
+                             "x_split": ops.split_f16(X, D, scale=sc[0:1], dst_row=rho),
                              "pong": tuple(torch.empty((Nv, D), dtype=torch.float16, device=dev) for _ in range(2))}
             if mode == "mfma_chain" and (state["pool"]["op"].dst is not None or state["pool"]["op"].valid is not None):   # (the lists need bu_row only)
                 ops.pool_cs_deps(state["pool"]["op"])
@@ -591,7 +606,8 @@ class HotPath:
         # the operator's structure was built ahead: the affinity kernel writes its weights straight into fragment order
         op = p["pool"]["op"] if p["pool"] is not None else None
         mfma_aff = op is not None and op.valid is not None
-        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"), mark=self.stage_mark, planes=mfma_aff)
+        rho = p["pool"]["rho"] if (p["pool"] is not None and mfma_aff) else None
+        E = self.student.forward(X, p["nbr_map"], p["pairs"], x_split=p.get("xs"), mark=self.stage_mark, planes=mfma_aff, plane_rows=rho)
         mark("embed head" if self.stage_mark is not None else "student")
         if after_student is not None:
             after_student()
@@ -603,11 +619,12 @@ class HotPath:
         else:
             w = ops.affinity_softmax(E, nbr, self.sharpen, into=op if op is not None and op.dst is not None else None)
         mark("affinity")
-        self._last_E = E
-        self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12
+        self._last_E, self._last_E_rho = E, rho
+        self._last_pool_inputs = (X, nbr, w, Nv, D)       # kept for bench.py's isolated timing of row 12 ...
+        self._last_pool_plan = p["pool"]                  # ... which re-applies THIS scene's operator (its row order included)
         out = self._pool(X, nbr, w, Nv, D, plan=p["pool"])
         mark("pooling")
-        out = ops.gather_rows(out, D, batch.scene_inds_reconstruct, row_map=rank)
+        out = ops.gather_rows(out, D, batch.scene_inds_reconstruct, row_map=p.get("rank_pool", rank))
         mark("gather")
         self.stats = {"Nv": Nv, "nbr_map": p["nbr_map"], "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8),
                       "pool_kernel": self._pool_kernel}
@@ -639,6 +656,8 @@ class HotPath:
             E = self._last_E
             if isinstance(E, tuple):
                 E = (E[0].float() + E[1].float()) / ops.AFFINITY_PLANE_SCALE
+                if getattr(self, "_last_E_rho", None) is not None:        # the planes were written in the operator's row order: back to voxel rows
+                    E = E[self._last_E_rho.long()]
             w = ops.affinity_softmax(E.contiguous(), nbr, self.sharpen)
         if self.num_iters == 0:
             out = torch.empty((Nv, D), dtype=torch.float32, device=dev)

@@ -169,8 +169,9 @@ int gp_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, v
 /* form of gp_sparse_conv_f16x3's plane_flags bit 0.                                                                      */
 int gp_pow2_scale(const float *x, int64_t ld_x, int32_t d, int64_t n, float *scale2, void *workspace,
                   size_t workspace_bytes, void *stream);
+/* dst_row (nullable, i32 [n]): row r of x is written to row dst_row[r] of hi / lo / row_inv_scale (a permutation: gp_rcb_order).   */
 int gp_split_f16_scaled(const float *x, int64_t ld_x, int32_t d, int64_t n, void *hi, void *lo, int64_t ld_h,
-                        const float *scale, float *row_inv_scale, void *stream);
+                        const float *scale, float *row_inv_scale, const int32_t *dst_row, void *stream);
 int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const void *x_lo, int64_t ld_xh,
                          const int32_t *pair_in, const int32_t *pair_pos,
                          const int32_t *seg_off, const int32_t *tile_start, const int32_t *tile_desc,
@@ -208,7 +209,19 @@ int gp_l2norm_rows(float *x, int64_t ld, int32_t d, int64_t n, void *stream);
 /* the operand of gp_affinity_cs_fragments (plane_scale 1024), written by the same epilogue instead of a separate split pass.    */
 int gp_embed_head_f16x3(const void *x_hi, const void *x_lo, int64_t ld_x, const float *x_row_inv_scale, const void *w_hi,
                         const void *w_lo, int64_t nv, int32_t cin, int32_t cout, float out_scale, int32_t l2_normalize,
-                        float *y, int64_t ld_y, void *e_hi, void *e_lo, float plane_scale, void *stream);
+                        float *y, int64_t ld_y, void *e_hi, void *e_lo, float plane_scale,
+                        const int32_t *e_dst_row /* nullable: plane row of input row r (gp_rcb_order's map); y keeps the input order */,
+                        void *stream);
+
+/* Row order of the POOLING operator (row 12's matrix-core kernels gather, per block of 128 consecutive rows, the union of the      */
+/* rows' neighbours: compact blocks have smaller unions).  gp_rcb_order: inside chunks of chunk_rows (1024 or 2048) consecutive rows   */
+/* of the Morton-ordered integer coords [nv, 3], recursive coordinate bisection into leaves of leaf_rows rows (every leaf but a       */
+/* chunk's last is full).  sigma i32 [nv]: new position -> row, rho i32 [nv]: row -> new position (both permutations of 0 .. nv - 1   */
+/* that keep every chunk in place).  gp_rows_renumber_i32: out[p, j] = rho[nbr[sigma[p], j]] for i32 [nv, k] neighbour lists.           */
+/* No reference counterpart: an internal order, composed away before any output (models/affinity_module.py:1575-1589 sees none).        */
+int gp_rcb_order(const int32_t *coords, int64_t nv, int32_t chunk_rows, int32_t leaf_rows, int32_t *sigma, int32_t *rho, void *stream);
+int gp_rows_renumber_i32(const int32_t *nbr, int64_t nv, int32_t k, const int32_t *sigma, const int32_t *rho, int32_t *out,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row 10: faiss.IndexFlatL2.search(K+1) on integer voxel coordinates, self dropped              */

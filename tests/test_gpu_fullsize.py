@@ -375,6 +375,27 @@ def test_config_m_full_size_properties():
     assert torch.equal(F_one, r["F"])
 
 
+def test_pooling_row_order_full_size(big):
+    """HotPath(pool_row_order="rcb") -- the default: the pooling operator in its own row order, feature planes, embedding planes and the
+    final gather written through the map -- against pool_row_order="morton" on the S-sized voxel set: the same refined features up to
+    the fp32 order of a row's 96-term sums (19 applications), fewer padded union rows in the operator."""
+    pl, scene, rigid = big["pl"], big["scene"], big["rigid"]
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+    st = pl.StudentWeights(pl.random_student_state_dict(512 + pl.GEO_DIM, hidden=256, embed=128, num_blocks=1, seed=3), "cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    F = torch.nn.functional.normalize(torch.randn(batch.scene_coords.shape[0], 512, device="cuda", generator=g), dim=1)
+    outs, totals = {}, {}
+    for order in ("rcb", "morton"):
+        hp = pl.HotPath(st, big["cfg"].mask_shape, K=96, num_iters=19, device="cuda", pool_row_order=order)
+        p = hp.prepare(batch, F)
+        assert (p["pool"]["rho"] is not None) == (order == "rcb")
+        outs[order] = hp.refine(batch, F, prepared=p)
+        totals[order] = p["pool"]["op"].total
+        assert hp.stats["pool_kernel"] == "cs_pool_kernel"
+    assert totals["rcb"] < 0.93 * totals["morton"], totals
+    assert (outs["rcb"] - outs["morton"]).abs().max() < 5e-6                          # unit-norm rows, convex combinations
+
+
 def test_config_s_full_size_properties():
     """BASELINE configs[1] -- the HEADLINE workload of bench.py -- at its full size under pytest: 150k points, all 25 views (648 x 484
     images, Q = 200 masks each), D = 512, K = 96, T = 19, student 518 -> 512 x 9 -> 128, through the default kernels; checked by the

@@ -969,6 +969,64 @@ def test_pool_tiles_matches_ell_and_oracle(ops, R):
             ops.pool_tiles_apply(dev(torch.randn(Nv, 64)), tiles, 64, torch.empty((Nv, 64), device="cuda"))
 
 
+# ------------------------------------------------------------------------------------------ row 12: the operator's own row order
+@pytest.mark.parametrize("chunk", [1024, 2048])
+def test_rcb_order_properties_and_the_maps_it_feeds(ops, chunk):
+    """gp_rcb_order (recursive coordinate bisection inside Morton chunks into 128-row leaves): sigma / rho are inverse permutations
+    that keep every chunk in place; a leaf's bounding box is tighter than the Morton block's it replaces and the neighbour union of
+    the operator's 128-row blocks shrinks; gp_rows_renumber_i32, the row maps of gp_split_f16_scaled and of gp_embed_head_f16x3's
+    planes are the index arithmetic they claim to be; the re-ordered operator pools to the same features."""
+    rng = np.random.default_rng(21)
+    c = surface_voxels(rng, 9000, ext=110)
+    ct, perm, rank, cs, grid = _sorted_voxels(ops, c)
+    Nv, K, D = len(c), 96, 512
+    sigma, rho = ops.rcb_order(cs, chunk, 128)
+    sg, rh = sigma.cpu().numpy().astype(np.int64), rho.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(sg), np.arange(Nv)) and np.array_equal(rh[sg], np.arange(Nv)) and np.array_equal(sg[rh], np.arange(Nv))
+    assert np.array_equal(sg // chunk, np.arange(Nv) // chunk)                       # a row never leaves its chunk
+    xyz = cs.cpu().numpy().astype(np.int64)
+    def box_volume(order):
+        vols = []
+        for b in range(0, Nv - 127, 128):
+            p = xyz[order[b:b + 128]]
+            vols.append(np.prod(p.max(0) - p.min(0) + 1))
+        return float(np.mean(vols))
+    assert box_volume(sg) < 0.8 * box_volume(np.arange(Nv))                            # compact leaves
+    nbr = ops.knn_lattice(grid, cs, perm, K)
+    nbr2 = ops.rows_renumber(nbr, sigma, rho)
+    assert torch.equal(nbr2.cpu(), torch.from_numpy(rh)[nbr.cpu().long()[torch.from_numpy(sg)]].to(torch.int32))
+    union = lambda nb: float(np.mean([len(np.unique(nb[b:b + 128])) for b in range(0, Nv - 127, 128)])) / 128.0
+    u_m, u_r = union(nbr.cpu().numpy()), union(nbr2.cpu().numpy())
+    assert u_r < 0.98 * u_m, (u_m, u_r)                                                # smaller block unions: what the order is for (S scene: 4.75 -> 4.2)
+    # the row maps: split planes and embedding planes written through rho
+    X = torch.randn(Nv, D, device="cuda")
+    sc = ops.pow2_scale(X, D)
+    h0, l0 = ops.split_f16(X, D, scale=sc[0:1])
+    h1, l1 = ops.split_f16(X, D, scale=sc[0:1], dst_row=rho)
+    assert torch.equal(h1[rho.long()], h0) and torch.equal(l1[rho.long()], l0)
+    hh, ll, inv0 = ops.split_f16(X, D, per_row=True)
+    hp_, lp_, inv1 = ops.split_f16(X, D, per_row=True, dst_row=rho)
+    assert torch.equal(hp_[rho.long()], hh) and torch.equal(lp_[rho.long()], ll) and torch.equal(inv1[rho.long()], inv0)
+    with pytest.raises(ValueError):
+        ops.split_f16(X, D, dst_row=rho)
+    Wo = torch.randn(1, D, 128, device="cuda") * 0.05
+    whi, wlo = ops.conv_weights_split(Wo, 64.0, blocked=False)
+    y0, (e0h, e0l) = ops.embed_head_f16x3((hh, ll), whi, wlo, 1.0 / 64.0, x_row_inv=inv0, planes=True)
+    y1, (e1h, e1l) = ops.embed_head_f16x3((hh, ll), whi, wlo, 1.0 / 64.0, x_row_inv=inv0, planes=True, plane_rows=rho)
+    assert torch.equal(y1, y0) and torch.equal(e1h[rho.long()], e0h) and torch.equal(e1l[rho.long()], e0l)
+    # the operator in its own order: same pooled features (another fp32 summation order), rows back through sigma
+    E = F.normalize(torch.randn(Nv, 128), dim=1)
+    w = ops.affinity_softmax(dev(E), nbr, 20.0)
+    op_m, op_r = ops.pool_cs_build(nbr, w), ops.pool_cs_build(nbr2, w[sigma.long()].contiguous())
+    assert op_r.total < op_m.total                                                     # fewer padded union rows to gather
+    ym, yr = torch.empty(Nv, D, device="cuda"), torch.empty(Nv, D, device="cuda")
+    ops.pool_cs_apply((h0, l0), op_m, D, out_f32=ym, out_scale=sc[1:2])
+    ops.pool_cs_apply((h1, l1), op_r, D, out_f32=yr, out_scale=sc[1:2])
+    assert (yr[rho.long()] - ym).abs().max() < 2e-6 * float(X.abs().max())
+    with pytest.raises(Exception, match="chunk_rows"):
+        ops.rcb_order(cs, 512, 128)
+
+
 @pytest.mark.parametrize("n_vox,K,BR", [(130, 96, 64), (70, 32, 64), (130, 32, 128), (65, 8, 64)])
 def test_pool_mfma_tiny_voxel_sets(ops, n_vox, K, BR):
     """edge shapes: a single (partial) row block, unions of exactly K+1..Nv rows, K far from 96, 1-step applications."""
