@@ -178,6 +178,12 @@ knn_ring_kernel(const void *grid, const int32_t *__restrict__ coords, const int3
     }
 }
 
+// Measured and left out (round 6; `knn_cell_kernel`, not in the tree): the first ring as one WORKGROUP PER 8^3 CELL -- the 27-cell block staged
+// once in LDS (packed coordinates + row ids, <= 2048 candidates) and the cell's ~25-60 queries answered from there by the same histogram /
+// threshold / tie / rank steps, the same results (tests) -- to stop re-reading ~19 KB of candidates from L2 twice per query (5 GB per S
+// scene: this kernel runs at the L2 ceiling).  0.88 ms with four waves and 48 KiB of LDS per workgroup, 0.54 ms with eight waves and
+// 36 KiB (32 waves per CU) against 0.45 ms here: per query the LDS atomics of the histogram, the rank sort and the staging of sparse
+// cells' blocks cost more than the L2 reads they replace.
 // exhaustive fallback: one 256-thread block per failed query, bisection on the 64-bit (d2,id) key
 __global__ void __launch_bounds__(256)
 knn_exhaustive_kernel(const int32_t *__restrict__ coords, const int32_t *__restrict__ ids, int64_t nv, int k,
