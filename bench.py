@@ -1019,7 +1019,9 @@ def main():
                         f"{min(val_scene_sizes(args.val_scenes, world))}..{max(val_scene_sizes(args.val_scenes, world))} points from "
                         f"scannet_val_point_counts.txt), 25 views, D={D}, K=96, pool_iters={args.pool_iters}, student 518->512x9->128")
         else:
-            workload = (f"{cfg.name}: ScanNetV2-shaped scene, N={cfg.num_points} pts, Nv={Nv}, {len(last.views)}/{cfg.num_views} views kept, "
+            workload = (f"{cfg.name}: ScanNetV2-shaped scene, N={cfg.num_points} pts, {args.scenes} scenes rotated: Nv={Nv} voxels in the LAST scene "
+                        f"(the one the isolated passes repeat), {int(round(tot_rows / n_launch))} on average over the timed pooling launches (what "
+                        f"roofline.algorithmic_bytes_per_launch prices), {len(last.views)}/{cfg.num_views} views kept, "
                         f"D={D}, K=96, pool_iters={args.pool_iters}, student 518->512x9->128 random-init")
         out = {
             "metric": "scenes/sec (ScanNet-val shape) + pooled-feature GB/s vs HBM peak",
