@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--pool-iters", type=int, default=19, help="applications of A (reference code: 19; BASELINE wording: 3)")
     ap.add_argument("--pool-mode", default=os.environ.get("GP_POOL_MODE", "auto"), choices=["auto", "mfma_cs", "mfma_chain", "mfma_engine", "mfma", "mfma_persist", "tiles", "ell"])
     ap.add_argument("--pool-row-order", default="rcb", choices=["rcb", "morton"],
-                    help="row order of the pooling operator: rcb (default: recursive coordinate bisection inside 2048-row Morton chunks into the "
+                    help="row order of the pooling operator: rcb (default: recursive coordinate bisection inside 1024-row Morton chunks into the "
                          "operator's 128-row blocks, smaller neighbour unions) or morton (the voxel order itself: rounds 1-5)")
     ap.add_argument("--api", default="both", choices=["device", "both"],
                     help="both: after the headline run also time the DROP-IN call SonataXAffinityTrainer.evaluate_scene(20-tuple of "
@@ -196,8 +196,10 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
         "kNN": ("row 10: Nv x (12 + K x 4)", nv * (12.0 + K * 4)),
         "affinity": ("row 11: Nv x (128 x 4 + K x 4 + K x 4)", nv * (128 * 4.0 + K * 8)),
         "pooling": (f"row 12: {pool_iters} x Nv x (2 x D x 4 + K x 8)", pool_iters * nv * (2.0 * d * 4 + K * 8)),
-        "gather": ("row 12 tail: Nv x D x 4 read + N x D x 4 written", (nv + n) * d * 4.0),
-        "classify+iou": ("row 13: N x D x 4 read + N x 16 (prediction, label)", n * d * 4.0 + n * 16.0),
+        "gather": ("row 12 tail + the class decision of row 13 in the same pass (gp_gather_rows_classify, round 6): Nv x D x 4 read + N x D x 4 "
+                   "written + N x 9 (prediction, zero flag); wider class tables: the gather alone", (nv + n) * d * 4.0 + n * 9.0),
+        "classify+iou": ("row 13: the IoU histograms over N x 16 (prediction, label); the N x D x 4 read of a separate classification pass "
+                         "only where the fused gather does not apply (more than 32 classes)", n * 16.0 + (n * d * 4.0 if cfg.num_classes > 32 else 0.0)),
     }
     out = {}
     for name, (what, b) in alg.items():
@@ -822,7 +824,7 @@ def main():
                     _lift_ahead(i + 1, after=started)
                     streams[1].wait_event(pending[i + 1][4])
                 host_t["hook"] += time.perf_counter() - t_h
-            feats = hp.refine(batch, F, after_student=hook, prepared=prep)
+            feats = hp.refine(batch, F, after_student=hook, prepared=prep, classify_text=(text, scale))
             hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale},
                                   batch.scene_label, cfg.num_classes, cfg.ignore_ids, counts)
         return batch
@@ -842,7 +844,7 @@ def main():
             F, text, scale = hp.lift_masks(batch, vlms[j])
         if stage:
             stage.mark("lift+fuse+fill")
-        feats = hp.refine(batch, F)
+        feats = hp.refine(batch, F, classify_text=(text, scale))
         if stage:
             stage.mark("refine: mean+student+knn+affinity+pool+gather")
         hp.classify_and_count({"scene_features": feats, "text_features": text, "logit_scale": scale},

@@ -107,6 +107,7 @@ SIGNATURES = {
     "gp_lift_masks_views": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int64,
                                       _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gp_classify_argmax": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int32, c_float, _P, _P, _P]),
+    "gp_gather_rows_classify": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, _P, c_int32, c_float, _P, _P, _P]),
     "gp_rows_argmax": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "gp_col_stats_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "gp_col_stats": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),

@@ -414,10 +414,15 @@ __global__ void classify16_kernel(const float *__restrict__ feat, int64_t ld, in
 // the same arithmetic (same 16-lane split of the row, same sum16 order, same divisions => the same bits and labels), but the
 // text matrix staged ONCE per workgroup in LDS (19 x 512 floats = 38 KiB do not fit the 32-KiB vector L1: the kernel above
 // re-fetches them from L2 for every group of points) and two points per 16-lane group and class sweep
+// GATHER (round 6: gp_gather_rows_classify): point p's row is row row_map[index[p]] of `feat` -- the final voxel -> point gather of
+// affinity_module.py:1589 -- and is ALSO written to out[p]: the per-point feature matrix (307 MB at S) is written once and never read
+// back by a separate classification pass.  Same loads per value, same arithmetic: the same rows, bits and labels as gather + classify.
 constexpr int CL_Q = 2;
+template <bool GATHER>
 __global__ void __launch_bounds__(256)
 classify16_lds_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t n, const float *__restrict__ text, int C,
-                      float scale, int64_t *__restrict__ pred, uint8_t *__restrict__ zero_row) {
+                      float scale, int64_t *__restrict__ pred, uint8_t *__restrict__ zero_row, const int64_t *__restrict__ index,
+                      const int32_t *__restrict__ row_map, float *__restrict__ out, int64_t ld_out) {
     extern __shared__ __align__(16) float cl_text[];        // [C][d]
     for (int i = threadIdx.x * 4; i < C * d; i += 256 * 4) *reinterpret_cast<float4 *>(cl_text + i) = *reinterpret_cast<const float4 *>(text + i);
     __syncthreads();
@@ -432,10 +437,17 @@ classify16_lds_kernel(const float *__restrict__ feat, int64_t ld, int d, int64_t
         for (int q = 0; q < CL_Q; ++q) {
             const int64_t p = base + g * CL_Q + q;
             live[q] = p < n;
+            int64_t src_row = p;
+            if constexpr (GATHER) {
+                if (live[q]) { src_row = index[p]; if (row_map) src_row = row_map[src_row]; }
+            }
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < CL_MAXJ; ++j) {
-                v[q][j] = (live[q] && j < nj) ? *reinterpret_cast<const float4 *>(feat + p * ld + (j * 16 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[q][j] = (live[q] && j < nj) ? *reinterpret_cast<const float4 *>(feat + src_row * ld + (j * 16 + l) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (GATHER) {
+                    if (live[q] && j < nj) *reinterpret_cast<float4 *>(out + p * ld_out + (j * 16 + l) * 4) = v[q][j];
+                }
                 ss += v[q][j].x * v[q][j].x + v[q][j].y * v[q][j].y + v[q][j].z * v[q][j].z + v[q][j].w * v[q][j].w;
             }
             ss = sum16(ss);
@@ -699,15 +711,33 @@ extern "C" int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int6
     const bool fast = d % 64 == 0 && d <= 64 * CL_MAXJ && ld % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)text_norm % 16 == 0;
     const size_t text_bytes = (size_t)c * d * sizeof(float);
     if (fast && text_bytes <= 64 * 1024 && !g_gp_knobs[14]) {
-        GP_SMEM_ATTR(classify16_lds_kernel, 64 * 1024);
+        GP_SMEM_ATTR(classify16_lds_kernel<false>, 64 * 1024);
         const int64_t groups = (n + 16 * CL_Q - 1) / (16 * CL_Q);
-        classify16_lds_kernel<<<(int)(groups < 2048 ? groups : 2048), 256, text_bytes, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
-                                                                                                     pred, zero_row);
+        classify16_lds_kernel<false><<<(int)(groups < 2048 ? groups : 2048), 256, text_bytes, gp_stream(stream_)>>>(
+            feat, ld, d, n, text_norm, c, logit_scale, pred, zero_row, nullptr, nullptr, nullptr, 0);
     } else if (fast)
         classify16_kernel<<<(int)((n * 16 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale, pred, zero_row);
     else
         classify_kernel<<<(int)((n * 64 + 255) / 256), 256, 0, gp_stream(stream_)>>>(feat, ld, d, n, text_norm, c, logit_scale,
                                                                                    pred, zero_row);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// out[p, 0:d] = src[row_map[index[p]], 0:d] (gp_gather_rows) AND pred / zero_row of gp_classify_argmax on those rows, in one pass
+extern "C" int gp_gather_rows_classify(const float *src, int64_t ld_src, int32_t d, const int64_t *index, int64_t n, const int32_t *row_map,
+                                       float *out, int64_t ld_out, const float *text_norm, int32_t c, float logit_scale, int64_t *pred,
+                                       uint8_t *zero_row, void *stream_) {
+    GP_CHECK_ARG(src && index && out && text_norm && pred && n > 0 && d > 0 && c > 0, "gp_gather_rows_classify: null/empty argument");
+    GP_CHECK_ARG(d % 64 == 0 && d <= 64 * CL_MAXJ && ld_src % 4 == 0 && ld_out % 4 == 0 && ld_out >= d && (uintptr_t)src % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0 && (uintptr_t)text_norm % 16 == 0 && (size_t)c * d * sizeof(float) <= 64 * 1024,
+                 "gp_gather_rows_classify: d=%d must be a multiple of 64 up to %d, rows 16-byte aligned, c * d * 4 <= 64 KiB (use gp_gather_rows + "
+                 "gp_classify_argmax otherwise)", d, 64 * CL_MAXJ);
+    GP_CHECK_ARG(out != src, "gp_gather_rows_classify: out must not alias src");
+    GP_SMEM_ATTR(classify16_lds_kernel<true>, 64 * 1024);
+    const int64_t groups = (n + 16 * CL_Q - 1) / (16 * CL_Q);
+    classify16_lds_kernel<true><<<(int)(groups < 2048 ? groups : 2048), 256, (size_t)c * d * sizeof(float), gp_stream(stream_)>>>(
+        src, ld_src, d, n, text_norm, c, logit_scale, pred, zero_row, index, row_map, out, ld_out);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -40,7 +40,7 @@ rcb_chunk_kernel(const int32_t *__restrict__ coords /*[nv, 3]*/, int64_t nv, int
     }
     if (tid == 0) { s_nseg = 1; s_start[0] = 0; s_len[0] = n; s_more = n > leaf; }
     __syncthreads();
-    int cur = 0;
+    int cur = 0, level = 0;
     while (s_more) {
         const int nseg = s_nseg;
         // ---- per segment: bounding box -> axis
@@ -87,17 +87,23 @@ rcb_chunk_kernel(const int32_t *__restrict__ coords /*[nv, 3]*/, int64_t nv, int
             s_key[i] = k;
         }
         __syncthreads();
-        for (int kk = 2; kk <= CH; kk <<= 1)
+        // In a FULL chunk the segments of level L are the aligned blocks of CH >> L positions (every cut is at half a power-of-two
+        // segment): the network only has to sort inside those blocks -- merges up to `limit`, the last one ascending in every block.
+        // (A chunk's tail -- the scene's last chunk -- has irregular segments: the whole array is sorted, the segment id leads the key.)
+        const int limit = (n == CH) ? (CH >> level) : CH;
+        for (int kk = 2; kk <= limit; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
                 for (int i = tid; i < CH; i += NT) {
                     const int ixj = i ^ j;
                     if (ixj > i) {
                         const unsigned x = s_key[i], y = s_key[ixj];
-                        if ((x > y) == ((i & kk) == 0)) { s_key[i] = y; s_key[ixj] = x; }
+                        const bool up = (kk == limit) || ((i & kk) == 0);
+                        if ((x > y) == up) { s_key[i] = y; s_key[ixj] = x; }
                     }
                 }
                 __syncthreads();
             }
+        ++level;
         for (int i = tid; i < n; i += NT) s_perm[cur ^ 1][i] = s_perm[cur][s_key[i] & 0xfffu];
         cur ^= 1;
         // ---- cut the segments that were sorted

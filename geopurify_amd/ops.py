@@ -188,6 +188,24 @@ def gather_rows(src, d, index, out=None, row_map=None):
     return out
 
 
+def gather_rows_classify(src, d, index, text_norm, logit_scale, row_map=None):
+    """gather_rows + classify_argmax in one pass (gp_gather_rows_classify): returns (out [n, d], pred i64 [n], zero u8 [n]).
+    d a multiple of 64 up to 512 and C * d * 4 <= 64 KiB (can_gather_rows_classify)."""
+    lib = _lib.load()
+    n = index.shape[0]
+    out = torch.empty((n, d), dtype=torch.float32, device=src.device)
+    pred = torch.empty(n, dtype=torch.int64, device=src.device)
+    zero = torch.empty(n, dtype=torch.uint8, device=src.device)
+    check(lib.gp_gather_rows_classify(_ptr(src), src.stride(0), int(d), _ptr(index), n, _ptr(row_map), _ptr(out), out.stride(0),
+                                      _ptr(text_norm), int(text_norm.shape[0]), float(logit_scale), _ptr(pred), _ptr(zero), _stream()),
+          "gp_gather_rows_classify")
+    return out, pred, zero
+
+
+def can_gather_rows_classify(d, num_classes):
+    return d % 64 == 0 and d <= 512 and num_classes * d * 4 <= 64 * 1024
+
+
 def sparse_conv(x, nbr_map, w, scale=None, shift=None, residual=None, relu=False, out=None):
     """x fp32 [nv, >=cin] (row stride = x.stride(0)); w fp32 [27,cin,cout] or [cin,cout]."""
     lib = _lib.load()
@@ -353,7 +371,7 @@ def split_f16(x, d=None, scale=None, per_row=False, interleaved=False, dst_row=N
     return (hi, lo, rinv) if per_row else (hi, lo)
 
 
-def rcb_order(coords_sorted, chunk_rows=2048, leaf_rows=128):
+def rcb_order(coords_sorted, chunk_rows=1024, leaf_rows=128):
     """Row order for the pooling operator (gp_rcb_order): recursive coordinate bisection of the Morton-ordered integer coords
     [nv, 3] inside chunks of chunk_rows rows into leaves of leaf_rows rows.  Returns (sigma, rho) i32 [nv]: new position -> row,
     row -> new position."""

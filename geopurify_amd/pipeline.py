@@ -384,7 +384,7 @@ class HotPath:
         self.pool_structure_ahead = bool(pool_structure_ahead)
         # rows 11 + operator fill as one matrix-core kernel (affinity_mfma=False: affinity_block_kernel + dst table; last A/B 26.08 -> 25.72 ms)
         self.affinity_mfma = bool(affinity_mfma)
-        # row order of the POOLING operator (round 6): "rcb" = recursive coordinate bisection inside 2048-row Morton chunks into the
+        # row order of the POOLING operator (round 6): "rcb" = recursive coordinate bisection inside 1024-row Morton chunks into the
         # operator's 128-row blocks (ops.rcb_order: block unions 4.75 -> 4.2 rows per row, a launch -4 %; only where the matrix-core
         # affinity kernel fills the operator -- it reads the embedding planes by pooling row), "morton" = the voxel order itself
         self.pool_row_order = pool_row_order
@@ -579,11 +579,11 @@ class HotPath:
                 how = "valid"
             rho = None
             nbr_op = nbr
-            if how == "valid" and self.pool_row_order == "rcb" and Nv > 2048:
+            if how == "valid" and self.pool_row_order == "rcb" and Nv > 1024:
                 # the operator's own row order: compact 128-row blocks (smaller neighbour unions).  Everything that enters the pooling by row
                 # is written through `rho` (the feature planes here, the embedding planes by the output layer), the lists are renumbered,
                 # and the final voxel -> point gather composes rho with the Morton rank; nothing else sees the order
-                sigma, rho = ops.rcb_order(cs, 2048, 128)
+                sigma, rho = ops.rcb_order(cs, 1024, 128)
                 nbr_op = ops.rows_renumber(nbr, sigma, rho)
                 state["rank_pool"] = rho[rank.long()].contiguous()
             state["pool"] = {"op": ops.pool_cs_plan(nbr_op, structure=how), "sc": sc, "rho": rho, "nbr": nbr_op,
@@ -594,12 +594,15 @@ class HotPath:
             mark("pool plan+split")
         return state
 
-    def refine(self, batch: SceneBatch, F, after_student=None, prepared=None):
+    def refine(self, batch: SceneBatch, F, after_student=None, prepared=None, classify_text=None):
         """evaluate_scene after the lift (affinity_module.py:1524-1589). F fp32 [N,D] -> [N,D].
         after_student: optional callable run on the host once the student's kernels are enqueued and before the affinity /
         pooling kernels are -- a scheduler's hook (bench.py enqueues the next scene's loader, lift and `prepare` on a second
         stream there, so that they run beside the matrix-core-bound convolutions and never beside the HBM-bound pooling).
-        prepared: the result of `prepare(batch, F)` when the scheduler ran it ahead."""
+        prepared: the result of `prepare(batch, F)` when the scheduler ran it ahead.
+        classify_text: (text_features [C, D], logit_scale) when the caller will classify the returned features next
+        (classify_and_count): the final voxel -> point gather then computes the predictions in the same pass
+        (gp_gather_rows_classify) and classify_and_count(result with THESE features) picks them up -- same rows, same labels."""
         p = prepared if prepared is not None else self.prepare(batch, F)
         X, rank, nbr, Nv, D = p["X"], p["rank"], p["nbr"], p["Nv"], p["D"]
         mark = self.stage_mark if self.stage_mark is not None else (lambda name: None)
@@ -624,7 +627,14 @@ class HotPath:
         self._last_pool_plan = p["pool"]                  # ... which re-applies THIS scene's operator (its row order included)
         out = self._pool(X, nbr, w, Nv, D, plan=p["pool"])
         mark("pooling")
-        out = ops.gather_rows(out, D, batch.scene_inds_reconstruct, row_map=p.get("rank_pool", rank))
+        self._fused_pred = None
+        if classify_text is not None and ops.can_gather_rows_classify(D, classify_text[0].shape[0]) and classify_text[0].shape[0] <= 32:
+            text_norm = torch.nn.functional.normalize(classify_text[0], dim=-1).contiguous()
+            out, pred, zero = ops.gather_rows_classify(out, D, batch.scene_inds_reconstruct, text_norm, classify_text[1],
+                                                       row_map=p.get("rank_pool", rank))
+            self._fused_pred = (out, classify_text[0], pred, zero)
+        else:
+            out = ops.gather_rows(out, D, batch.scene_inds_reconstruct, row_map=p.get("rank_pool", rank))
         mark("gather")
         self.stats = {"Nv": Nv, "nbr_map": p["nbr_map"], "pool_bytes_per_iter": Nv * (2 * D * 4 + self.K * 8),
                       "pool_kernel": self._pool_kernel}
@@ -768,8 +778,16 @@ class HotPath:
 
     # ---- row 13 + caller tail --------------------------------------------------------------------
     def classify_and_count(self, result, labels, num_classes, ignore_ids, counts):
-        text_norm = torch.nn.functional.normalize(result["text_features"], dim=-1).contiguous()
         feats = result["scene_features"]
+        fp = getattr(self, "_fused_pred", None)
+        if fp is not None and fp[0] is feats and fp[1] is result["text_features"]:
+            pred, zero = fp[2], fp[3]                     # computed by refine's final gather (classify_text=...): the same labels
+            self._fused_pred = None
+            ops.iou_hist(pred, labels, num_classes, ignore_ids, counts)
+            if self._chain_ops:
+                self.pool_chain_check(block=False)
+            return pred, zero
+        text_norm = torch.nn.functional.normalize(result["text_features"], dim=-1).contiguous()
         if text_norm.shape[0] > 32 and feats.shape[1] % 32 == 0:
             pred, zero = ops.classify_argmax_gemm(feats, text_norm)
         else:

@@ -477,6 +477,12 @@ int gp_views_visible_lists(const double *coords, int64_t n, const double *params
 /* pred[p] = argmax_c <normalize(F[p]), text_norm[c]> (first max on ties); zero_row[p] = sum|F|==0  */
 int gp_classify_argmax(const float *feat, int64_t ld, int32_t d, int64_t n, const float *text_norm,
                        int32_t c, float logit_scale, int64_t *pred, uint8_t *zero_row, void *stream);
+/* gp_gather_rows (the final voxel -> point gather, affinity_module.py:1589) and gp_classify_argmax (run/validation.py:413-416) in   */
+/* ONE pass: out[p, 0:d] = src[row_map[index[p]], 0:d] and pred / zero_row of those rows -- the per-point matrix is written once    */
+/* and not read back.  Same bits and labels as the two calls.  d a multiple of 64 up to 512, c * d * 4 <= 64 KiB.                  */
+int gp_gather_rows_classify(const float *src, int64_t ld_src, int32_t d, const int64_t *index, int64_t n, const int32_t *row_map,
+                            float *out, int64_t ld_out, const float *text_norm, int32_t c, float logit_scale, int64_t *pred,
+                            uint8_t *zero_row, void *stream);
 /* arg-max over the first c columns of logits rows fp32 [n, ld] (e.g. gp_sparse_conv with kv=1 as the   */
 /* exact-fp32 MFMA GEMM F @ T^T); zero_row from feat (optional).                                      */
 int gp_rows_argmax(const float *logits, int64_t ld, int32_t c, int64_t n, const float *feat, int64_t ld_f,

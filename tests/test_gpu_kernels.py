@@ -969,6 +969,30 @@ def test_pool_tiles_matches_ell_and_oracle(ops, R):
             ops.pool_tiles_apply(dev(torch.randn(Nv, 64)), tiles, 64, torch.empty((Nv, 64), device="cuda"))
 
 
+def test_gather_rows_classify_equals_the_two_calls(ops):
+    """gp_gather_rows_classify (the final voxel -> point gather with the class decision computed in the same pass): the rows of
+    gp_gather_rows and the labels / zero flags of gp_classify_argmax on them, bit for bit -- with and without a row map, a row of
+    zeros, a point count that leaves the last group partly empty; shapes the fused kernel does not take are an error."""
+    g = torch.Generator().manual_seed(8)
+    Nv, N, D, C = 3000, 7013, 512, 19
+    X = torch.randn(Nv, D + 32, generator=g)
+    X[17, :D] = 0.0
+    idx = torch.randint(0, Nv, (N,), generator=g)
+    idx[5] = 17
+    rmap = torch.randperm(Nv, generator=g).to(torch.int32)
+    text = F.normalize(torch.randn(C, D, generator=g), dim=1)
+    Xd, idd, rd, td = dev(X), dev(idx), dev(rmap), dev(text)
+    for row_map in (None, rd):
+        ref = ops.gather_rows(Xd, D, idd, row_map=row_map)
+        pred_ref, zero_ref = ops.classify_argmax(ref, td, 14.2)
+        out, pred, zero = ops.gather_rows_classify(Xd, D, idd, td, 14.2, row_map=row_map)
+        assert torch.equal(out, ref) and torch.equal(pred, pred_ref) and torch.equal(zero, zero_ref)
+        assert int(zero.sum()) >= 1 or row_map is not None
+    assert ops.can_gather_rows_classify(512, 19) and not ops.can_gather_rows_classify(512, 160) and not ops.can_gather_rows_classify(96, 19)
+    with pytest.raises(Exception, match="gp_gather_rows_classify"):
+        ops.gather_rows_classify(Xd, 96, idd, dev(F.normalize(torch.randn(C, 96), dim=1)), 1.0)
+
+
 # ------------------------------------------------------------------------------------------ row 12: the operator's own row order
 @pytest.mark.parametrize("chunk", [1024, 2048])
 def test_rcb_order_properties_and_the_maps_it_feeds(ops, chunk):
