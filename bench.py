@@ -795,7 +795,7 @@ def main():
             timeline.append({"after": after, "gpu": (e_first, e_load, e_lift, done), "host": (h0, h1, h2, time.perf_counter())})
         # No record_stream on these tensors (round 6): the allocator answered each with an event record on the consumer stream when the block
         # was freed -- ~40 markers in a row at every scene boundary, 0.14 ms in which streams[1] ran nothing (rocprofv3 kernel trace,
-        # profiles/r06_scene_boundary_gap.log).  The blocks are safe without: they belong to streams[0], and every LATER kernel of streams[0] sits
+        # profiles/r06_event_pairs_and_boundary.log).  The blocks are safe without: they belong to streams[0], and every LATER kernel of streams[0] sits
         # behind `after` -- the start of the NEXT refine on streams[1], i.e. behind every kernel of the scene that used them (or, for a scene
         # that was not lifted ahead, behind the whole of streams[1]: the wait_stream above).
         pending[i] = (batch, F, text, scale, done, prep)
@@ -882,7 +882,7 @@ def main():
     fork_streams()                                    # the side streams start after the zeroing (default stream)
     # HIP-event pairs around every pooling launch and every convolution layer of EVERY --time-every-th scene of the timed region: a
     # pair costs ~8 us of stream time (the marker waits for the kernel in front of it and holds the one behind), 56 pairs per scene =
-    # 0.24 ms = 1.1 % of the scene when every scene is timed (profiles/r06_event_pairs_price.log); the default, every 3rd scene (both rotated
+    # 0.24 ms = 1.1 % of the scene when every scene is timed (profiles/r06_event_pairs_and_boundary.log); the default, every 3rd scene (both rotated
     # scenes take their turn), still prices 152 pooling launches of a 24-scene timed region
     timers_on = os.environ.get("GP_BENCH_NO_TIMERS") != "1"
     t0 = time.perf_counter()
