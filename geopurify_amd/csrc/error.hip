@@ -40,7 +40,7 @@ const KnobRule k_rules[16] = {
     {0, -1, 0},          // 0: no such knob
     {0, 4, 0},           // 1
     {0, 8, 0},           // 2
-    {0, 0, 1u | 2u | 4u | 8u | 16u | 32u | 64u | 256u | 512u},         // 3
+    {0, 0, 1u | 2u | 4u | 8u | 16u | 32u | 256u | 512u},               // 3
     {0, 0, 1u | 2u | 4u | 8u | 16u | 32u | 64u | 128u | 256u | 512u},     // 4
     {0, 1, 0},           // 5
     {0, 256, 0},         // 6

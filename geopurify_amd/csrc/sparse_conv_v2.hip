@@ -432,6 +432,12 @@ __device__ __forceinline__ uint64_t cv_real() {
 //  * the centre-offset fold priced (tuning bit 8): with the centre offset's partial rows neither written nor read the twin's layer takes
 //    1.597 instead of 1.635 ms -- 2.3 % is the MOST a fold could return, before its own costs (a 128-row x 512-column tile per workgroup or a
 //    row-maximum exchange between the two column tiles): not built.
+//  * ONE wave per SIMD (source: commit 501a632, `conv_phase1_w4_kernel`): four waves x 128 x 128 with the 256 accumulator registers in AGPRs,
+//    every LDS byte read by two waves instead of four, no SIMD partner to wait for at the barrier; inline-asm MFMAs and LDS-DMA, the K loop
+//    scheduled by hand (B fragments one column tile ahead, next step's A fragments and the DMA of stage s + 2 between the lo*hi MFMAs).
+//    Compiler-scheduled around asm MFMAs: 1.869 ms, bit-identical; hand-scheduled, no spills in the loop: 1.613 ms vs 1.546 ms for this body
+//    on the same box, and not bit-identical (nothing pads the MFMA -> `v_accvgpr` / store hazards the compiler cannot see behind asm; the
+//    waits that would fix it only add time).  With one wave per SIMD nothing hides an LDS round trip or a DMA issue stall.  Not kept.
 template <bool TUNE, bool STAMP>
 __device__ __forceinline__ void
 conv_phase1_dma_body(const _Float16 *__restrict__ x_hi, const _Float16 *__restrict__ x_lo, int64_t ld_xh,
@@ -728,245 +734,6 @@ __global__ void __launch_bounds__(NT2) conv_phase1_stamp_kernel(P1_PARAMS) { con
 
 #undef P1_PARAMS
 #undef P1_FWD
-
-// ------------------------------------------------------------------------------------------------
-// Round 6 experiment: the same tile on FOUR waves (one per SIMD), each owning 128 pairs x 128 columns -- 64 accumulator tiles = 256
-// registers, which the compiler places in the AGPR half of a 512-register wave (`__launch_bounds__(256)`), operands in the VGPR half.
-// What it is for: (1) no SIMD partner -- the stamps of the eight-wave loop show its idle time is wave 0 waiting 1 780 cycles per step at
-// the barrier for wave 4, which the arbiter serves second; (2) a step reads 128 KiB of fragments from LDS instead of 192 (every staged
-// byte is read by two waves, not by two or four).  The step is split around the hand-over as in the PIPE experiments: head = every LDS read
-// + the hi*hi / hi*lo terms, hand-over, the LDS-DMA of stage s + 2 into the slot just freed, tail = the lo*hi terms on registers.  Same
-// products in the same order per accumulator: bit-identical partial rows.  Interleaved rows + step-blocked weights only (the product forms).
-constexpr int NT4 = 256;
-// (the accumulators are PINNED to AGPRs by the constraint: with the intrinsic the register allocator shuttles them between the two
-// halves of the file around every MFMA -- three to five v_accvgpr_mov / read / write per matrix instruction in the first build)
-// LDS-DMA with a scalar base + 32-bit lane offset (8 VGPRs for a wave's 8 gathered rows instead of 8 address pairs + temporaries), hidden
-// from the compiler: a visible LDS-DMA makes it drain `vmcnt(0)` in front of every later LDS read it cannot tell apart from the DMA's target
-template <int IMM>
-__device__ __forceinline__ void w4_glds(const void *sbase, uint32_t voff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_addr), "n"(IMM)
-                 : "memory");
-}
-__device__ __forceinline__ void w4_mfma(f32x4 &c, const f16x8 &a, const f16x8 &b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");      // (volatile + memory: the loop keeps the SOURCE order)
-}
-__global__ void __launch_bounds__(NT4)
-conv_phase1_w4_kernel(const _Float16 *__restrict__ x_il, int64_t ld_xh, const int32_t *__restrict__ pair_in,
-                      const int32_t *__restrict__ tile_start, const int4 *__restrict__ tile_desc, int nseg, int kv,
-                      const _Float16 *__restrict__ w_hi, const _Float16 *__restrict__ w_lo, int cin, int cout, float *__restrict__ P,
-                      int n_tiles, int tile_begin, int tile_count, int pair_base, const float *__restrict__ x_inv_scale, int64_t q_e_off) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    V2Smem &sm = *reinterpret_cast<V2Smem *>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t nb = gridDim.x, per_xcd = nb >> 3;
-    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int nt = (int)(lb % n_tiles);
-    const int mt_local = (int)(lb / n_tiles);
-    if (mt_local >= tile_count) return;
-    const int mt = tile_begin + mt_local;
-    if (mt >= tile_start[nseg]) return;
-    const int4 td = tile_desc[mt];
-    const int k = td.x, base = td.y, cnt = td.z;
-    const int n0 = nt * TN;
-    const int lrow = lane >> 2, lp = lane & 3;
-    const int q = (lp ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 8;
-    const int64_t db = w_lo - w_hi;
-    constexpr uint32_t a_bufstride = 2u * TM * APITCH * 2u;              // 32 KiB: 256 rows x 128 bytes [hi 32 | lo 32]
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw;
-    // staging: wave wv stages rows 64 wv .. 64 wv + 63 of both operands -- 8 full-line pieces of 8 gathered rows, 4 + 4 one-KiB runs of weights
-    uint32_t goff[8];
-    int in_rows[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wv * 64 + i * 8 + (lane >> 3);
-        const int in_row = pair_in[base + (row < cnt ? row : cnt - 1)];
-        in_rows[i] = in_row;
-        const int L = (lane & 7) ^ ((row >> 1) & 7);
-        goff[i] = (uint32_t)in_row * (uint32_t)(ld_xh * 2) + (uint32_t)L * 16u;
-    }
-    // weights: scalar base of the tile's step-blocked image (hi plane; the lo plane sits db halfs behind), lane offset inside a wave's 64 rows
-    const _Float16 *wtile = w_hi + (((int64_t)k * n_tiles + nt) * (cin / TK)) * TN * TK + (int64_t)(wv * 64) * TK;
-    const uint32_t woff = (uint32_t)((lrow * TK + q) * 2);
-    const uint32_t ldsA = lds0 + (uint32_t)(wv * 64) * 128u;                                      // + slot * a_bufstride + piece * 1024
-    const uint32_t ldsBh = lds0 + (uint32_t)offsetof(V2Smem, b_hi) + (uint32_t)(wv * 64) * (APITCH * 2);    // + slot * 16 KiB + piece * 1024
-    const uint32_t ldsBl = lds0 + (uint32_t)offsetof(V2Smem, b_lo) + (uint32_t)(wv * 64) * (APITCH * 2);
-    auto issue = [&](int c0, int buf) {
-        const unsigned char *xb = reinterpret_cast<const unsigned char *>(x_il) + (size_t)c0 * 4;          // a K step = 128 bytes of a row
-        const _Float16 *wb = wtile + (int64_t)c0 * TN;
-        const uint32_t la = ldsA + (uint32_t)buf * a_bufstride, lh = ldsBh + (uint32_t)buf * (TN * APITCH * 2), ll = ldsBl + (uint32_t)buf * (TN * APITCH * 2);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w4_glds<0>(xb, goff[i], la + i * 1024);
-        w4_glds<0>(wb, woff, lh); w4_glds<1024>(wb, woff, lh + 1024); w4_glds<2048>(wb, woff, lh + 2048); w4_glds<3072>(wb, woff, lh + 3072);
-        w4_glds<0>(wb + db, woff, ll); w4_glds<1024>(wb + db, woff, ll + 1024); w4_glds<2048>(wb + db, woff, ll + 2048); w4_glds<3072>(wb + db, woff, ll + 3072);
-    };
-    const int wm = wv >> 1, wn = wv & 1;
-    const int fl = lane & 15, fq = lane >> 4;
-    const int fsw = sw_slot(fl, fq) * 8;
-    // A fragments: row wm * 128 + 16 i + fl of the 128-byte-row image; the slot swizzle (row >> 1) & 7 = (fl >> 1) & 7 does not depend on i:
-    // one address per half + immediates (2 KiB per row tile)
-    const int hsw = (fl >> 1) & 7;
-    const uint32_t fa_hi0 = (uint32_t)((wm * 128 + fl) * 128 + ((fq ^ hsw) << 4));
-    const uint32_t fa_lo0 = (uint32_t)((wm * 128 + fl) * 128 + (((4 + fq) ^ hsw) << 4));
-    const int rows_here = cnt - wm * 128;
-    const int nrt = __builtin_amdgcn_readfirstlane(rows_here <= 0 ? 0 : (rows_here > 64 ? 8 : 4));       // live 16-row tiles, in steps of four
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int steps = cin / TK;
-    issue(0, 0);
-    // the tile's 256 row scales: hand-ordered loads between the first two stages (see conv_phase1_dma_body), parked behind the ring
-    const uint32_t rinv_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_raw + (uint32_t)sizeof(V2Smem);
-    const float *rinv_src = x_inv_scale ? x_inv_scale : reinterpret_cast<const float *>(pair_in);
-    float rv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("global_load_dword %0, %1, off" : "=v"(rv[i]) : "v"(rinv_src + in_rows[i]) : "memory");
-    issue(steps > 1 ? TK : 0, 1);
-    asm volatile("s_waitcnt vmcnt(16)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
-    if ((lane & 7) == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            asm volatile("ds_write_b32 %0, %1" ::"v"(rinv_a + (uint32_t)(wv * 64 + i * 8 + (lane >> 3)) * 4u), "v"(x_inv_scale ? rv[i] : 1.f) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // stage 0 has landed, stage 1 stays in flight
-    // The loop is scheduled BY HAND (every matrix instruction is a volatile asm with a memory clobber: nothing moves across it).  One wave per
-    // SIMD has no partner to cover its stalls, so nothing may stall: a step's B fragments are read one column tile ahead of their 16 MFMAs;
-    // the hand-over sits between the head (hi*hi, hi*lo: 128 MFMAs) and the tail (lo*hi: 64 MFMAs on registers); and the tail's 64 MFMAs carry,
-    // spread between them, the 16 LDS-DMA instructions of stage s + 2 (one per four MFMAs: the CU's address path takes 16 cycles per
-    // instruction, four waves share it) and the 18 fragment reads the NEXT step starts with (its A fragments and first B pair).
-    auto k_loop = [&](auto nrt_c) {
-        constexpr int NRT = decltype(nrt_c)::value;
-        constexpr int NR = NRT > 0 ? NRT : 1;
-        const unsigned char *xb0 = reinterpret_cast<const unsigned char *>(x_il);
-        // every fragment read = ONE of three base registers + a 16-bit immediate (the bases are made opaque: left to itself the compiler
-        // keeps a dozen derived addresses in registers, spills them, and waits `vmcnt(0)` -- for the LDS-DMA in flight -- at every reload)
-        typedef const __attribute__((address_space(3))) unsigned char *lds_ptr;
-        uint32_t ab_hi = lds0 + fa_hi0, ab_lo = lds0 + fa_lo0, bb = lds0 + (uint32_t)offsetof(V2Smem, b_hi) + (uint32_t)((wn * 128 + fl) * APITCH + fsw) * 2u;
-        asm volatile("" : "+v"(ab_hi), "+v"(ab_lo), "+v"(bb));
-        auto lds16 = [&](uint32_t basev, int imm) {
-            return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>((lds_ptr)(uintptr_t)basev + imm);
-        };
-        auto rd_hi = [&](int imm) { return lds16(ab_hi, imm); };
-        auto rd_lo = [&](int imm) { return lds16(ab_lo, imm); };
-        auto bh_at = [&](int buf, int j) { return lds16(bb, buf * (TN * APITCH * 2) + j * 1024); };
-        auto bl_at = [&](int buf, int j) { return lds16(bb, 2 * TN * APITCH * 2 + buf * (TN * APITCH * 2) + j * 1024); };
-        // ah / b0h / b0l: read for the NEXT step in this step's tail into the registers this step's head has finished with; al is needed
-        // by the tail itself, so it alternates between two sets (the loop is unrolled by two: no moves)
-        // ONE loop body (the last steps take wave-uniform branches around the DMA / the prefetch): peeled copies get their own register
-        // assignment and the compiler then shuffles accumulators between AGPRs right behind asm MFMAs whose results have not landed
-        // (no hazard padding around inline asm: wrong sums in the first build of this loop).
-        auto step = [&](auto buf_c, int s, f16x8 (&ah)[NR], f16x8 (&al_c)[NR], f16x8 (&al_n)[NR], f16x8 &b0h, f16x8 &b0l) {
-            constexpr int buf = decltype(buf_c)::value;      // (the ring slot is the step's parity: a constant of the unrolled pair -- every LDS address an immediate)
-            const bool dma = s + 2 < steps, more = s + 1 < steps;
-            f16x8 bh[8], bl = b0l;
-            bh[0] = b0h;
-            // ---- head
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f16x8 bl_n = bl;
-                if (j < 7) { bh[j + 1] = bh_at(buf, j + 1); bl_n = bl_at(buf, j + 1); }
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) w4_mfma(acc[i][j], ah[i], bh[j]);
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) w4_mfma(acc[i][j], ah[i], bl);
-                bl = bl_n;
-            }
-            // ---- hand-over: stage s + 1 (issued one step ago) has landed, every wave is done reading stage s
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // ---- tail, with the next stage's DMA and the next step's first reads in its shadow
-            const unsigned char *xb = xb0 + (size_t)(s + 2) * TK * 4;
-            const _Float16 *wb = wtile + (int64_t)(s + 2) * TK * TN;
-            const uint32_t la = ldsA + (uint32_t)buf * a_bufstride, lh = ldsBh + (uint32_t)buf * (TN * APITCH * 2), ll = ldsBl + (uint32_t)buf * (TN * APITCH * 2);
-            constexpr uint32_t a_next = (uint32_t)(buf ^ 1) * a_bufstride;
-            auto tail_j = [&](auto j_c) {
-                constexpr int j = decltype(j_c)::value;
-                if (dma) {
-                    w4_glds<0>(xb, goff[j], la + j * 1024);
-                    if constexpr (j & 1) w4_glds<(j >> 1) * 1024>(wb + db, woff, ll + (j >> 1) * 1024);
-                    else w4_glds<(j >> 1) * 1024>(wb, woff, lh + (j >> 1) * 1024);
-                }
-                if (more) {
-                    if constexpr (j < NRT) { ah[j] = rd_hi(j * 2048 + (int)a_next); al_n[j] = rd_lo(j * 2048 + (int)a_next); }
-                    if constexpr (j == 7) { b0h = bh_at(buf ^ 1, 0); b0l = bl_at(buf ^ 1, 0); }
-                }
-#pragma unroll
-                for (int i = 0; i < NRT; ++i) w4_mfma(acc[i][j], al_c[i], bh[j]);
-            };
-            tail_j(std::integral_constant<int, 0>{}); tail_j(std::integral_constant<int, 1>{}); tail_j(std::integral_constant<int, 2>{});
-            tail_j(std::integral_constant<int, 3>{}); tail_j(std::integral_constant<int, 4>{}); tail_j(std::integral_constant<int, 5>{});
-            tail_j(std::integral_constant<int, 6>{}); tail_j(std::integral_constant<int, 7>{});
-        };
-        f16x8 ah[NR], alA[NR], alB[NR], b0h, b0l;
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) { ah[i] = rd_hi(i * 2048); alA[i] = rd_lo(i * 2048); }
-        b0h = bh_at(0, 0);
-        b0l = bl_at(0, 0);
-        for (int s = 0; s < steps; s += 2) {
-            step(std::integral_constant<int, 0>{}, s, ah, alA, alB, b0h, b0l);
-            if (s + 1 < steps) step(std::integral_constant<int, 1>{}, s + 1, ah, alB, alA, b0h, b0l);
-        }
-    };
-    if (nrt == 8) k_loop(std::integral_constant<int, 8>{});
-    else if (nrt == 4) k_loop(std::integral_constant<int, 4>{});
-    else k_loop(std::integral_constant<int, 0>{});
-    // (the matrix instructions are inline asm: the compiler's hazard recogniser does not see them -- the last results must have left the
-    // matrix pipe before the first v_accvgpr_read: 16 passes = 64 cycles)
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    // ---- epilogue: the 24-bit block-floating partial rows of conv_phase1_dma_body (same bytes)
-    const float *s_rinv = reinterpret_cast<const float *>(smem_raw + sizeof(V2Smem));
-    unsigned char *pb = reinterpret_cast<unsigned char *>(P);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < nrt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int grow = wm * 128 + i * 16 + fq * 4 + r;
-                const float sc = s_rinv[grow];
-                const int64_t prow = base - pair_base + grow;
-                const int col = n0 + wn * 128 + fl * 8;
-                float m = fmaxf(fmaxf(fabsf(acc[i][0][r]), fabsf(acc[i][1][r])), fabsf(acc[i][2][r]));
-                m = fmaxf(fmaxf(m, fabsf(acc[i][3][r])), fabsf(acc[i][4][r]));
-                m = fmaxf(fmaxf(m, fabsf(acc[i][5][r])), fabsf(acc[i][6][r]));
-                m = fmaxf(m, fabsf(acc[i][7][r]));
-                unsigned mi = (acc[i][0][r] != acc[i][0][r]) ? 0x7f800000u : __float_as_uint(m);
-                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0xb1, 0xf, 0xf, true));
-                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0x4e, 0xf, 0xf, true));
-                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0x124, 0xf, 0xf, true));
-                mi = max(mi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mi, 0x128, 0xf, 0xf, true));
-                const unsigned Em = (mi + 1u) >> 23;
-                const unsigned fld = 275u - Em;
-                const float sf = __uint_as_float((fld > 254u ? 254u : fld) << 23);
-                int Es = (int)Em + ((int)(__float_as_uint(sc) >> 23) - 127);
-                Es = Es < 22 ? 22 : Es;
-                const unsigned E = (Em == 255u || Es > 254) ? 255u : (unsigned)Es;
-                unsigned t[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = __float_as_uint(fmaf(acc[i][j][r], sf, 12582912.f));
-                if (grow < cnt) {
-                    u32x4 h;
-                    u32x2 l;
-                    h[0] = __builtin_amdgcn_perm(t[1], t[0], 0x04020100u);
-                    h[1] = __builtin_amdgcn_perm(t[2], t[1], 0x05040201u);
-                    h[2] = __builtin_amdgcn_perm(t[3], t[2], 0x06050402u);
-                    h[3] = __builtin_amdgcn_perm(t[5], t[4], 0x04020100u);
-                    l[0] = __builtin_amdgcn_perm(t[6], t[5], 0x05040201u);
-                    l[1] = __builtin_amdgcn_perm(t[7], t[6], 0x06050402u);
-                    unsigned char *dst = pb + ((unsigned)prow * (unsigned)cout + (unsigned)(col & ~127)) * 3u;
-                    *reinterpret_cast<u32x4 *>(dst + fl * 16) = h;
-                    *reinterpret_cast<u32x2 *>(dst + 256 + fl * 8) = l;
-                    if (fl == 0) (pb + q_e_off)[(unsigned)prow * (unsigned)(cout >> 7) + (unsigned)(col >> 7)] = (unsigned char)E;
-                }
-            }
-        }
-    }
-}
 
 // sum of a voxel's partial rows in ASCENDING offset order (bitwise reproducible), NL independent loads in flight per round
 // (a voxel has 7.3 partial rows on average: one round of 8 for most voxels)
@@ -1591,7 +1358,6 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
     GP_SMEM_ATTR(conv_phase1_dma_kernel, P1_DMA_SMEM);
     GP_SMEM_ATTR(conv_phase1_tuning_kernel, P1_DMA_SMEM);
     GP_SMEM_ATTR(conv_phase1_stamp_kernel, P1_DMA_SMEM);
-    GP_SMEM_ATTR(conv_phase1_w4_kernel, P1_DMA_SMEM);
 
     // tuning aid: gp_debug_ptr(1, buf, bytes) selects the stamped twin; every chunk launch writes its workgroups' stamps at
     // blockIdx * 16 uint64 (a chunk overwrites the previous one's: the last chunk of the last call stays)
@@ -1654,18 +1420,11 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         const bool q24 = dma_path && !(g_conv_ablate & 32) && q24_fits;   // tuning bit 5: the fp32 partial rows of rounds 1-4, same kernels otherwise
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            const int tune = (g_conv_ablate & ~(16 | 64)) | ((dma_path && !q24_fits) ? 32 : 0);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            const int tune = (g_conv_ablate & ~16) | ((dma_path && !q24_fits) ? 32 : 0);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
                 cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off, w_blocked, plane_flags & 1
-            const bool w4 = dma_path && q24 && (g_conv_ablate & 64) && (plane_flags & 1) && w_blocked && !stamp &&
-                            nv * ld_xh * 2 < ((int64_t)1 << 32);              // (experiment: the four-wave tile, knob 3 bit 6)
-            if (w4) {
-                conv_phase1_w4_kernel<<<(unsigned)nblocks, NT4, P1_DMA_SMEM, s>>>(
-                    static_cast<const _Float16 *>(x_hi), ld_xh, pair_in, tile_start, reinterpret_cast<const int4 *>(tile_desc), nseg, kv,
-                    static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), cin, cout, partial, n_tiles, tile_begin, tile_count,
-                    pair_base, x_row_inv_scale, q_e_off);
-            } else if (dma_path) {
+            if (dma_path) {
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 16 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
                              g_gp_debug_bytes[1], (size_t)nblocks * 16 * sizeof(uint64_t));
