@@ -46,7 +46,7 @@ SIGNATURES = {
                                        c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P,
                                        c_int64, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), _P, _P,
                                        _P, _P, c_int64, _P, c_int32, c_int32, _P]),
-    "gp_conv_weights_split_blocked": (c_int32, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
+    "gp_conv_weights_split_blocked": (c_int32, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, c_int32, _P]),
     "gp_pow2_scale": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_size_t, _P]),
     "gp_split_f16_scaled": (c_int32, [_P, c_int64, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P, _P]),
     "gp_rcb_order": (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
@@ -114,11 +114,11 @@ SIGNATURES = {
     "gp_bn_train_apply": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64,
                                     _P, _P, c_int64, c_float, _P, _P, _P]),
     "gp_bn_train_backward": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64,
-                                       _P, c_int64, _P, _P, _P, c_size_t, _P]),
+                                       _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "gp_col_sums_f64": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
     "gp_bn_bwd_sums_f64": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "gp_bn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, _P, _P, c_int64, c_int64, c_int32, _P, c_int64,
-                                  _P, c_int64, _P]),
+                                  _P, c_int64, _P, _P]),
     "gp_infonce_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "gp_infonce_fwd_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, c_int64, c_int32, c_float, _P, _P, c_int64,
                                      _P, c_size_t, _P]),
@@ -127,6 +127,8 @@ SIGNATURES = {
                                       _P, _P, _P, c_size_t, _P]),
     "gp_adamw_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "gp_knn_points_f32": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
+    "gp_sampler_select": (c_int32, [_P, c_int64, c_int64, c_int64, _P, c_int32, _P, _P, _P]),
+    "gp_normalize_split_f16": (c_int32, [_P, c_int64, c_int32, c_int64, c_int64, c_float, _P, _P, c_int64, _P]),
     "gp_iou_hist_i64": (c_int32, [_P, _P, c_int64, c_int32, POINTER(c_int64), c_int32, _P, _P]),
     "gp_fused_decode_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gp_fused_decode": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),

@@ -1185,8 +1185,10 @@ __global__ void weight_split_kernel(const float *__restrict__ w, int kv, int cin
 
 // the same split into the step-blocked layout of the two-phase kernels: [kv][cout / 256][cin / 32][256 rows][32 halfs], row rho of a
 // column tile = its column (rho & 128) | (rho & 15) << 3 | (rho >> 4 & 7) (the LDS row the LDS-DMA kernel stages it in)
+// transpose_flip: the operand of the DATA-GRADIENT convolution V[k] = W[kv - 1 - k]^T taken straight from w ([kv][cout][cin] of V's
+// dimensions: the forward layer's [kv][its cin][its cout]) -- no flipped / transposed fp32 copy in between, and reads along w's rows.
 __global__ void weight_split_blocked_kernel(const float *__restrict__ w, int kv, int cin, int cout, float s,
-                                            _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+                                            _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, int transpose_flip) {
     const int64_t total = (int64_t)kv * cin * cout;
     const int steps = cin / TK, nt = cout / TN;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1196,7 +1198,8 @@ __global__ void weight_split_blocked_kernel(const float *__restrict__ w, int kv,
         const int t = (int)((i / ((int64_t)TK * TN * steps)) % nt);
         const int64_t k = i / ((int64_t)TK * TN * steps * nt);
         const int c = (rho & 128) | ((rho & 15) << 3) | ((rho >> 4) & 7);
-        const float v = w[(k * cin + st * TK + kk) * cout + t * TN + c] * s;
+        const float v = (transpose_flip ? w[((kv - 1 - k) * cout + t * TN + c) * cin + st * TK + kk]
+                                        : w[(k * cin + st * TK + kk) * cout + t * TN + c]) * s;
         const _Float16 h = (_Float16)v;
         hi[i] = h;
         lo[i] = (_Float16)(v - (float)h);
@@ -1283,11 +1286,11 @@ extern "C" int gp_conv_weights_split(const float *w, int32_t kv, int32_t cin, in
 }
 
 extern "C" int gp_conv_weights_split_blocked(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2, void *w_hi,
-                                             void *w_lo, void *stream_) {
+                                             void *w_lo, int32_t transpose_flip, void *stream_) {
     GP_CHECK_ARG(w && w_hi && w_lo && kv > 0 && cin > 0 && cout > 0, "gp_conv_weights_split_blocked: null/empty argument");
     GP_CHECK_ARG(cin % TK == 0 && cout % TN == 0, "gp_conv_weights_split_blocked: cin=%d must be a multiple of %d and cout=%d of %d", cin, TK, cout, TN);
     weight_split_blocked_kernel<<<2048, 256, 0, gp_stream(stream_)>>>(w, kv, cin, cout, scale_pow2, static_cast<_Float16 *>(w_hi),
-                                                                      static_cast<_Float16 *>(w_lo));
+                                                                      static_cast<_Float16 *>(w_lo), transpose_flip);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -44,44 +44,105 @@ __device__ __forceinline__ void col_partial(int64_t nv, int c, double *__restric
 __global__ void __launch_bounds__(256) cs_sum_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, double *__restrict__ partial) {
     col_partial<1>(nv, c, partial, [&](int64_t r, int col, double *v) { v[0] = (double)y[r * ld + col]; });
 }
+// sums of x and x^2 in one sweep (gp_col_stats)
+__global__ void __launch_bounds__(256) cs_sum2_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, double *__restrict__ partial) {
+    col_partial<2>(nv, c, partial, [&](int64_t r, int col, double *v) { const double x = (double)y[r * ld + col]; v[0] = x; v[1] = x * x; });
+}
 __global__ void __launch_bounds__(256) cs_var_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c,
                                                      const float *__restrict__ mean, double *__restrict__ partial) {
     col_partial<1>(nv, c, partial, [&](int64_t r, int col, double *v) { double d = (double)y[r * ld + col] - (double)mean[col]; v[0] = d * d; });
 }
-// out[q][c] = scale * sum over chunks: one workgroup per 64 columns, the chunks strided over 4 waves (fixed order)
-__global__ void __launch_bounds__(256) cs_final_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c, double scale,
-                                                       float *__restrict__ out) {
-    __shared__ double red[4][64];
+// out[q][c] = scale * sum over chunks: one workgroup per 64 columns, the chunks strided over CF_WAVES waves (fixed order).  16 waves:
+// with 4 the 8-16 workgroups of a 512-column layer each walked 110 dependent loads (40 us per call, 27 calls per training step).
+constexpr int CF_WAVES = 16;
+template <typename OUT>
+__device__ __forceinline__ void cs_final_body(const double *__restrict__ partial, int64_t nchunks, int nq, int c, double scale, OUT *__restrict__ out) {
+    __shared__ double red[CF_WAVES][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;                 // flat (q, col)
     double s = 0.0;
     if (i < nq * c) {
         const int q = i / c, col = i % c;
-        for (int64_t k = wv; k < nchunks; k += 4) s += partial[(k * nq + q) * c + col];
+        for (int64_t k = wv; k < nchunks; k += CF_WAVES) s += partial[(k * nq + q) * c + col];
     }
     red[wv][lane] = s;
     __syncthreads();
-    if (wv == 0 && i < nq * c) out[i] = (float)((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale);
+    if (wv == 0 && i < nq * c) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < CF_WAVES; ++w) t += red[w][lane];
+        out[i] = (OUT)(t * scale);
+    }
+}
+// mean[c], var[c] from the partial sums of x (q = 0) and x^2 (q = 1)
+__global__ void __launch_bounds__(CF_WAVES * 64) cs_meanvar_final_kernel(const double *__restrict__ partial, int64_t nchunks, int c, double inv_n,
+                                                                         float *__restrict__ mean, float *__restrict__ var) {
+    __shared__ double red[2][CF_WAVES][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0;
+    if (col < c)
+        for (int64_t k = wv; k < nchunks; k += CF_WAVES) { s0 += partial[(k * 2) * c + col]; s1 += partial[(k * 2 + 1) * c + col]; }
+    red[0][wv][lane] = s0;
+    red[1][wv][lane] = s1;
+    __syncthreads();
+    if (wv == 0 && col < c) {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < CF_WAVES; ++w) { t0 += red[0][w][lane]; t1 += red[1][w][lane]; }
+        const double m = t0 * inv_n, v = t1 * inv_n - m * m;
+        mean[col] = (float)m;
+        var[col] = (float)(v > 0.0 ? v : 0.0);
+    }
+}
+__global__ void __launch_bounds__(CF_WAVES * 64) cs_final_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c, double scale,
+                                                                 float *__restrict__ out) {
+    cs_final_body(partial, nchunks, nq, c, scale, out);
 }
 
 // ------------------------------------------------------------------------------------------------ BN forward / backward
-__global__ void bn_apply_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, const float *__restrict__ mean,
-                                const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                const float *__restrict__ residual, int64_t ld_res, int relu, float *__restrict__ out, int64_t ld_out,
-                                _Float16 *__restrict__ out_hi, _Float16 *__restrict__ out_lo, int64_t ld_sp) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= nv * c) return;
-    int64_t r = i / c;
-    int col = (int)(i % c);
-    float invstd = 1.0f / sqrtf(var[col] + eps);
-    float v = (y[r * ld + col] - mean[col]) * invstd * gamma[col] + beta[col];
-    if (residual) v += residual[r * ld_res + col];
-    if (relu) v = v > 0.f ? v : 0.f;
-    out[r * ld_out + col] = v;
-    if (out_hi) {
-        _Float16 h = (_Float16)v;
-        out_hi[r * ld_sp + col] = h;
-        out_lo[r * ld_sp + col] = (_Float16)(v - (float)h);
+template <int W>
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, const float *__restrict__ mean,
+                const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                const float *__restrict__ residual, int64_t ld_res, int relu, float *__restrict__ out, int64_t ld_out,
+                _Float16 *__restrict__ out_hi, _Float16 *__restrict__ out_lo, int64_t ld_sp) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int cw = c / W;
+    const int64_t total = nv * cw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cw;
+        const int col = (int)(i - r * cw) * W;
+        float yv[W], rv[W], v[W];
+        if (W == 4) {
+            *reinterpret_cast<float4 *>(yv) = *reinterpret_cast<const float4 *>(y + r * ld + col);
+            if (residual) *reinterpret_cast<float4 *>(rv) = *reinterpret_cast<const float4 *>(residual + r * ld_res + col);
+        } else {
+            yv[0] = y[r * ld + col];
+            if (residual) rv[0] = residual[r * ld_res + col];
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float invstd = 1.0f / sqrtf(var[col + k] + eps);
+            v[k] = (yv[k] - mean[col + k]) * invstd * gamma[col + k] + beta[col + k];
+            if (residual) v[k] += rv[k];
+            if (relu) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        if (W == 4) *reinterpret_cast<float4 *>(out + r * ld_out + col) = *reinterpret_cast<const float4 *>(v);
+        else out[r * ld_out + col] = v[0];
+        if (out_hi) {
+            if (W == 4) {
+                f16x4 h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { h[k] = (_Float16)v[k]; l[k] = (_Float16)(v[k] - (float)h[k]); }
+                *reinterpret_cast<f16x4 *>(out_hi + r * ld_sp + col) = h;
+                *reinterpret_cast<f16x4 *>(out_lo + r * ld_sp + col) = l;
+            } else {
+                const _Float16 h = (_Float16)v[0];
+                out_hi[r * ld_sp + col] = h;
+                out_lo[r * ld_sp + col] = (_Float16)(v[0] - (float)h);
+            }
+        }
     }
 }
 __global__ void bn_running_kernel(const float *__restrict__ mean, const float *__restrict__ var, int c, int64_t nv, float momentum,
@@ -104,21 +165,78 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *__restr
         v[1] = (double)dz * (double)xhat;
     });
 }
-__global__ void bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
-                                    const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean, const float *__restrict__ var,
-                                    float eps, const float *__restrict__ gamma, const float *__restrict__ sums, int64_t n_total, int64_t nv, int c,
-                                    float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dz_out, int64_t ld_dz) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= nv * c) return;
-    int64_t r = i / c;
-    int col = (int)(i % c);
-    float dz = dout[r * ld_d + col];
-    if (act && !(act[r * ld_a + col] > 0.f)) dz = 0.f;
-    float invstd = 1.0f / sqrtf(var[col] + eps);
-    float xhat = (y[r * ld_y + col] - mean[col]) * invstd;
-    float inv_n = 1.0f / (float)n_total;
-    dy[r * ld_dy + col] = gamma[col] * invstd * (dz - sums[col] * inv_n - xhat * sums[c + col] * inv_n);
-    if (dz_out) dz_out[r * ld_dz + col] = dz;
+// W = 4: c and every leading dimension are multiples of 4 (16-byte accesses); amax_bits (nullable): atomicMax of |dy| as the uint image of a
+// non-negative float, one atomic per workgroup -- the power-of-two scale of the gradient's f16 split without another sweep over dy.
+template <int W>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
+                    const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean, const float *__restrict__ var,
+                    float eps, const float *__restrict__ gamma, const float *__restrict__ sums, int64_t n_total, int64_t nv, int c,
+                    float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dz_out, int64_t ld_dz, unsigned *__restrict__ amax_bits) {
+    const int cw = c / W;
+    const int64_t total = nv * cw;
+    const float inv_n = 1.0f / (float)n_total;
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cw;
+        const int col = (int)(i - r * cw) * W;
+        float dz[W], yv[W], av[W], o[W];
+        if (W == 4) {
+            *reinterpret_cast<float4 *>(dz) = *reinterpret_cast<const float4 *>(dout + r * ld_d + col);
+            *reinterpret_cast<float4 *>(yv) = *reinterpret_cast<const float4 *>(y + r * ld_y + col);
+            if (act) *reinterpret_cast<float4 *>(av) = *reinterpret_cast<const float4 *>(act + r * ld_a + col);
+        } else {
+            dz[0] = dout[r * ld_d + col];
+            yv[0] = y[r * ld_y + col];
+            if (act) av[0] = act[r * ld_a + col];
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            if (act && !(av[k] > 0.f)) dz[k] = 0.f;
+            const float invstd = 1.0f / sqrtf(var[col + k] + eps);
+            const float xhat = (yv[k] - mean[col + k]) * invstd;
+            o[k] = gamma[col + k] * invstd * (dz[k] - sums[col + k] * inv_n - xhat * sums[c + col + k] * inv_n);
+            m = fmaxf(m, fabsf(o[k]));
+        }
+        if (W == 4) {
+            *reinterpret_cast<float4 *>(dy + r * ld_dy + col) = *reinterpret_cast<const float4 *>(o);
+            if (dz_out) *reinterpret_cast<float4 *>(dz_out + r * ld_dz + col) = *reinterpret_cast<const float4 *>(dz);
+        } else {
+            dy[r * ld_dy + col] = o[0];
+            if (dz_out) dz_out[r * ld_dz + col] = dz[0];
+        }
+    }
+    if (amax_bits) {
+        __shared__ float s_m[4];
+        m = gp_wave_max(m);
+        if (gp_lane() == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+            atomicMax(amax_bits, __float_as_uint(m));
+        }
+    }
+}
+// scale2[0] holds the amax bits on entry; [s, 1/s] on exit
+__global__ void bn_scale2_kernel(float *__restrict__ scale2) {
+    const float s = gp_pow2_for(__uint_as_float(reinterpret_cast<const unsigned *>(scale2)[0]));
+    scale2[0] = s;
+    scale2[1] = 1.f / s;
+}
+static int bn_bwd_apply_launch(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y, const float *mean,
+                               const float *var, float eps, const float *gamma, const float *sums, int64_t n_total, int64_t nv, int c, float *dy,
+                               int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2, hipStream_t s) {
+    if (dy_scale2) GP_CHECK_HIP(hipMemsetAsync(dy_scale2, 0, 8, s));
+    unsigned *bits = reinterpret_cast<unsigned *>(dy_scale2);
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = c % 4 == 0 && ld_dout % 4 == 0 && ld_y % 4 == 0 && ld_dy % 4 == 0 && (!act || ld_act % 4 == 0) && (!dz_out || ld_dz % 4 == 0) &&
+                     al16(dout) && al16(y) && al16(dy) && al16(act) && al16(dz_out);
+    const int64_t items = nv * (vec ? c / 4 : c);
+    const unsigned blocks = (unsigned)(items / 256 + 1 < 4096 ? items / 256 + 1 : 4096);
+    if (vec) bn_bwd_apply_kernel<4><<<blocks, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, bits);
+    else bn_bwd_apply_kernel<1><<<blocks, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, bits);
+    if (dy_scale2) bn_scale2_kernel<<<1, 1, 0, s>>>(dy_scale2);
+    return GP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ InfoNCE
@@ -276,6 +394,189 @@ knn_points_kernel(const float *__restrict__ xyz, int64_t n, const int64_t *__res
     for (int j = tid; j < k; j += 256) out[(int64_t)blockIdx.x * k + j] = ci[j + 1];     // column 0 (the point itself) dropped
 }
 
+
+// ------------------------------------------------------------------------------------------------ the sampler's selections
+// sample_contrastive_pairs_hybrid (affinity_module.py:1116-1124) on one row of the anchors x points similarity per workgroup:
+//   positive = arg-max over the points other than the anchor (ties: the lowest index);
+//   macro    = the k points of lowest similarity other than the anchor and the positive, ascending by (value, index)
+// -- torch.argmax + torch.topk(largest=False) of the reference, which on the device are a 4-pass radix select over the whole 2.4-GB
+// matrix plus a gather pass (4.7 ms at 4096 x 150k) and an arg-max sweep (0.5 ms).  Here:
+//   sweep 1 (HBM): every thread keeps the lowest key and the highest (key, -index) of the elements it reads.  The (k+1)-th lowest of the
+//     1024 thread minima is an upper bound B of the k-th lowest selectable element (k+1 distinct elements lie at or below it, at most one
+//     of them the positive), and on anything but adversarial data only ~2k elements of the row lie at or below it;
+//   sweep 2 (the row again, from L2): elements <= B are collected into LDS, ranked by counting, the k lowest written in order.
+//   If more than SR_CAP elements lie at or below B (massive ties, or the low values all in one thread's stride) the candidates are narrowed
+//     by a radix select over the 64-bit key (value | index) 12 bits at a time -- keys are unique, so it terminates with <= SR_CAP -- one
+//     sweep per level, then collected and ranked the same way.
+// Keys: the order-preserving uint image of a float (-0 counts as +0; a NaN with a clear sign bit orders above +inf, as in torch).
+constexpr int SR_NT = 1024, SR_CAP = 4096, SR_BINS = 4096;
+__device__ __forceinline__ unsigned sr_key(float v) {
+    unsigned u = __float_as_uint(v);
+    if (u == 0x80000000u) u = 0u;
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long sr_shfl_xor(unsigned long long v, int o) {
+    unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// f(index, value) over the n elements of a row; 16-byte loads where the row allows
+template <typename F>
+__device__ __forceinline__ void sr_sweep(const float *__restrict__ row, int n, bool vec, F f) {
+    if (vec) {
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x; i < n4; i += SR_NT) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + 4 * (int64_t)i);
+            f(4 * i, a.x); f(4 * i + 1, a.y); f(4 * i + 2, a.z); f(4 * i + 3, a.w);
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += SR_NT) f(i, row[i]);
+    } else {
+        for (int i = threadIdx.x; i < n; i += SR_NT) f(i, row[i]);
+    }
+}
+__global__ void __launch_bounds__(SR_NT)
+sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const int64_t *__restrict__ anchor, int k,
+                      int64_t *__restrict__ positive, int64_t *__restrict__ macro) {
+    __shared__ __align__(16) unsigned long long cand[SR_CAP];
+    __shared__ unsigned hist[SR_BINS];
+    __shared__ __align__(16) unsigned s_min[SR_NT];
+    __shared__ unsigned long long s_red[SR_NT / 64];
+    __shared__ unsigned s_bound;
+    __shared__ int s_cnt, s_pos, s_bin, s_acc, s_done;
+    const int tid = threadIdx.x;
+    const float *row = sim + (int64_t)blockIdx.x * ld;
+    const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sim) & 15) == 0);
+    const int anc = (int)anchor[blockIdx.x];
+    // ---- sweep 1
+    unsigned tmin = 0xffffffffu;
+    unsigned long long tmax = 0ull;
+    sr_sweep(row, n, vec, [&](int i, float v) {
+        if (i == anc) return;
+        const unsigned kx = sr_key(v);
+        tmin = kx < tmin ? kx : tmin;
+        const unsigned long long m = ((unsigned long long)kx << 32) | (unsigned)(0x7fffffff - i);
+        tmax = m > tmax ? m : tmax;
+    });
+    s_min[tid] = tmin;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = sr_shfl_xor(tmax, o); tmax = t > tmax ? t : tmax; }
+    if ((tid & 63) == 0) s_red[tid >> 6] = tmax;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long m = s_red[0];
+        for (int w = 1; w < SR_NT / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
+        s_pos = 0x7fffffff - (int)(unsigned)(m & 0xffffffffu);
+    }
+    {   // the thread whose minimum has rank k among the 1024 (ties by thread id) publishes the bound
+        int rank = 0;
+        for (int u = 0; u < SR_NT; u += 4) {
+            const uint4 m4 = *reinterpret_cast<const uint4 *>(&s_min[u]);
+            rank += (m4.x < tmin || (m4.x == tmin && u < tid)) + (m4.y < tmin || (m4.y == tmin && u + 1 < tid)) +
+                    (m4.z < tmin || (m4.z == tmin && u + 2 < tid)) + (m4.w < tmin || (m4.w == tmin && u + 3 < tid));
+        }
+        if (rank == k) s_bound = tmin;
+    }
+    __syncthreads();
+    const unsigned bound = s_bound;
+    const int pos = s_pos;
+    if (tid == 0) positive[blockIdx.x] = pos;
+    // ---- sweep 2: the elements at or below the bound
+    sr_sweep(row, n, vec, [&](int i, float v) {
+        const unsigned kx = sr_key(v);
+        if (kx <= bound && i != anc && i != pos) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < SR_CAP) cand[p] = ((unsigned long long)kx << 32) | (unsigned)i;
+        }
+    });
+    __syncthreads();
+    int cnt = s_cnt;
+    if (cnt > SR_CAP) {
+        // ---- the rare path: radix select on the 64-bit keys of the elements at or below the bound, 12 bits per sweep
+        unsigned long long prefix = 0ull;
+        int acc = 0, shift = 64;
+        for (int level = 0;; ++level) {
+            const int width = level < 5 ? 12 : 4;
+            shift -= width;
+            for (int i = tid; i < SR_BINS; i += SR_NT) hist[i] = 0u;
+            __syncthreads();
+            sr_sweep(row, n, vec, [&](int i, float v) {
+                const unsigned kx = sr_key(v);
+                if (kx <= bound && i != anc && i != pos) {
+                    const unsigned long long key = ((unsigned long long)kx << 32) | (unsigned)i;
+                    if (level == 0 || (key >> (shift + width)) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & ((1u << width) - 1u)], 1u);
+                }
+            });
+            __syncthreads();
+            if (tid == 0) {
+                const int need = k - acc;
+                int run = 0, t = 0;
+                for (; t < (1 << width) - 1; ++t) { if (run + (int)hist[t] >= need) break; run += (int)hist[t]; }
+                s_bin = t;
+                s_acc = acc + run;
+                s_done = (acc + run + (int)hist[t] <= SR_CAP);
+                s_cnt = 0;
+            }
+            __syncthreads();
+            prefix = (prefix << width) | (unsigned)s_bin;
+            acc = s_acc;
+            if (s_done) break;                            // the last level's bins hold one key each: acc + 1 <= k
+        }
+        sr_sweep(row, n, vec, [&](int i, float v) {
+            const unsigned kx = sr_key(v);
+            if (kx <= bound && i != anc && i != pos) {
+                const unsigned long long key = ((unsigned long long)kx << 32) | (unsigned)i;
+                if ((key >> shift) <= prefix) { const int p = atomicAdd(&s_cnt, 1); if (p < SR_CAP) cand[p] = key; }
+            }
+        });
+        __syncthreads();
+        cnt = s_cnt < SR_CAP ? s_cnt : SR_CAP;
+    }
+    // ---- rank by counting (keys are unique); the k lowest in order
+    for (int t = tid; t < cnt; t += SR_NT) {
+        const unsigned long long me = cand[t];
+        int rank = 0;
+        int u = 0;
+        for (; u + 2 <= cnt; u += 2) {
+            const ulonglong2 c2 = *reinterpret_cast<const ulonglong2 *>(&cand[u]);
+            rank += (c2.x < me) + (c2.y < me);
+        }
+        if (u < cnt) rank += cand[u] < me;
+        if (rank < k) macro[(int64_t)blockIdx.x * k + rank] = (int64_t)(unsigned)(me & 0xffffffffu);
+    }
+}
+
+// rows of x / max(|row|, eps) (F.normalize, affinity_module.py:1114) written as f16 hi/lo planes; rows n .. n_pad of the planes are zero
+// (the similarity GEMM's weight operand wants a multiple of 256 rows).  One wave per row, two sweeps of the row (the second from L1/L2).
+__global__ void __launch_bounds__(256)
+normalize_split_kernel(const float *__restrict__ x, int64_t ld_x, int d, int64_t n, int64_t n_pad, float eps, _Float16 *__restrict__ hi,
+                       _Float16 *__restrict__ lo, int64_t ld_h) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int lane = gp_lane();
+    for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; r < n_pad; r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        float inv = 0.f;
+        if (r < n) {
+            float ss = 0.f;
+            for (int c = lane * 4; c < d; c += 256) {
+                const float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+                ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            }
+            inv = fmaxf(sqrtf(gp_wave_sum(ss)), eps);
+        }
+        for (int c = lane * 4; c < d; c += 256) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < n) {
+                const float4 a = *reinterpret_cast<const float4 *>(x + r * ld_x + c);
+                v[0] = a.x / inv; v[1] = a.y / inv; v[2] = a.z / inv; v[3] = a.w / inv;
+            }
+            f16x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h[q] = (_Float16)v[q]; l[q] = (_Float16)(v[q] - (float)h[q]); }
+            *reinterpret_cast<f16x4 *>(hi + r * ld_h + c) = h;
+            *reinterpret_cast<f16x4 *>(lo + r * ld_h + c) = l;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t gp_col_stats_workspace_bytes(int64_t nv, int32_t c) {
@@ -283,7 +584,7 @@ extern "C" size_t gp_col_stats_workspace_bytes(int64_t nv, int32_t c) {
     return gp_align_up((size_t)nch * 2 * c * sizeof(double), 256);
 }
 
-// mean[c], var[c] (biased) of the rows of y: two passes (mean, then squared deviations), fp64 accumulation
+// mean[c], var[c] (biased) of the rows of y: one sweep, fp64 sums of x and x^2 in a fixed order, var = E[x^2] - mean^2 in fp64
 extern "C" int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, float *mean, float *var, void *workspace,
                             size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(y && mean && var && workspace && nv > 0 && c > 0, "gp_col_stats: null/empty argument");
@@ -292,29 +593,17 @@ extern "C" int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, f
     double *partial = static_cast<double *>(workspace);
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    cs_sum_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
-    cs_final_kernel<<<(c + 63) / 64, 256, 0, s>>>(partial, nch, 1, c, 1.0 / (double)nv, mean);
-    cs_var_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, mean, partial);
-    cs_final_kernel<<<(c + 63) / 64, 256, 0, s>>>(partial, nch, 1, c, 1.0 / (double)nv, var);
+    cs_sum2_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
+    cs_meanvar_final_kernel<<<(c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, c, 1.0 / (double)nv, mean, var);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
 
 // fp64 column sums for SyncBatchNorm (run/train.py:212-213 converts the student to MinkowskiSyncBatchNorm): the caller
 // all-reduces them over the ranks.  mean == NULL: out[col] = sum_r y[r][col]; else out[col] = sum_r (y[r][col] - mean[col])^2.
-__global__ void __launch_bounds__(256) cs_final_f64_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c,
-                                                           double *__restrict__ out) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (i < nq * c) {
-        const int q = i / c, col = i % c;
-        for (int64_t k = wv; k < nchunks; k += 4) s += partial[(k * nq + q) * c + col];
-    }
-    red[wv][lane] = s;
-    __syncthreads();
-    if (wv == 0 && i < nq * c) out[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+__global__ void __launch_bounds__(CF_WAVES * 64) cs_final_f64_kernel(const double *__restrict__ partial, int64_t nchunks, int nq, int c,
+                                                                     double *__restrict__ out) {
+    cs_final_body(partial, nchunks, nq, c, 1.0, out);
 }
 extern "C" int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, double *out, void *workspace,
                                size_t workspace_bytes, void *stream_) {
@@ -326,7 +615,7 @@ extern "C" int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
     if (mean) cs_var_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, mean, partial);
     else cs_sum_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
-    cs_final_f64_kernel<<<(c + 63) / 64, 256, 0, s>>>(partial, nch, 1, c, out);
+    cs_final_f64_kernel<<<(c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 1, c, out);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -341,18 +630,18 @@ extern "C" int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const floa
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
     bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
-    cs_final_f64_kernel<<<(2 * c + 63) / 64, 256, 0, s>>>(partial, nch, 2, c, sums);
+    cs_final_f64_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, sums);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
 // dy = gamma/sqrt(var+eps) * (dz - sums[col]/n_total - xhat * sums[c+col]/n_total) with caller-supplied (all-reduced) sums
 extern "C" int gp_bn_bwd_apply(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
                                const float *mean, const float *var, float eps, const float *gamma, const float *sums, int64_t n_total,
-                               int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, void *stream_) {
+                               int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2, void *stream_) {
     GP_CHECK_ARG(dout && y && mean && var && gamma && sums && dy && nv > 0 && c > 0 && n_total >= nv, "gp_bn_bwd_apply: bad argument");
-    int64_t n = nv * c;
-    bn_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, gp_stream(stream_)>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma,
-                                                                                      sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz);
+    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2,
+                                 gp_stream(stream_));
+    if (rc != GP_OK) return rc;
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -365,9 +654,15 @@ extern "C" int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t
     GP_CHECK_ARG(y && mean && var && gamma && beta && out && nv > 0 && c > 0, "gp_bn_train_apply: null/empty argument");
     GP_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr), "gp_bn_train_apply: split outputs come as a pair");
     hipStream_t s = gp_stream(stream_);
-    int64_t n = nv * c;
-    bn_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(y, ld, nv, c, mean, var, gamma, beta, eps, residual, ld_res, relu, out, ld_out,
-                                                                 static_cast<_Float16 *>(out_hi), static_cast<_Float16 *>(out_lo), ld_split);
+    auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    const bool vec = c % 4 == 0 && ld % 4 == 0 && ld_out % 4 == 0 && (!residual || ld_res % 4 == 0) && (!out_hi || ld_split % 4 == 0) && al(y, 16) &&
+                     al(out, 16) && al(residual, 16) && al(out_hi, 8) && al(out_lo, 8);
+    const int64_t items = nv * (vec ? c / 4 : c);
+    const unsigned blocks = (unsigned)(items / 256 + 1 < 4096 ? items / 256 + 1 : 4096);
+    if (vec) bn_apply_kernel<4><<<blocks, 256, 0, s>>>(y, ld, nv, c, mean, var, gamma, beta, eps, residual, ld_res, relu, out, ld_out,
+                                                     static_cast<_Float16 *>(out_hi), static_cast<_Float16 *>(out_lo), ld_split);
+    else bn_apply_kernel<1><<<blocks, 256, 0, s>>>(y, ld, nv, c, mean, var, gamma, beta, eps, residual, ld_res, relu, out, ld_out,
+                                                 static_cast<_Float16 *>(out_hi), static_cast<_Float16 *>(out_lo), ld_split);
     if (running_mean && running_var)
         bn_running_kernel<<<(c + 255) / 256, 256, 0, s>>>(mean, var, c, nv, momentum, running_mean, running_var);
     GP_CHECK_LAUNCH();
@@ -378,7 +673,7 @@ extern "C" int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t
 // dy = gamma/sqrt(var+eps) * (dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) receives dz (identity branch)
 extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
                                     const float *mean, const float *var, float eps, const float *gamma, int64_t nv, int32_t c,
-                                    float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dgamma, float *dbeta,
+                                    float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dgamma, float *dbeta, float *dy_scale2,
                                     void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(dout && y && mean && var && gamma && dy && dgamma && dbeta && workspace && nv > 0 && c > 0,
                  "gp_bn_train_backward: null/empty argument");
@@ -390,10 +685,9 @@ extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const fl
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
     bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
-    cs_final_kernel<<<(2 * c + 63) / 64, 256, 0, s>>>(partial, nch, 2, c, 1.0, sums);
-    int64_t n = nv * c;
-    bn_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, nv, nv, c,
-                                                                     dy, ld_dy, dz_out, ld_dz);
+    cs_final_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, 1.0, sums);
+    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, nv, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2, s);
+    if (rc != GP_OK) return rc;
     GP_CHECK_HIP(hipMemcpyAsync(dbeta, sums, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));
     GP_CHECK_HIP(hipMemcpyAsync(dgamma, sums + c, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));
     GP_CHECK_LAUNCH();
@@ -451,6 +745,30 @@ extern "C" int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *que
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int32_t), s));
     knn_points_kernel<<<(unsigned)num_queries, 256, 0, s>>>(xyz, n, queries, k, out, flag_dev);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// positive i64 [A], macro i64 [A, k] of the rows of sim fp32 [A, >= n] (leading dimension ld): see sampler_select_kernel
+extern "C" int gp_sampler_select(const float *sim, int64_t ld, int64_t num_anchors, int64_t n, const int64_t *anchor_idx, int32_t k,
+                                 int64_t *positive, int64_t *macro, void *stream_) {
+    GP_CHECK_ARG(sim && anchor_idx && positive && macro && num_anchors > 0 && ld >= n, "gp_sampler_select: null/empty argument");
+    GP_CHECK_ARG(k >= 1 && k < SR_NT && k <= SR_CAP && n >= (int64_t)k + 2 && n < 0x7fffffff, "gp_sampler_select: k=%d, n=%lld out of range (1 <= k < %d, n >= k + 2)",
+                 k, (long long)n, SR_NT);
+    sampler_select_kernel<<<(unsigned)num_anchors, SR_NT, 0, gp_stream(stream_)>>>(sim, ld, (int)n, anchor_idx, k, positive, macro);
+    GP_CHECK_LAUNCH();
+    return GP_OK;
+}
+
+// hi + lo = x[r] / max(|x[r]|_2, eps) for r < n, zero rows for n <= r < n_pad
+extern "C" int gp_normalize_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, int64_t n_pad, float eps, void *hi, void *lo,
+                                      int64_t ld_h, void *stream_) {
+    GP_CHECK_ARG(x && hi && lo && n > 0 && n_pad >= n && d > 0 && d % 4 == 0 && ld_x % 4 == 0 && ld_h % 4 == 0 && ld_h >= d,
+                 "gp_normalize_split_f16: bad argument");
+    GP_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "gp_normalize_split_f16: x must be 16-byte aligned");
+    const int64_t waves = n_pad < 16384 ? n_pad : 16384;
+    normalize_split_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, gp_stream(stream_)>>>(x, ld_x, d, n, n_pad, eps, static_cast<_Float16 *>(hi),
+                                                                                       static_cast<_Float16 *>(lo), ld_h);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

@@ -313,19 +313,28 @@ def conv_pairs_build(nbr_map, chunk_rows="balanced", col_tiles=2):
     return cp
 
 
-def conv_weights_split(w, scale_pow2, blocked=None):
+def conv_weights_split(w, scale_pow2, blocked=None, transpose_flip=False):
     """w fp32 [kv,cin,cout] -> (w_hi, w_lo) f16 of scale_pow2*w.
     blocked (default: whenever the shape allows, cin % 32 == 0 and cout % 256 == 0): the step-blocked layout of the two-phase
     convolution, tensors of shape [kv, cout/256, cin/32, 256, 32] -- sparse_conv_f16x3 recognises it by its five dimensions;
-    else [kv,cout,cin] (the dense output layer's operand, gp_embed_head_f16x3; also accepted by sparse_conv_f16x3)."""
+    else [kv,cout,cin] (the dense output layer's operand, gp_embed_head_f16x3; also accepted by sparse_conv_f16x3).
+    transpose_flip: the halves of V[k] = w[kv-1-k]^T (the data-gradient operand; V's cin = w's cout and vice versa) straight from w."""
     lib = _lib.load()
     kv, cin, cout = w.shape
+    if transpose_flip:
+        if cout % 32 == 0 and cin % 256 == 0 and blocked is not False:
+            hi = torch.empty((kv, cin // 256, cout // 32, 256, 32), dtype=torch.float16, device=w.device)
+            lo = torch.empty_like(hi)
+            check(lib.gp_conv_weights_split_blocked(_ptr(w), kv, cout, cin, float(scale_pow2), _ptr(hi), _ptr(lo), 1, _stream()),
+                  "gp_conv_weights_split_blocked")
+            return hi, lo
+        return conv_weights_split(w.flip(0).transpose(1, 2).contiguous(), scale_pow2, blocked)
     if blocked is None:
         blocked = cin % 32 == 0 and cout % 256 == 0
     if blocked:
         hi = torch.empty((kv, cout // 256, cin // 32, 256, 32), dtype=torch.float16, device=w.device)
         lo = torch.empty_like(hi)
-        check(lib.gp_conv_weights_split_blocked(_ptr(w), kv, cin, cout, float(scale_pow2), _ptr(hi), _ptr(lo), _stream()),
+        check(lib.gp_conv_weights_split_blocked(_ptr(w), kv, cin, cout, float(scale_pow2), _ptr(hi), _ptr(lo), 0, _stream()),
               "gp_conv_weights_split_blocked")
         return hi, lo
     hi = torch.empty((kv, cout, cin), dtype=torch.float16, device=w.device)
@@ -342,11 +351,12 @@ def conv_weights_shape(w_hi):
     return tuple(int(v) for v in w_hi.shape)
 
 
-def split_f16(x, d=None, scale=None, per_row=False, interleaved=False, dst_row=None):
+def split_f16(x, d=None, scale=None, per_row=False, interleaved=False, dst_row=None, extra_zero_rows=0):
     """fp32 rows -> (hi, lo) f16 rows with x * s = hi + lo.  Unscaled (s = 1): exact to 2^-22 relative only for |x| >= 2^-3
     (below that the lo half is a subnormal f16: absolute error 2^-25).  scale = device scalar from pow2_scale(): one power of
     two for the whole block; per_row=True: a power of two per row, returns (hi, lo, row_inv_scale).
-    dst_row (i32 [n], a permutation; scaled forms only): row r is written to row dst_row[r] of the outputs (rcb_order's map)."""
+    dst_row (i32 [n], a permutation; scaled forms only): row r is written to row dst_row[r] of the outputs (rcb_order's map).
+    extra_zero_rows (plane forms): that many all-zero rows behind the n rows of hi and lo (the weight gradient's padded pairs point there)."""
     lib = _lib.load()
     d = x.shape[1] if d is None else d
     if interleaved:
@@ -357,8 +367,11 @@ def split_f16(x, d=None, scale=None, per_row=False, interleaved=False, dst_row=N
         check(lib.gp_split_f16_scaled(_ptr(x), x.stride(0), int(d), x.shape[0], _ptr(rows), None, rows.stride(0), None, _ptr(rinv),
                                       _ptr(dst_row), _stream()), "gp_split_f16_scaled")
         return rows, None, rinv
-    hi = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
-    lo = torch.empty((x.shape[0], d), dtype=torch.float16, device=x.device)
+    hi = torch.empty((x.shape[0] + extra_zero_rows, d), dtype=torch.float16, device=x.device)
+    lo = torch.empty((x.shape[0] + extra_zero_rows, d), dtype=torch.float16, device=x.device)
+    if extra_zero_rows:
+        hi[x.shape[0]:].zero_()
+        lo[x.shape[0]:].zero_()
     if scale is None and not per_row:
         if dst_row is not None:
             raise ValueError("split_f16: dst_row needs a scaled form (scale= or per_row=True)")
@@ -1052,15 +1065,16 @@ def bn_bwd_sums_f64(dout, act, y, mean, var, eps):
     return sums
 
 
-def bn_bwd_apply(dout, act, y, mean, var, eps, gamma, sums_f32, n_total, want_dz=False):
-    """dy (and dz) of the BatchNorm backward pass from reduction vectors taken over n_total rows (all ranks)."""
+def bn_bwd_apply(dout, act, y, mean, var, eps, gamma, sums_f32, n_total, want_dz=False, dy_scale2=None):
+    """dy (and dz) of the BatchNorm backward pass from reduction vectors taken over n_total rows (all ranks).
+    dy_scale2 (fp32 [2] device tensor): receives pow2_scale(dy) from the same sweep."""
     lib = _lib.load()
     nv, c = y.shape[0], mean.shape[0]
     dy = torch.empty((nv, c), dtype=torch.float32, device=y.device)
     dz = torch.empty((nv, c), dtype=torch.float32, device=y.device) if want_dz else None
     check(lib.gp_bn_bwd_apply(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y), y.stride(0),
                               _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(sums_f32), int(n_total), nv, int(c), _ptr(dy), dy.stride(0),
-                              _ptr(dz), dz.stride(0) if dz is not None else 0, _stream()), "gp_bn_bwd_apply")
+                              _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dy_scale2), _stream()), "gp_bn_bwd_apply")
     return (dy, dz) if want_dz else dy
 
 
@@ -1080,8 +1094,9 @@ def bn_train_apply(y, mean, var, gamma, beta, eps, residual=None, relu=True, wan
     return out, ((hi, lo) if want_split else None)
 
 
-def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False):
-    """Returns dy, dgamma, dbeta (, dz).  act: post-ReLU activation (mask) or None."""
+def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False, dy_scale2=None):
+    """Returns dy, dgamma, dbeta (, dz).  act: post-ReLU activation (mask) or None.
+    dy_scale2 (fp32 [2] device tensor): receives pow2_scale(dy) from the sweep that writes dy."""
     lib = _lib.load()
     nv, c = y.shape[0], mean.shape[0]
     dev = y.device
@@ -1092,8 +1107,8 @@ def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False):
     ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c) + 2 * c * 4 + 512, dev)
     check(lib.gp_bn_train_backward(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y),
                                    y.stride(0), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), nv, int(c), _ptr(dy), dy.stride(0),
-                                   _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(),
-                                   _stream()), "gp_bn_train_backward")
+                                   _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dgamma), _ptr(dbeta), _ptr(dy_scale2), _ptr(ws),
+                                   ws.numel(), _stream()), "gp_bn_train_backward")
     return (dy, dgamma, dbeta, dz) if want_dz else (dy, dgamma, dbeta)
 
 
@@ -1136,6 +1151,32 @@ def knn_points(xyz, queries, k):
     return out, flag
 
 
+def sampler_select(sim, anchor_indices, k, n=None):
+    """positive i64 [A], macro i64 [A, k] of sim fp32 [A, >= n] (gp_sampler_select): the arg-max over the points other than the anchor
+    and the k lowest other than anchor and positive, ascending by (value, index).  sim is not written."""
+    lib = _lib.load()
+    A = sim.shape[0]
+    n = sim.shape[1] if n is None else n
+    assert sim.stride(1) == 1 and anchor_indices.dtype == torch.int64 and anchor_indices.is_contiguous()
+    positive = torch.empty(A, dtype=torch.int64, device=sim.device)
+    macro = torch.empty((A, k), dtype=torch.int64, device=sim.device)
+    check(lib.gp_sampler_select(_ptr(sim), sim.stride(0), A, int(n), _ptr(anchor_indices), int(k), _ptr(positive), _ptr(macro), _stream()),
+          "gp_sampler_select")
+    return positive, macro
+
+
+def normalize_split_f16(x, n_pad=None, eps=1e-12):
+    """(hi, lo) f16 [n_pad, d] of F.normalize(x, dim=1); rows beyond x's are zero (gp_normalize_split_f16)."""
+    lib = _lib.load()
+    n, d = x.shape
+    n_pad = n if n_pad is None else n_pad
+    hi = torch.empty((n_pad, d), dtype=torch.float16, device=x.device)
+    lo = torch.empty((n_pad, d), dtype=torch.float16, device=x.device)
+    check(lib.gp_normalize_split_f16(_ptr(x), x.stride(0), int(d), n, int(n_pad), float(eps), _ptr(hi), _ptr(lo), hi.stride(0), _stream()),
+          "gp_normalize_split_f16")
+    return hi, lo
+
+
 class WgradPlan:
     """Pair lists of one voxel set in the layout of gp_conv_wgrad_f16x3 (shared by every 3x3x3 layer of a step)."""
 
@@ -1164,6 +1205,43 @@ def wgrad_plan_build(offset_pairs, nv, steps_per_segment=128):
         step0 += steps
     return WgradPlan(torch.cat(pin).contiguous(), torch.cat(pout).contiguous(),
                      torch.tensor(segs, dtype=torch.int32, device=dev).contiguous(),
+                     torch.tensor(seg_off, dtype=torch.int32, device=dev), len(segs), nv)
+
+
+def kernel_map_pairs(nbr_map):
+    """The (output row, input row) pairs of every kernel offset of nbr_map i32 [kv, nv] in offset-major, row-ascending order:
+    (offset i64 [P], out_rows i64 [P], in_rows i64 [P], counts: host list of kv ints).  Two host syncs for the whole map (a per-offset
+    torch.nonzero costs one each: 27 syncs with the GPU idle at the head of every training step)."""
+    kv, nv = nbr_map.shape
+    kk, rr = torch.nonzero(nbr_map >= 0, as_tuple=True)
+    counts = readback(torch.bincount(kk, minlength=kv))
+    in_rows = nbr_map.reshape(-1)[kk * nv + rr].long()
+    return kk, rr, in_rows, [int(c) for c in counts]
+
+
+def wgrad_plan_from_pairs(kk, out_rows, in_rows, counts, nv, steps_per_segment=128):
+    """wgrad_plan_build for the pair arrays of kernel_map_pairs: same layout (every offset padded to a multiple of 32 pairs with
+    (in 0, out nv)), built with a handful of device operations instead of four per offset."""
+    dev = out_rows.device
+    shift, segs, seg_off = [], [], [0]
+    base = cum = step0 = 0
+    for k, n in enumerate(counts):
+        pad = (-n) % 32
+        shift.append(base - cum)
+        steps = (n + pad) // 32
+        for s in range(0, steps, steps_per_segment):
+            segs.append((k, step0 + s, min(steps_per_segment, steps - s), 0))
+        seg_off.append(len(segs))
+        step0 += steps
+        base += n + pad
+        cum += n
+    pin = torch.zeros(max(base, 1), dtype=torch.int32, device=dev)
+    pout = torch.full((max(base, 1),), nv, dtype=torch.int32, device=dev)
+    if cum:
+        dest = torch.arange(cum, device=dev) + torch.tensor(shift, dtype=torch.int64, device=dev)[kk]
+        pin[dest] = in_rows.to(torch.int32)
+        pout[dest] = out_rows.to(torch.int32)
+    return WgradPlan(pin, pout, torch.tensor(segs, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous(),
                      torch.tensor(seg_off, dtype=torch.int32, device=dev), len(segs), nv)
 
 

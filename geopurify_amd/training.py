@@ -44,20 +44,18 @@ def lr_schedule(step_index, base_lr, group, warmup_iters, main_iters):
     return eta_min + (lr0 - eta_min) * 0.5 * (1.0 + math.cos(math.pi * t / max(main_iters, 1)))
 
 
-def _anchor_similarities(Fn, anchor_indices):
-    """sim[a, p] = <Fn[anchor_a], Fn[p]> (einsum('ad,pd->ap'), affinity_module.py:1115).  On the device with a feature
-    width that is a multiple of 32 this is the gather-GEMM of the convolution operator with ONE offset: the anchors are
-    the gathered rows, the points play the output channels (weights are stored [cout][cin] = [point][feature]), f16
-    hi/lo operands with fp32 accumulation (fp32-class, 2.5x the rate of the library fp32 GEMM).  Otherwise torch.matmul."""
-    N, Dt = Fn.shape
-    if not (Fn.is_cuda and Dt % 32 == 0 and N >= 256):
+def _anchor_similarities(F_teacher, anchor_indices):
+    """sim[a, p] = <Fn[anchor_a], Fn[p]> with Fn = F.normalize(F_teacher) (affinity_module.py:1114-1115).  On the device with a feature
+    width that is a multiple of 32 this is the gather-GEMM of the convolution operator with ONE offset: the anchors are the gathered
+    rows, the points play the output channels (weights are stored [cout][cin] = [point][feature]), f16 hi/lo operands with fp32
+    accumulation (fp32-class, 2.5x the rate of the library fp32 GEMM); the normalisation, the split and the padding of the point rows
+    to a multiple of 256 are one sweep (gp_normalize_split_f16).  Otherwise torch.  Returns sim [A, N] (a view of [A, Np])."""
+    N, Dt = F_teacher.shape
+    if not (F_teacher.is_cuda and Dt % 32 == 0 and N >= 256):
+        Fn = torch.nn.functional.normalize(F_teacher, p=2, dim=1)
         return Fn[anchor_indices] @ Fn.t()
     Np = (N + 255) // 256 * 256
-    Fp = Fn
-    if Np != N:
-        Fp = torch.zeros((Np, Dt), dtype=torch.float32, device=Fn.device)
-        Fp[:N] = Fn
-    hi, lo = ops.split_f16(Fp)
+    hi, lo = ops.normalize_split_f16(F_teacher.contiguous(), Np)
     pairs = ops.conv_pairs_build(anchor_indices.to(torch.int32).view(1, -1).contiguous(), chunk_rows=None)      # one gather-GEMM, one chunk
     sim = ops.sparse_conv_f16x3(None, pairs, hi.view(1, Np, Dt), lo.view(1, Np, Dt), None, None, relu=False, x_split=(hi, lo))
     return sim[:, :N]
@@ -66,16 +64,22 @@ def _anchor_similarities(Fn, anchor_indices):
 # --------------------------------------------------------------------------------------------------
 def sample_contrastive_pairs_hybrid(F_teacher, neighbor_indices, anchor_indices, num_negatives):
     """affinity_module.py:1113-1136 after the randperm (anchors are the caller's draw).  neighbor_indices i64 [A,K]
-    are the anchors' rows of the point kNN.  Returns positive [A], negative [A, num_negatives]."""
-    Fn = torch.nn.functional.normalize(F_teacher, p=2, dim=1)
-    sim = _anchor_similarities(Fn, anchor_indices)
+    are the anchors' rows of the point kNN.  Returns positive [A], negative [A, num_negatives].
+    On the device the arg-max and the 48 global negatives of a row come from one kernel (gp_sampler_select: two sweeps of the row instead
+    of torch's arg-max sweep + 4-pass radix select + gather); the 15 local ones are torch.topk over the 96 neighbours."""
+    sim = _anchor_similarities(F_teacher, anchor_indices)
     A, N = sim.shape
     rows = torch.arange(A, device=sim.device)
-    sim[rows, anchor_indices] = float("-inf")         # the reference clones the [A,N] matrix for this; marking in place is the same
-    positive = torch.argmax(sim, dim=1)
-    sim[rows, anchor_indices] = float("inf")          # in place, as the reference (sim_matrix_neg aliases the matrix)
-    sim[rows, positive] = float("inf")
-    _, macro = torch.topk(sim, k=N_MACRO, largest=False, dim=1)
+    if sim.is_cuda and N >= N_MACRO + 2:
+        positive, macro = ops.sampler_select(sim, anchor_indices.contiguous(), N_MACRO, n=N)
+        sim[rows, anchor_indices] = float("inf")
+        sim[rows, positive] = float("inf")
+    else:
+        sim[rows, anchor_indices] = float("-inf")         # the reference clones the [A,N] matrix for this; marking in place is the same
+        positive = torch.argmax(sim, dim=1)
+        sim[rows, anchor_indices] = float("inf")          # in place, as the reference (sim_matrix_neg aliases the matrix)
+        sim[rows, positive] = float("inf")
+        _, macro = torch.topk(sim, k=N_MACRO, largest=False, dim=1)
     sims_local = torch.gather(sim, 1, neighbor_indices)
     _, hardest = torch.topk(sims_local, k=num_negatives - N_MACRO, largest=False, dim=1)
     micro = torch.gather(neighbor_indices, 1, hardest)
@@ -135,34 +139,32 @@ class StudentTrainer:
             return ops.sparse_conv_f16x3(x, ctx["pairs"], hi, lo, scale, None, relu=False, x_split=x_split)
         return ops.sparse_conv(x, ctx["nbr_map"], w)
 
-    def _grad_split(self, dy):
-        """dY scaled by a power of two (device scalar, no host sync) so that 1e-6-sized gradients are normal f16
-        numbers, split into hi/lo with one extra all-zero row (the target of the padded pairs of the weight gradient).
-        Returns (scaled fp32 rows, (hi, lo) [nv+1, c], 1/scale as a 1-element device tensor)."""
-        nv, c = dy.shape
-        amax = dy.abs().amax().clamp_min(1e-30)
-        s = torch.exp2(torch.floor(torch.log2(1.0 / amax)))
-        dys = torch.zeros((nv + 1, c), dtype=torch.float32, device=dy.device)
-        dys[:nv] = dy * s
-        return dys, ops.split_f16(dys), (1.0 / s).reshape(1).contiguous()
+    def _grad_split(self, dy, scale2=None):
+        """dY * s split into f16 hi/lo with one extra all-zero row (the target of the padded pairs of the weight gradient); s = the
+        power of two of gp_pow2_scale (max |dY| * s in [2^13, 2^14): 1e-6-sized gradients become normal f16 numbers), a device scalar --
+        no host sync.  scale2 = [s, 1/s] when the producer of dY took it in its own sweep (bn_train_backward(dy_scale2=)), else one
+        amax pass here.  Returns ((hi, lo) [nv+1, c], 1/s as a 1-element device tensor)."""
+        if scale2 is None:
+            scale2 = ops.pow2_scale(dy)
+        return ops.split_f16(dy, scale=scale2[0:1], extra_zero_rows=1), scale2[1:2]
 
-    def _dgrad(self, dy, w, ctx, gs=None):
-        """dx = sum_k dy[nbr_k] @ w[26-k]^T."""
-        v = w.flip(0).transpose(1, 2).contiguous()
-        if self.fast and v.shape[2] % 256 == 0:
-            dys, (hi_y, lo_y), inv_s = gs if gs is not None else self._grad_split(dy)
+    def _dgrad(self, dy, w, ctx, gs=None, residual=None):
+        """dx = sum_k dy[nbr_k] @ w[26-k]^T (+ residual: the identity branch's gradient, added in the operator's output pass)."""
+        if self.fast and w.shape[1] % 256 == 0:
+            (hi_y, lo_y), inv_s = gs if gs is not None else self._grad_split(dy)
             nv = dy.shape[0]
-            hi, lo = ops.conv_weights_split(v, W_POW2)
-            scale = (ctx["inv_pow2"][v.shape[2]] * inv_s).contiguous()
-            return ops.sparse_conv_f16x3(dys[:nv], ctx["pairs"], hi, lo, scale, None, relu=False, x_split=(hi_y[:nv], lo_y[:nv]))
-        return ops.sparse_conv(dy, ctx["nbr_map"], v)
+            hi, lo = ops.conv_weights_split(w, W_POW2, transpose_flip=True)
+            scale = (ctx["inv_pow2"][w.shape[1]] * inv_s).contiguous()
+            return ops.sparse_conv_f16x3(None, ctx["pairs"], hi, lo, scale, None, residual=residual, relu=False, x_split=(hi_y[:nv], lo_y[:nv]))
+        dx = ops.sparse_conv(dy, ctx["nbr_map"], w.flip(0).transpose(1, 2).contiguous())
+        return dx if residual is None else dx + residual
 
     def _wgrad(self, x, x_split, dy, ctx, cin, gs=None):
         """dW[k] = x[in_k]^T @ dy[out_k]: matrix-core kernel (gp_conv_wgrad_f16x3) when the shapes allow (cin >= 256,
         cout a multiple of 256), else library GEMMs on gathered rows."""
         cout = dy.shape[1]
         if self.fast and x_split is not None and cin >= 256 and cout % 256 == 0:
-            _, ysplit, inv_s = gs if gs is not None else self._grad_split(dy)
+            ysplit, inv_s = gs if gs is not None else self._grad_split(dy)
             return ops.conv_wgrad_f16x3(x_split, ysplit, ctx["wgrad_plan"], cin, cin, cout, inv_scale=inv_s)
         dw = torch.zeros((27, cin, cout), dtype=torch.float32, device=dy.device)
         for k, (out_rows, in_rows) in enumerate(ctx["offset_pairs"]):
@@ -179,12 +181,20 @@ class StudentTrainer:
         Nv = X.shape[0]
         ctx = {"nbr_map": nbr_map, "pairs": ops.conv_pairs_build(nbr_map, col_tiles=max(1, self.hidden // 256)) if self.fast else None,
                "inv_pow2": {c: torch.full((c,), 1.0 / W_POW2, dtype=torch.float32, device=dev) for c in {self.hidden}}}
-        ctx["offset_pairs"] = []
-        for k in range(27):
-            m = nbr_map[k]
-            out_rows = torch.nonzero(m >= 0).squeeze(1)
-            ctx["offset_pairs"].append((out_rows, m[out_rows].long()))
-        ctx["wgrad_plan"] = ops.wgrad_plan_build(ctx["offset_pairs"], Nv) if self.fast else None
+        if nbr_map.is_cuda:
+            kk, rr, rin, counts = ops.kernel_map_pairs(nbr_map)
+            offs = [0]
+            for n in counts:
+                offs.append(offs[-1] + n)
+            ctx["offset_pairs"] = [(rr[offs[k]:offs[k + 1]], rin[offs[k]:offs[k + 1]]) for k in range(len(counts))]
+            ctx["wgrad_plan"] = ops.wgrad_plan_from_pairs(kk, rr, rin, counts, Nv) if self.fast else None
+        else:
+            ctx["offset_pairs"] = []
+            for k in range(27):
+                m = nbr_map[k]
+                out_rows = torch.nonzero(m >= 0).squeeze(1)
+                ctx["offset_pairs"].append((out_rows, m[out_rows].long()))
+            ctx["wgrad_plan"] = None
         mom = self.bn_momentum
         n_all = sharding.sync_row_count(Nv, dev, self.group) if self.sync_bn else Nv       # one count per step, not one per layer
 
@@ -205,14 +215,16 @@ class StudentTrainer:
             return out, sp, (mean, var)
 
         def bn_bwd(dout, act, y, st, gamma, want_dz=False):
-            """(dy, dgamma, dbeta[, dz]); with SyncBatchNorm the dy formula uses the reductions over all ranks"""
+            """(dy, dgamma, dbeta, dz | None, scale2 of dy | None); with SyncBatchNorm the dy formula uses the reductions over all ranks"""
+            sc2 = torch.empty(2, dtype=torch.float32, device=dev) if self.fast else None
             if self.sync_bn:
                 c = st[0].shape[0]
                 g_sums, l_sums = sharding.sync_bwd_sums(ops.bn_bwd_sums_f64(dout, act, y, st[0], st[1], self.bn_eps), self.group)
-                r = ops.bn_bwd_apply(dout, act, y, st[0], st[1], self.bn_eps, gamma, g_sums, st[2], want_dz=want_dz)
+                r = ops.bn_bwd_apply(dout, act, y, st[0], st[1], self.bn_eps, gamma, g_sums, st[2], want_dz=want_dz, dy_scale2=sc2)
                 dy, dz = r if want_dz else (r, None)
-                return (dy, l_sums[c:].clone(), l_sums[:c].clone(), dz) if want_dz else (dy, l_sums[c:].clone(), l_sums[:c].clone())
-            return ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz)
+                return dy, l_sums[c:].clone(), l_sums[:c].clone(), dz, sc2
+            r = ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz, dy_scale2=sc2)
+            return r[0], r[1], r[2], (r[3] if want_dz else None), sc2
 
         # ---------------- forward (activations kept for the backward pass)
         saved = []
@@ -245,7 +257,7 @@ class StudentTrainer:
                     self._ident_plans.pop(next(iter(self._ident_plans)))
             dEp = torch.zeros((Nv, 256), dtype=torch.float32, device=dev)
             dEp[:, :Wo.shape[1]] = dE
-            _, ysplit, inv_s = self._grad_split(dEp)
+            ysplit, inv_s = self._grad_split(dEp)
             g["output_layer.kernel"] = ops.conv_wgrad_f16x3(hs, ysplit, plan, Wo.shape[0], Wo.shape[0], 256, inv_scale=inv_s)[0, :, :Wo.shape[1]].contiguous()
             dh = ops.sparse_conv(dE.contiguous(), None, Wo.t().contiguous().unsqueeze(0))
         else:
@@ -253,20 +265,20 @@ class StudentTrainer:
             dh = dE @ Wo.t()
         for i in reversed(range(self.num_blocks)):
             h_in, y1, a1, st1, y2, st2, h_out, h_in_s, a1_s = blocks[i]
-            dy2, dg2, db2, dz = bn_bwd(dh, h_out, y2, st2, P[f"res_blocks.{i}.norm2.bn.weight"], want_dz=True)
+            dy2, dg2, db2, dz, sc2 = bn_bwd(dh, h_out, y2, st2, P[f"res_blocks.{i}.norm2.bn.weight"], want_dz=True)
             g[f"res_blocks.{i}.norm2.bn.weight"], g[f"res_blocks.{i}.norm2.bn.bias"] = dg2, db2
-            gs2 = self._grad_split(dy2) if self.fast else None
+            gs2 = self._grad_split(dy2, sc2) if self.fast else None
             g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, a1_s, dy2, ctx, self.hidden, gs2)
             da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx, gs2)
-            dy1, dg1, db1 = bn_bwd(da1, a1, y1, st1, P[f"res_blocks.{i}.norm1.bn.weight"])
+            dy1, dg1, db1, _, sc1 = bn_bwd(da1, a1, y1, st1, P[f"res_blocks.{i}.norm1.bn.weight"])
             g[f"res_blocks.{i}.norm1.bn.weight"], g[f"res_blocks.{i}.norm1.bn.bias"] = dg1, db1
-            gs1 = self._grad_split(dy1) if self.fast else None
+            gs1 = self._grad_split(dy1, sc1) if self.fast else None
             g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1)
-            dh = dz + self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1)
+            dh = self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1, residual=dz)
         h0 = blocks[0][0] if self.num_blocks else h
-        dy0, dg0, db0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"])
+        dy0, dg0, db0, _, sc0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"])
         g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
-        g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad)
+        g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad, self._grad_split(dy0, sc0) if self.fast else None)
         return loss, g, E
 
     # ---- optimizer ---------------------------------------------------------------------------------------

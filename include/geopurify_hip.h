@@ -189,8 +189,10 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
 /* w_blocked = 1: w_hi / w_lo come from gp_conv_weights_split_blocked -- the same halves as [kv][cout / 256][cin / 32][256][32]: a K   */
 /* step's 16 KiB of a column tile contiguous (one 1-KiB run per LDS-DMA instruction instead of 16 half lines), row rho of a tile =     */
 /* its column (rho & 128) | (rho & 15) << 3 | (rho >> 4 & 7).  cin % 32 == 0, cout % 256 == 0.  0: the [kv][cout][cin] halves above.    */
+/* transpose_flip = 1: the data-gradient operand V[k] = W[kv - 1 - k]^T straight from the forward layer's w: cin / cout are V's (the      */
+/* forward layer's cout / cin), w is read as [kv][cout][cin] with the offsets mirrored -- no flipped, transposed fp32 copy in between.  */
 int gp_conv_weights_split_blocked(const float *w, int32_t kv, int32_t cin, int32_t cout, float scale_pow2,
-                                  void *w_hi, void *w_lo, void *stream);
+                                  void *w_hi, void *w_lo, int32_t transpose_flip, void *stream);
 /* res_hi / res_lo f16 [nv, ld_rh] (+ res_row_inv_scale fp32 [nv] or NULL): the residual as the split planes an earlier layer wrote  */
 /* (its y_hi / y_lo / y_row_inv_scale) instead of fp32 rows -- (hi + lo) * inv, the value that layer's consumer multiplied with; the    */
 /* producer then needs no fp32 copy (y = NULL).  `residual` and res_hi exclude each other.                                             */
@@ -496,7 +498,9 @@ int gp_iou_hist_i64(const int64_t *pred, const int64_t *target, int64_t n, int32
 /* training step of the student (models/affinity_module.py:1138-1237,                */
 /* run/train.py:188-198,346-353).  Convolutions forward / dgrad reuse gp_sparse_conv_f16x3 (dgrad   */
 /* = the same operator with weights V[k] = W[26-k]^T); these are the remaining pieces.              */
-/* gp_col_stats: mean / biased variance of the rows (BatchNorm1d in training mode over voxel rows). */
+/* gp_col_stats: mean / biased variance of the rows (BatchNorm1d in training mode over voxel rows): ONE sweep, fp64 sums of x and  */
+/* x^2 in a fixed order, var = max(E[x^2] - mean^2, 0) in fp64 (53-bit sums of 24-bit data: the cancellation costs                 */
+/* log2(mean^2 / var) of ~29 spare bits).                                                                                            */
 size_t gp_col_stats_workspace_bytes(int64_t nv, int32_t c);
 int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, float *mean, float *var,
                  void *workspace, size_t workspace_bytes, void *stream);
@@ -508,11 +512,13 @@ int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t c, const f
                       float momentum, float *running_mean, float *running_var, void *stream);
 /* dz = dout*(act>0) (act NULL: no mask); dgamma = sum dz*xhat; dbeta = sum dz;                       */
 /* dy = gamma/sqrt(var+eps)*(dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) <- dz.                */
+/* dy_scale2 (nullable, 2 floats on the device) <- [s, 1/s] of gp_pow2_scale(dy), taken inside the sweep that writes dy: */
+/* the scale of the gradient's f16 split (gp_split_f16_scaled) without another pass over it.                           */
 /* workspace: gp_col_stats_workspace_bytes(nv, c) + 2*c*4 (rounded up to 256).                        */
 int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y,
                          int64_t ld_y, const float *mean, const float *var, float eps, const float *gamma,
                          int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz,
-                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+                         float *dgamma, float *dbeta, float *dy_scale2, void *workspace, size_t workspace_bytes, void *stream);
 /* SyncBatchNorm pieces (run/train.py:212-213 converts the student to MinkowskiSyncBatchNorm; geopurify_amd/sharding.py     */
 /* all-reduces these small vectors over the ranks).  gp_col_sums_f64: mean == NULL -> out[col] = sum_r y[r][col], else         */
 /* out[col] = sum_r (y[r][col] - mean[col])^2 (fp64, fixed order).  gp_bn_bwd_sums_f64: sums[0:c] = sum dz,                    */
@@ -525,7 +531,7 @@ int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const float *act, int
                        size_t workspace_bytes, void *stream);
 int gp_bn_bwd_apply(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
                     const float *mean, const float *var, float eps, const float *gamma, const float *sums, int64_t n_total,
-                    int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, void *stream);
+                    int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2, void *stream);
 /* InfoNCE (affinity_module.py:1219-1233) forward + backward: samples s -> voxel rows sample_to_voxel[s]; */
 /* point_to_batch i64 [A*(2+Nn)] = sample ids of (anchors | positives | negatives row-major).           */
 /* loss f32 device scalar; de f32 [nv, d] = d loss / d e (overwritten).                                  */
@@ -552,6 +558,17 @@ int gp_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_av
 /* order (d^2 in fp64 of the fp32 coordinates, row id); *flag_dev != 0: degenerate duplicates, result invalid.   */
 int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *queries, int64_t num_queries, int32_t k,
                       int64_t *out, int32_t *flag_dev, void *stream);
+/* The sampler's selections on the anchors x points similarity (sample_contrastive_pairs_hybrid, affinity_module.py:1116-1124):    */
+/* per row a of sim fp32 [num_anchors, >= n] (leading dimension ld): positive[a] = arg-max over the points other than anchor_idx[a]   */
+/* (ties: the lowest index -- torch.argmax after the -inf mark); macro[a, 0:k] = the k points of lowest similarity other than the     */
+/* anchor and the positive, ascending by (value, index) (torch.topk(largest=False) after the two +inf marks).  sim is not written.    */
+/* 1 <= k < 1024, n >= k + 2.  -0 counts as +0; NaNs order above +inf.                                                               */
+int gp_sampler_select(const float *sim, int64_t ld, int64_t num_anchors, int64_t n, const int64_t *anchor_idx, int32_t k,
+                      int64_t *positive, int64_t *macro, void *stream);
+/* F.normalize(x, p=2, dim=1) (affinity_module.py:1114) written as the f16 hi/lo planes of the similarity GEMM's operands:            */
+/* hi + lo = x[r] / max(|x[r]|_2, eps) for r < n; rows n <= r < n_pad of the planes are zero.  d % 4 == 0, x 16-byte aligned.         */
+int gp_normalize_split_f16(const float *x, int64_t ld_x, int32_t d, int64_t n, int64_t n_pad, float eps, void *hi, void *lo,
+                           int64_t ld_h, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* decode of a fused-feature file on the device (dataset/feature_loader.py:113-192). */

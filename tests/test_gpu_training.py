@@ -58,6 +58,99 @@ def test_batchnorm_training_forward_backward(ops):
     assert (dy.cpu() - yr.grad).abs().max() < 1e-5
     assert (dg.cpu() - gr.grad).abs().max() < 2e-3 and (db.cpu() - br.grad).abs().max() < 2e-3      # sums of 3001 terms
     assert torch.equal(dz.cpu(), dout * (out_ref.detach() > 0))
+    # the gradient's split scale from the same sweep == the separate amax pass over dy; the unaligned (scalar) form writes the same dy
+    sc2 = torch.empty(2, device="cuda")
+    dy2 = ops.bn_train_backward(dev(dout), out, dev(y), mean, var, 1e-5, dev(gamma), dy_scale2=sc2)[0]
+    assert torch.equal(dy2, dy) and torch.equal(sc2, ops.pow2_scale(dy)) and float(sc2[0] * sc2[1]) == 1.0
+    assert 2.0 ** 13 <= float(dy.abs().max() * sc2[0]) < 2.0 ** 14
+    yo = torch.zeros(nv * c + 1, device="cuda")[1:].view(nv, c)                 # 4-byte aligned only
+    yo.copy_(dev(y))
+    dy3 = ops.bn_train_backward(dev(dout), out, yo, mean, var, 1e-5, dev(gamma), dy_scale2=sc2)[0]
+    assert torch.equal(dy3, dy) and torch.equal(sc2, ops.pow2_scale(dy))
+    hi, lo = ops.split_f16(dy, scale=sc2[0:1], extra_zero_rows=1)
+    assert hi.shape[0] == nv + 1 and not hi[nv].any() and not lo[nv].any()
+    assert ((hi[:nv].float() + lo[:nv].float()) * sc2[1] - dy).abs().max() <= dy.abs().max() * 2.0 ** -21
+
+
+def test_weight_split_transpose_flip_is_the_split_of_the_mirrored_transposed_weights(ops):
+    """the data-gradient operand V[k] = W[26-k]^T taken straight from W: the same halves as the split of the flipped, transposed copy"""
+    torch.manual_seed(5)
+    for cin, cout in ((512, 256), (256, 544 - 32), (96, 256)):                    # the last shape has no blocked form: the fallback
+        w = torch.randn(27, cin, cout, device="cuda") * 0.02
+        got = ops.conv_weights_split(w, 16.0, transpose_flip=True)
+        ref = ops.conv_weights_split(w.flip(0).transpose(1, 2).contiguous(), 16.0)
+        assert got[0].shape == ref[0].shape and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+def _select_reference(sim, anchors, k):
+    """arg-max over the points other than the anchor (lowest index on ties); the k lowest other than anchor and positive by (value, index)"""
+    A, n = sim.shape
+    pos = np.empty(A, dtype=np.int64)
+    macro = np.empty((A, k), dtype=np.int64)
+    for a in range(A):
+        row = sim[a].astype(np.float64) + 0.0                        # -0 -> +0
+        m = row.copy()
+        m[anchors[a]] = -np.inf
+        pos[a] = int(np.argmax(m))
+        m = row.copy()
+        m[anchors[a]] = np.inf
+        m[pos[a]] = np.inf
+        macro[a] = np.lexsort((np.arange(n), m))[:k]
+    return pos, macro
+
+
+@pytest.mark.parametrize("case", ["random", "ties", "one_stride", "equal_block", "small", "unaligned"])
+def test_sampler_select_is_argmax_and_k_lowest(ops, case):
+    """gp_sampler_select against numpy (exact: indices ordered by (value, index)); the cases drive the common path (a few candidates under
+    the bound of the thread minima), the radix path (more than 4096 elements at or below the bound: all low values in ONE thread's stride;
+    thousands of exactly equal lowest values, picked by index) and rows that cannot be read 16 bytes at a time."""
+    rng = np.random.default_rng({"random": 0, "ties": 1, "one_stride": 2, "equal_block": 3, "small": 4, "unaligned": 5}[case])
+    A, n, k, ld = 24, 50001, 48, 50004
+    if case == "random":
+        sim = (rng.standard_normal((A, n)) * 0.03).astype(np.float32)
+        sim[0, :100] = -0.0
+    elif case == "ties":
+        sim = np.round(rng.standard_normal((A, n)) * 4).astype(np.float32) / 64        # ~40 distinct values
+    elif case == "one_stride":
+        A, n, ld = 6, 600001, 600004                                  # 586 elements per thread: 20 threads hold 11.7k low values, all at or
+        sim = rng.random((A, n), dtype=np.float32) + 1.0              # below the bound (the 49th lowest thread minimum is an ordinary value)
+        j = np.arange(0, n // 4, 1024)
+        idx = (4 * (np.arange(20)[:, None] + j[None, :]))[:, :, None] + np.arange(4)[None, None, :]
+        idx = idx.reshape(-1)
+        idx = idx[idx < n]
+        sim[:, idx] = -rng.random((A, len(idx)), dtype=np.float32)
+    elif case == "equal_block":
+        sim = rng.random((A, n), dtype=np.float32)
+        sim[:, 1000:1000 + 9000] = -1.0                                                   # 9000 equal lowest values: the first 48 by index
+        sim[:, 20000:20005] = -1.5
+    elif case == "small":
+        n, ld = 50, 52
+        sim = rng.standard_normal((A, n)).astype(np.float32)
+    else:
+        n, ld = 4999, 5001
+        sim = rng.standard_normal((A, n)).astype(np.float32)
+    anchors = rng.integers(0, n, A)
+    buf = torch.full((A, ld), float("nan"), device="cuda")
+    buf[:, :n] = dev(sim)
+    before = buf.clone()
+    pos, macro = ops.sampler_select(buf, dev(anchors.astype(np.int64)), k, n=n)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(buf), torch.nan_to_num(before))
+    rp, rm = _select_reference(sim, anchors, k)
+    assert np.array_equal(pos.cpu().numpy(), rp)
+    assert np.array_equal(macro.cpu().numpy(), rm)
+
+
+def test_normalize_split_is_f_normalize(ops):
+    torch.manual_seed(3)
+    n, d, n_pad = 1003, 1088, 1280
+    x = torch.randn(n, d) * torch.rand(n, 1) * 5
+    x[7] = 0
+    hi, lo = ops.normalize_split_f16(dev(x), n_pad)
+    ref = F.normalize(x.double(), dim=1)
+    got = hi.double().cpu() + lo.double().cpu()
+    assert got.shape == (n_pad, d) and not got[n:].any() and not got[7].any()
+    assert (got[:n] - ref).abs().max() < 3e-7                         # fp32 norm and quotient + the split's 2^-22 relative
 
 
 def test_infonce_forward_backward(ops):
