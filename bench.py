@@ -240,8 +240,10 @@ def training_step_rate(batch, dev, sd, steps=6):
         o = tr.scene_step(F_lift, batch.scene_gauss_features, batch.scene_inds_reconstruct, batch.scene_coords_3d, xyz, F_teacher,
                           anchors, num_negatives=63, K=96, optimize=True)
         return o
-    for _ in range(2):                                 # warm-up: allocator, operator plans
-        o = one()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                           # the inference schedule's cached blocks have other sizes: without this the first steps
+    for _ in range(3):                                 # free and re-allocate them one by one (device syncs inside the timed steps)
+        o = one()                                      # warm-up: allocator, operator plans
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -1338,7 +1338,13 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
                                     const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
                                     const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, int32_t w_blocked,
                                     int32_t plane_flags, void *stream_) {
-    GP_CHECK_ARG(plane_flags >= 0 && plane_flags < 16, "gp_sparse_conv_f16x3: plane_flags is a mask of 1 (x interleaved), 2 (y interleaved), 4 (residual interleaved), 8 (fp32 partial rows)");
+    GP_CHECK_ARG(plane_flags >= 0 && plane_flags < 32, "gp_sparse_conv_f16x3: plane_flags is a mask of 1 (x interleaved), 2 (y interleaved), 4 (residual interleaved), 8 (fp32 partial rows), 16 (one dense offset: phase 1 writes y)");
+    // bit 4: ONE offset whose map holds every output row (a gather-GEMM: the training sampler's anchors x points similarity): pair p IS
+    // output row p, nothing is summed, so phase 1 stores its fp32 rows straight into y and phase 2 (a 2 x 2.4 GB round trip there) is not run
+    const bool direct = (plane_flags & 16) != 0;
+    GP_CHECK_ARG(!direct || (kv == 1 && num_pairs == nv && x_hi && y && ld_y == cout && !scale && !shift && !residual && !res_hi && !relu && !y_hi &&
+                             !y_row_inv_scale && !(g_gp_knobs[3] & 16)),
+                 "gp_sparse_conv_f16x3: plane_flags bit 4 is for kv = 1 with a pair for every row, pre-split x, contiguous fp32 y and no epilogue");
     GP_CHECK_ARG(!(plane_flags & 1) || (x_hi && ld_xh % 64 == 0 && cin % 32 == 0), "gp_sparse_conv_f16x3: interleaved x rows come as ONE tensor (x_hi) of 2 x cin halfs per row");
     GP_CHECK_ARG(!(plane_flags & 2) || (y_hi && ld_yh % 64 == 0 && (uintptr_t)y_hi % 16 == 0), "gp_sparse_conv_f16x3: interleaved y rows go to ONE tensor (y_hi) of 2 x cout halfs per row");
     GP_CHECK_ARG(!(plane_flags & 4) || (res_hi && ld_rh % 64 == 0), "gp_sparse_conv_f16x3: interleaved residual rows come as ONE tensor (res_hi)");
@@ -1423,10 +1429,11 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
         const bool q24 = dma_path && !(g_conv_ablate & 32) && q24_fits;   // tuning bit 5: the fp32 partial rows of rounds 1-4, same kernels otherwise
         if (tile_count > 0) {
             int64_t nblocks = (((int64_t)tile_count * n_tiles + 7) / 8) * 8;
-            const int tune = (g_conv_ablate & ~16) | ((dma_path && !q24_fits) ? 32 : 0);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
+            const int tune = (g_conv_ablate & ~16) | ((dma_path && (!q24_fits || direct)) ? 32 : 0);   // bit 4 picks the register-staged path on the host; the rest are kernel tuning bits
 #define P1_ARGS static_cast<const _Float16 *>(x_hi), static_cast<const _Float16 *>(x_lo), ld_xh, pair_in, pair_off, tile_start,              \
                 reinterpret_cast<const int4 *>(tile_desc), nseg, kv, static_cast<const _Float16 *>(w_hi), static_cast<const _Float16 *>(w_lo), \
-                cin, cout, partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, q_e_off, w_blocked, plane_flags & 1
+                cin, cout, direct ? y + (int64_t)pair_base * cout : partial, n_tiles, tune, tile_begin, tile_count, pair_base, x_row_inv_scale, stamp, \
+                q_e_off, w_blocked, plane_flags & 1
             if (dma_path) {
                 GP_CHECK_ARG(!stamp || g_gp_debug_bytes[1] >= (size_t)nblocks * 16 * sizeof(uint64_t),
                              "gp_sparse_conv_f16x3: the stamp buffer of gp_debug_ptr(1) holds %zu bytes, this launch writes %zu",
@@ -1445,6 +1452,7 @@ extern "C" int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_
             }
 #undef P1_ARGS
         }
+        if (direct) continue;
         // one resident round: 6 workgroups of 4 waves per CU (80 registers per lane)
         const int64_t p2_full = (row_count * 64 + 255) / 256;
         int64_t p2_res = (int64_t)gp_cu_count() * p2_wg_per_cu;

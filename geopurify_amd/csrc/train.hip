@@ -340,48 +340,74 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
 // ------------------------------------------------------------------------------------------------ K nearest points of a query point
 constexpr int KP_BINS = 2048, KP_CAP = 2048;
 __device__ __forceinline__ int kp_bin(double d2) { return (int)(__float_as_uint((float)d2) >> 20); }   // sign 0, 8 exponent + 3 mantissa bits
-__global__ void __launch_bounds__(256)
+// One workgroup per query.  Sweep 1: every thread keeps the lowest d^2 of the points it visits; the (k+1)-th lowest of the NT thread minima
+// bounds the (k+1)-th lowest distance from above (k+1 distinct points lie at or below it) and, points being in no particular order along a
+// thread's stride, only ~1.3 (k+1) points do.  Sweep 2 (the coordinates again, from L2) collects them; a bitonic sort by (d^2, id) orders them.
+// (Rounds 3-5 found the bound with a 2048-bin LDS histogram of all n distances: 150k same-address-heavy LDS atomics per query, 1.34 ms for
+// 4096 queries; it remains as the fallback when more than KP_CAP points lie under the thread-minimum bound -- a point order with the stride's
+// period -- and flags the query only if its own bound does not fit either: massively duplicated points.)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 knn_points_kernel(const float *__restrict__ xyz, int64_t n, const int64_t *__restrict__ queries, int k, int64_t *__restrict__ out,
                   int32_t *__restrict__ flag) {
     __shared__ unsigned hist[KP_BINS];
     __shared__ double cd[KP_CAP];
     __shared__ int ci[KP_CAP];
+    __shared__ double s_tm[NT];
+    __shared__ double s_bound;
     __shared__ int s_thr, s_cnt;
     const int tid = threadIdx.x;
     const int64_t q = queries[blockIdx.x];
     const double qx = xyz[q * 3], qy = xyz[q * 3 + 1], qz = xyz[q * 3 + 2];
-    for (int i = tid; i < KP_BINS; i += 256) hist[i] = 0;
+    auto dist2 = [&](int64_t i) { const double dx = xyz[i * 3] - qx, dy = xyz[i * 3 + 1] - qy, dz = xyz[i * 3 + 2] - qz; return dx * dx + dy * dy + dz * dz; };
+    double tmin = INFINITY;
+    for (int64_t i = tid; i < n; i += NT) { const double d2 = dist2(i); tmin = d2 < tmin ? d2 : tmin; }
+    s_tm[tid] = tmin;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    for (int64_t i = tid; i < n; i += 256) {
-        double dx = xyz[i * 3] - qx, dy = xyz[i * 3 + 1] - qy, dz = xyz[i * 3 + 2] - qz;
-        atomicAdd(&hist[kp_bin(dx * dx + dy * dy + dz * dz)], 1u);
+    {
+        int rank = 0;
+        for (int u = 0; u < NT; ++u) { const double m = s_tm[u]; rank += (m < tmin) || (m == tmin && u < tid); }
+        if (rank == k) s_bound = tmin;
     }
     __syncthreads();
-    if (tid == 0) {                                       // first bin at which the running count reaches k+1
-        unsigned run = 0;
-        int t = 0;
-        for (; t < KP_BINS; ++t) { run += hist[t]; if (run >= (unsigned)(k + 1)) break; }
-        s_thr = t < KP_BINS ? t : KP_BINS - 1;
-        if (run > (unsigned)KP_CAP) { *flag = 1; s_thr = -1; }
+    const double bound = s_bound;
+    for (int64_t i = tid; i < n; i += NT) {
+        const double d2 = dist2(i);
+        if (d2 <= bound) { const int pos = atomicAdd(&s_cnt, 1); if (pos < KP_CAP) { cd[pos] = d2; ci[pos] = (int)i; } }
     }
     __syncthreads();
-    const int thr = s_thr;
-    if (thr < 0) return;
-    for (int64_t i = tid; i < n; i += 256) {
-        double dx = xyz[i * 3] - qx, dy = xyz[i * 3 + 1] - qy, dz = xyz[i * 3 + 2] - qz;
-        double d2 = dx * dx + dy * dy + dz * dz;
-        if (kp_bin(d2) <= thr) { int pos = atomicAdd(&s_cnt, 1); cd[pos] = d2; ci[pos] = (int)i; }
+    if (s_cnt > KP_CAP) {                                  // (uniform) the histogram bound of rounds 3-5
+        __syncthreads();
+        for (int i = tid; i < KP_BINS; i += NT) hist[i] = 0;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += NT) atomicAdd(&hist[kp_bin(dist2(i))], 1u);
+        __syncthreads();
+        if (tid == 0) {                                       // first bin at which the running count reaches k+1
+            unsigned run = 0;
+            int t = 0;
+            for (; t < KP_BINS; ++t) { run += hist[t]; if (run >= (unsigned)(k + 1)) break; }
+            s_thr = t < KP_BINS ? t : KP_BINS - 1;
+            if (run > (unsigned)KP_CAP) { *flag = 1; s_thr = -1; }
+        }
+        __syncthreads();
+        const int thr = s_thr;
+        if (thr < 0) return;
+        for (int64_t i = tid; i < n; i += NT) {
+            const double d2 = dist2(i);
+            if (kp_bin(d2) <= thr) { int pos = atomicAdd(&s_cnt, 1); cd[pos] = d2; ci[pos] = (int)i; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int cnt = s_cnt;
     int np2 = 1;
     while (np2 < cnt) np2 <<= 1;
-    for (int i = cnt + tid; i < np2; i += 256) { cd[i] = INFINITY; ci[i] = INT32_MAX; }
+    for (int i = cnt + tid; i < np2; i += NT) { cd[i] = INFINITY; ci[i] = INT32_MAX; }
     __syncthreads();
     for (int kk = 2; kk <= np2; kk <<= 1)                 // bitonic sort by (d2, id)
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 256) {
+            for (int i = tid; i < np2; i += NT) {
                 int ixj = i ^ j;
                 if (ixj > i) {
                     bool up = (i & kk) == 0;
@@ -391,25 +417,27 @@ knn_points_kernel(const float *__restrict__ xyz, int64_t n, const int64_t *__res
             }
             __syncthreads();
         }
-    for (int j = tid; j < k; j += 256) out[(int64_t)blockIdx.x * k + j] = ci[j + 1];     // column 0 (the point itself) dropped
+    for (int j = tid; j < k; j += NT) out[(int64_t)blockIdx.x * k + j] = ci[j + 1];     // column 0 (the point itself) dropped
 }
-
 
 // ------------------------------------------------------------------------------------------------ the sampler's selections
 // sample_contrastive_pairs_hybrid (affinity_module.py:1116-1124) on one row of the anchors x points similarity per workgroup:
 //   positive = arg-max over the points other than the anchor (ties: the lowest index);
 //   macro    = the k points of lowest similarity other than the anchor and the positive, ascending by (value, index)
 // -- torch.argmax + torch.topk(largest=False) of the reference, which on the device are a 4-pass radix select over the whole 2.4-GB
-// matrix plus a gather pass (4.7 ms at 4096 x 150k) and an arg-max sweep (0.5 ms).  Here:
-//   sweep 1 (HBM): every thread keeps the lowest key and the highest (key, -index) of the elements it reads.  The (k+1)-th lowest of the
-//     1024 thread minima is an upper bound B of the k-th lowest selectable element (k+1 distinct elements lie at or below it, at most one
-//     of them the positive), and on anything but adversarial data only ~2k elements of the row lie at or below it;
-//   sweep 2 (the row again, from L2): elements <= B are collected into LDS, ranked by counting, the k lowest written in order.
-//   If more than SR_CAP elements lie at or below B (massive ties, or the low values all in one thread's stride) the candidates are narrowed
-//     by a radix select over the 64-bit key (value | index) 12 bits at a time -- keys are unique, so it terminates with <= SR_CAP -- one
-//     sweep per level, then collected and ranked the same way.
+// matrix plus a gather pass (4.7 ms at 4096 x 150k) and an arg-max sweep (0.5 ms).  Here the row is read from memory ONCE:
+//   sweep (HBM, 16 bytes per lane, fully coalesced): every thread keeps the lowest key and the highest (key, -index) of the elements it
+//     reads, and the lowest key of every GROUP of 4 << lg consecutive elements (1 << lg neighbouring lanes, joined by shuffles) goes to LDS.
+//     The (k+1)-th lowest of the 1024 thread minima is an upper bound B of the k-th lowest selectable element (k+1 distinct elements lie
+//     at or below it, at most one of them the positive), and on anything but adversarial data only ~2k elements of the row lie at or below it;
+//   collect: the groups whose minimum is <= B (a walk over LDS) are read again -- a few dozen 64-byte pieces -- their elements <= B go to
+//     LDS, are ranked by counting, the k lowest written in order.
+//   If more than SR_CAP elements lie at or below B (massive ties, or the low values all in a few threads' strides) the candidates are
+//     narrowed by a radix select over the 64-bit key (value | index) 12 bits at a time -- keys are unique, so it terminates with <= SR_CAP --
+//     one walk over the flagged groups per level, then collected and ranked the same way.
 // Keys: the order-preserving uint image of a float (-0 counts as +0; a NaN with a clear sign bit orders above +inf, as in torch).
-constexpr int SR_NT = 1024, SR_CAP = 4096, SR_BINS = 4096;
+// LDS: 48 KiB of group minima + 16 KiB of candidates (the rare path's histogram shares them) + 4 KiB: two workgroups per CU.
+constexpr int SR_NT = 1024, SR_CAP = 2048, SR_BINS = 4096, SR_GROUPS = 12288;
 __device__ __forceinline__ unsigned sr_key(float v) {
     unsigned u = __float_as_uint(v);
     if (u == 0x80000000u) u = 0u;
@@ -419,47 +447,63 @@ __device__ __forceinline__ unsigned long long sr_shfl_xor(unsigned long long v, 
     unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
-// f(index, value) over the n elements of a row; 16-byte loads where the row allows
+// f(index, key) over the elements of the groups whose minimum is at or below `bound`
 template <typename F>
-__device__ __forceinline__ void sr_sweep(const float *__restrict__ row, int n, bool vec, F f) {
-    if (vec) {
-        const int n4 = n >> 2;
-        for (int i = threadIdx.x; i < n4; i += SR_NT) {
-            const float4 a = *reinterpret_cast<const float4 *>(row + 4 * (int64_t)i);
-            f(4 * i, a.x); f(4 * i + 1, a.y); f(4 * i + 2, a.z); f(4 * i + 3, a.w);
+__device__ __forceinline__ void sr_walk(const float *__restrict__ row, int n, const unsigned *gmin, int ngroups, int lg, unsigned bound, F f) {
+    const int gsz = 4 << lg;
+    for (int g = threadIdx.x; g < ngroups; g += SR_NT)
+        if (gmin[g] <= bound) {
+            const int e0 = g * gsz, e1 = e0 + gsz < n ? e0 + gsz : n;
+            for (int i = e0; i < e1; ++i) f(i, sr_key(row[i]));
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += SR_NT) f(i, row[i]);
-    } else {
-        for (int i = threadIdx.x; i < n; i += SR_NT) f(i, row[i]);
-    }
 }
-__global__ void __launch_bounds__(SR_NT)
-sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const int64_t *__restrict__ anchor, int k,
+__global__ void __launch_bounds__(SR_NT, 8)
+sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, const int64_t *__restrict__ anchor, int k,
                       int64_t *__restrict__ positive, int64_t *__restrict__ macro) {
     __shared__ __align__(16) unsigned long long cand[SR_CAP];
-    __shared__ unsigned hist[SR_BINS];
+    __shared__ unsigned gmin[SR_GROUPS];
     __shared__ __align__(16) unsigned s_min[SR_NT];
     __shared__ unsigned long long s_red[SR_NT / 64];
     __shared__ unsigned s_bound;
     __shared__ int s_cnt, s_pos, s_bin, s_acc, s_done;
-    const int tid = threadIdx.x;
+    unsigned *hist = reinterpret_cast<unsigned *>(cand);                 // [SR_BINS]: the rare path's, before the candidates are collected
+    const int tid = threadIdx.x, lane = tid & 63;
     const float *row = sim + (int64_t)blockIdx.x * ld;
     const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(sim) & 15) == 0);
     const int anc = (int)anchor[blockIdx.x];
-    // ---- sweep 1
+    const int n4 = (n + 3) >> 2, ngroups = (n4 + (1 << lg) - 1) >> lg;
+    // ---- the sweep
     unsigned tmin = 0xffffffffu;
     unsigned long long tmax = 0ull;
-    sr_sweep(row, n, vec, [&](int i, float v) {
-        if (i == anc) return;
-        const unsigned kx = sr_key(v);
-        tmin = kx < tmin ? kx : tmin;
-        const unsigned long long m = ((unsigned long long)kx << 32) | (unsigned)(0x7fffffff - i);
-        tmax = m > tmax ? m : tmax;
-    });
+#pragma unroll 4
+    for (int f0 = tid - lane; f0 < n4; f0 += SR_NT) {
+        const int f = f0 + lane, i0 = 4 * f;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && i0 + 3 < n) {
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(row + i0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (i0 + q < n) v[q] = row[i0 + q];
+        }
+        unsigned gk = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if (i < n && i != anc) {
+                const unsigned kx = sr_key(v[q]);
+                gk = kx < gk ? kx : gk;
+                const unsigned long long m = ((unsigned long long)kx << 32) | (unsigned)(0x7fffffff - i);
+                tmax = m > tmax ? m : tmax;
+            }
+        }
+        tmin = gk < tmin ? gk : tmin;
+        for (int o = 1; o < (1 << lg); o <<= 1) { const unsigned t = __shfl_xor(gk, o, 64); gk = t < gk ? t : gk; }
+        if ((lane & ((1 << lg) - 1)) == 0 && f < n4) gmin[f >> lg] = gk;
+    }
     s_min[tid] = tmin;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = sr_shfl_xor(tmax, o); tmax = t > tmax ? t : tmax; }
-    if ((tid & 63) == 0) s_red[tid >> 6] = tmax;
+    if (lane == 0) s_red[tid >> 6] = tmax;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (tid == 0) {
@@ -480,9 +524,8 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const in
     const unsigned bound = s_bound;
     const int pos = s_pos;
     if (tid == 0) positive[blockIdx.x] = pos;
-    // ---- sweep 2: the elements at or below the bound
-    sr_sweep(row, n, vec, [&](int i, float v) {
-        const unsigned kx = sr_key(v);
+    // ---- collect the elements at or below the bound
+    sr_walk(row, n, gmin, ngroups, lg, bound, [&](int i, unsigned kx) {
         if (kx <= bound && i != anc && i != pos) {
             const int p = atomicAdd(&s_cnt, 1);
             if (p < SR_CAP) cand[p] = ((unsigned long long)kx << 32) | (unsigned)i;
@@ -491,7 +534,7 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const in
     __syncthreads();
     int cnt = s_cnt;
     if (cnt > SR_CAP) {
-        // ---- the rare path: radix select on the 64-bit keys of the elements at or below the bound, 12 bits per sweep
+        // ---- the rare path: radix select on the 64-bit keys of the elements at or below the bound, 12 bits per walk
         unsigned long long prefix = 0ull;
         int acc = 0, shift = 64;
         for (int level = 0;; ++level) {
@@ -499,8 +542,7 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const in
             shift -= width;
             for (int i = tid; i < SR_BINS; i += SR_NT) hist[i] = 0u;
             __syncthreads();
-            sr_sweep(row, n, vec, [&](int i, float v) {
-                const unsigned kx = sr_key(v);
+            sr_walk(row, n, gmin, ngroups, lg, bound, [&](int i, unsigned kx) {
                 if (kx <= bound && i != anc && i != pos) {
                     const unsigned long long key = ((unsigned long long)kx << 32) | (unsigned)i;
                     if (level == 0 || (key >> (shift + width)) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & ((1u << width) - 1u)], 1u);
@@ -519,10 +561,11 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const in
             __syncthreads();
             prefix = (prefix << width) | (unsigned)s_bin;
             acc = s_acc;
-            if (s_done) break;                            // the last level's bins hold one key each: acc + 1 <= k
+            const int done = s_done;
+            __syncthreads();                              // (the histogram shares the candidates' memory: everyone has read s_* before it is reused)
+            if (done) break;                              // the last level's bins hold one key each: acc + 1 <= k
         }
-        sr_sweep(row, n, vec, [&](int i, float v) {
-            const unsigned kx = sr_key(v);
+        sr_walk(row, n, gmin, ngroups, lg, bound, [&](int i, unsigned kx) {
             if (kx <= bound && i != anc && i != pos) {
                 const unsigned long long key = ((unsigned long long)kx << 32) | (unsigned)i;
                 if ((key >> shift) <= prefix) { const int p = atomicAdd(&s_cnt, 1); if (p < SR_CAP) cand[p] = key; }
@@ -744,7 +787,8 @@ extern "C" int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *que
     GP_CHECK_ARG(n < INT32_MAX, "gp_knn_points_f32: too many points");
     hipStream_t s = gp_stream(stream_);
     GP_CHECK_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int32_t), s));
-    knn_points_kernel<<<(unsigned)num_queries, 256, 0, s>>>(xyz, n, queries, k, out, flag_dev);
+    if (k + 1 <= 256) knn_points_kernel<256><<<(unsigned)num_queries, 256, 0, s>>>(xyz, n, queries, k, out, flag_dev);
+    else knn_points_kernel<1024><<<(unsigned)num_queries, 1024, 0, s>>>(xyz, n, queries, k, out, flag_dev);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
@@ -753,9 +797,11 @@ extern "C" int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *que
 extern "C" int gp_sampler_select(const float *sim, int64_t ld, int64_t num_anchors, int64_t n, const int64_t *anchor_idx, int32_t k,
                                  int64_t *positive, int64_t *macro, void *stream_) {
     GP_CHECK_ARG(sim && anchor_idx && positive && macro && num_anchors > 0 && ld >= n, "gp_sampler_select: null/empty argument");
-    GP_CHECK_ARG(k >= 1 && k < SR_NT && k <= SR_CAP && n >= (int64_t)k + 2 && n < 0x7fffffff, "gp_sampler_select: k=%d, n=%lld out of range (1 <= k < %d, n >= k + 2)",
-                 k, (long long)n, SR_NT);
-    sampler_select_kernel<<<(unsigned)num_anchors, SR_NT, 0, gp_stream(stream_)>>>(sim, ld, (int)n, anchor_idx, k, positive, macro);
+    GP_CHECK_ARG(k >= 1 && k < SR_NT && k <= SR_CAP && n >= (int64_t)k + 2 && n <= (int64_t)SR_GROUPS * 256,
+                 "gp_sampler_select: k=%d, n=%lld out of range (1 <= k < %d, k + 2 <= n <= %d)", k, (long long)n, SR_NT, SR_GROUPS * 256);
+    int lg = 0;                                             // 4 << lg elements per group: the fewest that fit the row's groups into LDS
+    while ((((n + 3) >> 2) + (1 << lg) - 1) >> lg > SR_GROUPS) ++lg;
+    sampler_select_kernel<<<(unsigned)num_anchors, SR_NT, 0, gp_stream(stream_)>>>(sim, ld, (int)n, lg, anchor_idx, k, positive, macro);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }

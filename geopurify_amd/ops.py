@@ -417,7 +417,7 @@ def pow2_scale(x, d=None):
 
 
 def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=None, relu=False, out=None,
-                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None, want_f32=True, fp32_partials=False):
+                      x_split=None, out_split=None, x_row_inv=None, out_row_inv=None, want_f32=True, fp32_partials=False, dense_single_offset=False):
     """x fp32 [nv, >=cin] and/or x_split=(hi, lo) f16 (pre-split operand -> LDS-DMA path);
     out_split=(hi, lo) f16 buffers to also receive the split output.  x_row_inv fp32 [nv]: the per-row inverse scales of
     a row-scaled x_split; out_row_inv fp32 [nv]: receive the output's (out_split is then row-scaled).
@@ -428,7 +428,9 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     convert).
     fp32_partials=True: the partial rows between the two phases as fp32 (the format of rounds 1-4, which the 24-bit block-floating rows
     are checked against; also what a call takes by itself when a chunk's 24-bit rows would pass 4 GiB) -- an explicit argument of the
-    call (plane_flags bit 3), not a process-wide switch."""
+    call (plane_flags bit 3), not a process-wide switch.
+    dense_single_offset=True (plane_flags bit 4): kv = 1 and every output row has its pair -- a gather-GEMM; phase 1 writes the fp32 output
+    itself, no partial rows, no phase 2."""
     lib = _lib.load()
     res_planes = residual if isinstance(residual, (tuple, list)) else None
     if res_planes is not None:
@@ -438,19 +440,23 @@ def sparse_conv_f16x3(x, pairs, w_hi, w_lo, scale=None, shift=None, residual=Non
     w_blocked = int(w_hi.dim() == 5)
     nv = pairs.nv
     dev = w_hi.device
-    if pairs.partial is None or pairs.partial.shape[1] < cout:
-        pairs.partial = torch.empty((max(pairs.max_chunk_pairs, 1), cout), dtype=torch.float32, device=dev)
+    if dense_single_offset:
+        partial = torch.empty(64, dtype=torch.float32, device=dev)                    # (not written: phase 1 stores into `out`)
+    else:
+        if pairs.partial is None or pairs.partial.shape[1] < cout or pairs.partial.shape[0] < max(pairs.max_chunk_pairs, 1):
+            pairs.partial = torch.empty((max(pairs.max_chunk_pairs, 1), cout), dtype=torch.float32, device=dev)
+        partial = pairs.partial
     if out is None and (want_f32 or out_split is None):
         out = torch.empty((nv, cout), dtype=torch.float32, device=dev)        # want_f32=False: only the split planes are written
     xh, xl = x_split if x_split is not None else (None, None)
     yh, yl = out_split if out_split is not None else (None, None)
     # interleaved rows ([K step][hi 32 | lo 32], ONE tensor of 2 x channels halfs per row): given as (tensor, None)
     plane_flags = (1 if (xh is not None and xl is None) else 0) | (2 if (yh is not None and yl is None) else 0) | \
-                  (4 if (rh is not None and rl is None) else 0) | (8 if fp32_partials else 0)
+                  (4 if (rh is not None and rl is None) else 0) | (8 if fp32_partials else 0) | (16 if dense_single_offset else 0)
     check(lib.gp_sparse_conv_f16x3(_ptr(x), x.stride(0) if x is not None else 0, _ptr(xh), _ptr(xl),
                                    xh.stride(0) if xh is not None else 0, _ptr(pairs.pair_in), _ptr(pairs.pair_pos),
                                    _ptr(pairs.pair_off), _ptr(pairs.tile_start), _ptr(pairs.tile_desc), pairs.nseg, pairs.num_pairs, nv, kv, _ptr(w_hi), _ptr(w_lo), cin, cout,
-                                   _ptr(pairs.partial), _ptr(scale), _ptr(shift), _ptr(residual),
+                                   _ptr(partial), _ptr(scale), _ptr(shift), _ptr(residual),
                                    residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
                                    out.stride(0) if out is not None else 0, _ptr(yh), _ptr(yl), yh.stride(0) if yh is not None else 0,
                                    int(pairs.num_chunks), pairs.chunk_row_off, pairs.chunk_tile_off, pairs.chunk_pair_off,

@@ -57,7 +57,8 @@ def _anchor_similarities(F_teacher, anchor_indices):
     Np = (N + 255) // 256 * 256
     hi, lo = ops.normalize_split_f16(F_teacher.contiguous(), Np)
     pairs = ops.conv_pairs_build(anchor_indices.to(torch.int32).view(1, -1).contiguous(), chunk_rows=None)      # one gather-GEMM, one chunk
-    sim = ops.sparse_conv_f16x3(None, pairs, hi.view(1, Np, Dt), lo.view(1, Np, Dt), None, None, relu=False, x_split=(hi, lo))
+    sim = ops.sparse_conv_f16x3(None, pairs, hi.view(1, Np, Dt), lo.view(1, Np, Dt), None, None, relu=False, x_split=(hi, lo),
+                                dense_single_offset=True)                      # phase 1 writes the fp32 matrix itself: no 2 x 2.4-GB second pass
     return sim[:, :N]
 
 

@@ -183,6 +183,9 @@ int gp_sparse_conv_f16x3(const float *x, int64_t ld_x, const void *x_hi, const v
                          const int32_t *chunk_pair_off_host, const float *x_row_inv_scale, float *y_row_inv_scale,
                          const void *res_hi, const void *res_lo, int64_t ld_rh, const float *res_row_inv_scale, int32_t w_blocked,
                          int32_t plane_flags, void *stream);
+/* plane_flags bit 4 (16): ONE offset (kv = 1) whose map holds every output row -- a gather-GEMM y[u] = x[pair_in[u]] @ w[0] (the training   */
+/* sampler's anchors x points similarity): phase 1 stores fp32 rows straight into y (contiguous, ld_y = cout; no scale / shift / residual / */
+/* ReLU / split output) and phase 2 is not run.                                                                                            */
 /* plane_flags (mask): 1 = x_hi is ONE tensor of INTERLEAVED rows, [cin / 32 steps][hi 32 | lo 32] halfs per row (ld_xh >= 2 cin; x_lo  */
 /* unused): the LDS-DMA kernel then stages a row and K step as ONE full 128-byte line instead of two half lines; 2 = y_hi receives the   */
 /* output in that form (y_lo unused; what the next layer reads); 4 = the residual planes res_hi come in that form.  0: separate planes. */

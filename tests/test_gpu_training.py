@@ -209,6 +209,42 @@ def test_knn_points_exact(ops):
     out, flag = ops.knn_points(dev(xyz), dev(q), 96)
     assert int(flag.item()) == 0
     assert np.array_equal(out.cpu().numpy(), o_train.knn_points_bruteforce(xyz, q, 96))
+    # k + 1 > 256: the 1024-thread form
+    out, flag = ops.knn_points(dev(xyz), dev(q[:20]), 300)
+    assert int(flag.item()) == 0 and np.array_equal(out.cpu().numpy(), o_train.knn_points_bruteforce(xyz, q[:20], 300))
+
+
+def test_knn_points_order_with_the_stride_period_takes_the_histogram_bound(ops):
+    """points ordered so that a query's neighbourhood lies in a few threads' strides (index = thread + 256 j): the bound from the thread minima
+    admits more than 2048 points and the kernel falls back to the distance histogram of rounds 3-5 -- same exact result"""
+    rng = np.random.default_rng(8)
+    n = 256 * 200
+    xyz = (rng.random((n, 3)) * 10).astype(np.float32)
+    near = np.concatenate([np.arange(t, n, 256) for t in range(40)])           # 8000 points in 40 strides ...
+    xyz[near] = (np.array([5.0, 5.0, 5.0]) + rng.standard_normal((len(near), 3)) * 0.05).astype(np.float32)      # ... in a 5-cm cluster
+    far = np.setdiff1d(np.arange(n), near)
+    xyz[far] += np.where(np.abs(xyz[far] - 5.0).max(1, keepdims=True) < 1.0, 3.0, 0.0).astype(np.float32)       # nothing else near it
+    q = near[:6].astype(np.int64)
+    out, flag = ops.knn_points(dev(xyz), dev(q), 96)
+    assert int(flag.item()) == 0
+    assert np.array_equal(out.cpu().numpy(), o_train.knn_points_bruteforce(xyz, q, 96))
+
+
+def test_gather_gemm_single_dense_offset_equals_the_two_phase_operator(ops):
+    """plane_flags bit 4 (the sampler's anchors x points similarity): phase 1 writes the fp32 rows itself; against the two-phase call with
+    fp32 partial rows (bit-identical: the same stores, then a pass that adds nothing) and against fp64"""
+    torch.manual_seed(9)
+    n, d, A = 5120, 160, 700
+    Fn = F.normalize(torch.randn(n, d), dim=1)
+    anchors = torch.randperm(n)[:A]
+    hi, lo = ops.split_f16(dev(Fn))
+    pairs = ops.conv_pairs_build(dev(anchors.to(torch.int32)).view(1, -1).contiguous(), chunk_rows=None)
+    w = (hi.view(1, n, d), lo.view(1, n, d))
+    direct = ops.sparse_conv_f16x3(None, pairs, w[0], w[1], x_split=(hi, lo), dense_single_offset=True)
+    two = ops.sparse_conv_f16x3(None, pairs, w[0], w[1], x_split=(hi, lo), fp32_partials=True)
+    assert direct.shape == (A, n) and torch.equal(direct, two)
+    ref = Fn[anchors].double() @ Fn.double().t()
+    assert (direct.double().cpu() - ref).abs().max() < 2e-6
 
 
 @pytest.mark.parametrize("cin_pad", [256, 544])
