@@ -223,7 +223,7 @@ def stage_rooflines(ms, n, nv, views, n_vis, cfg, pool_iters, d):
     return out
 
 
-def training_step_rate(batch, dev, sd, steps=6):
+def training_step_rate(batch, dev, sd, steps=8):
     """SURVEY 8f-1 (BASELINE config 5 shape): optimisation steps per second of the student on the bench scene --
     4096 anchors x (1 + 63) samples, teacher features [N, 1088] synthetic, lifted features random unit rows
     (the lift itself is timed by the headline metric), sampler + forward + backward + AdamW inside the timed region."""
@@ -242,14 +242,19 @@ def training_step_rate(batch, dev, sd, steps=6):
         return o
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                           # the inference schedule's cached blocks have other sizes: without this the first steps
-    for _ in range(3):                                 # free and re-allocate them one by one (device syncs inside the timed steps)
+    for _ in range(5):                                 # free and re-allocate them one by one (device syncs inside the timed steps)
         o = one()                                      # warm-up: allocator, operator plans
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         o = one()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    log("training steps (ms, GPU clock between the steps' ends): " + " ".join(f"{a.elapsed_time(b):.1f}" for a, b in zip(marks[:-1], marks[1:])))
     # roofline of the step's matrix work: every fp32-class product is three f16 MFMAs, so the ISSUED rate is 3 x
     # the algorithmic one; priced over the WHOLE step (sampler, BatchNorm sweeps, top-k, AdamW included), i.e. a lower bound of what
     # the matrix kernels themselves reach -- their own durations are in profiles/r05_train_kernel_stats.csv
