@@ -1251,8 +1251,9 @@ def wgrad_plan_from_pairs(kk, out_rows, in_rows, counts, nv, steps_per_segment=1
                      torch.tensor(seg_off, dtype=torch.int32, device=dev), len(segs), nv)
 
 
-def conv_wgrad_f16x3(x_split, y_split, plan, cin_pad, cin_out, cout, inv_scale=None):
-    """x_split (hi, lo) f16 [nv, >=cin_pad]; y_split (hi, lo) f16 [nv+1, >=cout] whose last row is zero."""
+def conv_wgrad_f16x3(x_split, y_split, plan, cin_pad, cin_out, cout, inv_scale=None, out=None):
+    """x_split (hi, lo) f16 [nv, >=cin_pad]; y_split (hi, lo) f16 [nv+1, >=cout] whose last row is zero.
+    out: contiguous fp32 [kv, cin_out, cout] to receive dW (e.g. a slice of a gradient bucket: sharding.GradientBuckets.view)."""
     lib = _lib.load()
     xh, xl = x_split
     yh, yl = y_split
@@ -1261,7 +1262,8 @@ def conv_wgrad_f16x3(x_split, y_split, plan, cin_pad, cin_out, cout, inv_scale=N
     if plan.workspace is None or plan.workspace.numel() < need:
         plan.workspace = _ws(need, xh.device)
     kv = plan.seg_off.shape[0] - 1
-    dw = torch.empty((kv, cin_out, cout), dtype=torch.float32, device=xh.device)
+    dw = out if out is not None else torch.empty((kv, cin_out, cout), dtype=torch.float32, device=xh.device)
+    assert dw.shape == (kv, cin_out, cout) and dw.is_contiguous() and dw.dtype == torch.float32
     check(lib.gp_conv_wgrad_f16x3(_ptr(xh), _ptr(xl), xh.stride(0), _ptr(yh), _ptr(yl), yh.stride(0), _ptr(plan.pair_in),
                                   _ptr(plan.pair_out), _ptr(plan.segs), plan.num_segments, _ptr(plan.seg_off), kv, int(cin_pad),
                                   int(cin_out), int(cout), _ptr(inv_scale), _ptr(dw), _ptr(plan.workspace), plan.workspace.numel(),

@@ -72,6 +72,69 @@ def allreduce_mean_gradients(grads, group=None):
     return grads
 
 
+class GradientBuckets:
+    """Data-parallel gradient averaging OVERLAPPED with the backward pass (run/train.py:206 wraps the student in DistributedDataParallel,
+    whose reducer does this with autograd hooks; here the backward pass is the library's own, so it says itself when a gradient is done).
+    The gradients of a step live in a few flat buckets laid out in the ORDER THE BACKWARD PASS PRODUCES THEM (output layer first); the
+    weight-gradient kernels write straight into their slice (`view(name)` is the kernel's output buffer: no concatenation, no copy back),
+    and as soon as the last gradient of a bucket is `ready` its SUM all-reduce is launched asynchronously (RCCL's own stream, ordered
+    behind the producing kernels by the process group; on xGMI a 60-MB bucket is well under a layer's 4-5 ms of backward work), while the
+    next layers' data and weight gradients run.  `finish()` waits for the handles, scales by 1 / world size and returns name -> tensor.
+    order: list of (name, shape) in backward order.  Without a process group (or world size 1) nothing is launched."""
+
+    def __init__(self, order, device, group=None, bucket_bytes=64 << 20, dtype=torch.float32):
+        self.group, self.world = group, _world(group)
+        self.layout, self.buckets = {}, []
+        cur, cur_names, off = [], [], 0
+        item = torch.empty(0, dtype=dtype).element_size()
+
+        def close():
+            nonlocal cur, cur_names, off
+            if cur_names:
+                self.buckets.append({"flat": torch.empty(off, dtype=dtype, device=device), "names": cur_names, "pending": len(cur_names),
+                                     "work": None})
+            cur, cur_names, off = [], [], 0
+        for name, shape in order:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            n_al = (n + 63) // 64 * 64                                  # slices start on 256-byte boundaries (16-byte vector stores)
+            if cur_names and (off + n_al) * item > bucket_bytes:
+                close()
+            self.layout[name] = (len(self.buckets), off, n, tuple(int(d) for d in shape))
+            cur_names.append(name)
+            off += n_al
+        close()
+
+    def view(self, name):
+        """the slice of `name` (its shape): the buffer the gradient is to be written into"""
+        b, off, n, shape = self.layout[name]
+        return self.buckets[b]["flat"][off:off + n].view(shape)
+
+    def put(self, name, tensor):
+        """a gradient that was produced elsewhere: copied into its slice, then ready"""
+        self.view(name).copy_(tensor.reshape(self.layout[name][3]))
+        self.ready(name)
+
+    def ready(self, name):
+        """the kernels writing `name` are enqueued on the current stream; launches the bucket's all-reduce when it was its last"""
+        bk = self.buckets[self.layout[name][0]]
+        bk["pending"] -= 1
+        if bk["pending"] == 0 and self.world > 1:
+            import torch.distributed as dist
+            bk["work"] = dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """name -> averaged gradient (views of the buckets); every gradient must have been marked ready"""
+        for bk in self.buckets:
+            if bk["pending"] != 0:
+                raise RuntimeError(f"GradientBuckets.finish: {bk['pending']} gradient(s) of {bk['names']} were never marked ready")
+            if bk["work"] is not None:
+                bk["work"].wait()
+                bk["flat"].mul_(1.0 / self.world)
+        return {name: self.view(name) for name in self.layout}
+
+
 def _world(group=None):
     import torch.distributed as dist
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1

@@ -11,7 +11,8 @@ end, holding {'epoch', 'model_state_dict', 'optimizer_state_dict', 'tensorboard_
 
 Differences, on purpose: scenes, 2D-VLM outputs and the teacher's per-point features are synthetic (no datasets, X-Decoder
 or Sonata offline); with torch.distributed initialised every rank trains on its own scenes (the same number of steps per
-rank) and the student gradients are averaged by ONE bucketed all-reduce per step (sharding.allreduce_mean_gradients)
+rank) and the student gradients are averaged by bucketed all-reduces launched inside the backward pass (sharding.GradientBuckets; a
+model whose forward does not do that gets ONE all-reduce after backward: sharding.allreduce_mean_gradients)
 instead of DistributedDataParallel hooks.  As in the reference's multi-GPU recipe (run/train.py:212-213 converts the student
 to MinkowskiSyncBatchNorm), BatchNorm statistics and the backward reductions are taken over the rows of ALL ranks: four small
 fp64 all-reduces per BatchNorm layer and step (sharding.sync_batch_stats / sync_bwd_sums), so every rank holds the same
@@ -108,7 +109,7 @@ def train(model, optimizer, scheduler, loader, args, start_epoch=0, scalars=None
             optimizer.zero_grad()
             loss = model(batch)
             loss.backward()
-            if world > 1:
+            if world > 1 and not getattr(loss, "gradients_averaged", False):     # (training_forward averages inside its backward pass)
                 sharding.allreduce_mean_gradients({n: p.grad for n, p in student.named_parameters() if p.grad is not None})
             optimizer.step()
             scheduler.step()

@@ -160,23 +160,36 @@ class StudentTrainer:
         dx = ops.sparse_conv(dy, ctx["nbr_map"], w.flip(0).transpose(1, 2).contiguous())
         return dx if residual is None else dx + residual
 
-    def _wgrad(self, x, x_split, dy, ctx, cin, gs=None):
+    def _wgrad(self, x, x_split, dy, ctx, cin, gs=None, out=None):
         """dW[k] = x[in_k]^T @ dy[out_k]: matrix-core kernel (gp_conv_wgrad_f16x3) when the shapes allow (cin >= 256,
-        cout a multiple of 256), else library GEMMs on gathered rows."""
+        cout a multiple of 256), else library GEMMs on gathered rows.  out: the buffer to write it into (a gradient bucket's slice)."""
         cout = dy.shape[1]
         if self.fast and x_split is not None and cin >= 256 and cout % 256 == 0:
             ysplit, inv_s = gs if gs is not None else self._grad_split(dy)
-            return ops.conv_wgrad_f16x3(x_split, ysplit, ctx["wgrad_plan"], cin, cin, cout, inv_scale=inv_s)
+            return ops.conv_wgrad_f16x3(x_split, ysplit, ctx["wgrad_plan"], cin, cin, cout, inv_scale=inv_s, out=out)
         dw = torch.zeros((27, cin, cout), dtype=torch.float32, device=dy.device)
         for k, (out_rows, in_rows) in enumerate(ctx["offset_pairs"]):
             if out_rows.numel():
                 dw[k] = x[in_rows, :cin].t() @ dy[out_rows]
         return dw
 
+    def gradient_order(self):
+        """(name, shape) of every gradient in the order forward_backward produces them (the layout of sharding.GradientBuckets)"""
+        P = self.params
+        names = ["output_layer.kernel"]
+        for i in reversed(range(self.num_blocks)):
+            names += [f"res_blocks.{i}.norm2.bn.weight", f"res_blocks.{i}.norm2.bn.bias", f"res_blocks.{i}.conv2.kernel",
+                      f"res_blocks.{i}.norm1.bn.weight", f"res_blocks.{i}.norm1.bn.bias", f"res_blocks.{i}.conv1.kernel"]
+        names += ["input_layer.1.bn.weight", "input_layer.1.bn.bias", "input_layer.0.kernel"]
+        return [(n, tuple(P[n].shape)) for n in names]
+
     # ---- one scene: loss and gradients --------------------------------------------------------------
-    def forward_backward(self, X, nbr_map, sample_to_voxel, point_to_batch, num_anchors, num_negatives, update_running=True):
+    def forward_backward(self, X, nbr_map, sample_to_voxel, point_to_batch, num_anchors, num_negatives, update_running=True, grad_sink=None):
         """X fp32 [Nv, cin_pad] voxel inputs (rows in the order of nbr_map i32 [27,Nv]); sample_to_voxel i64 [S];
-        point_to_batch i64 [A*(2+Nn)].  Returns (loss 0-d device tensor, grads dict, embeddings [Nv, embed])."""
+        point_to_batch i64 [A*(2+Nn)].  Returns (loss 0-d device tensor, grads dict, embeddings [Nv, embed]).
+        grad_sink (sharding.GradientBuckets over gradient_order()): the weight gradients are written into its slices and every gradient is
+        announced the moment its kernels are enqueued, so that the buckets' all-reduces run beside the rest of the backward pass; the
+        returned dict then holds the slices -- LOCAL sums until grad_sink.finish() has averaged them."""
         P, B = self.params, self.buffers
         dev = X.device
         Nv = X.shape[0]
@@ -246,7 +259,18 @@ class StudentTrainer:
         loss, dE = ops.infonce_fwd_bwd(E, sample_to_voxel, point_to_batch, num_anchors, num_negatives, self.temperature)
 
         # ---------------- backward
-        g = {}
+        class _Grads(dict):                               # g[name] = tensor: into the sink's slice (copied unless it was written there)
+            def __setitem__(d, name, t):
+                if grad_sink is not None:
+                    v = grad_sink.view(name)
+                    if t.data_ptr() == v.data_ptr():
+                        grad_sink.ready(name)
+                    else:
+                        grad_sink.put(name, t)
+                    t = v
+                dict.__setitem__(d, name, t)
+        g = _Grads()
+        buf = (lambda name: grad_sink.view(name)) if grad_sink is not None else (lambda name: None)
         if dense_hip:
             # dW = h^T dE on the weight-gradient kernel: one "offset" whose pairs are the identity; the gradient rides in a
             # 256-column operand (columns >= embed are zero) because the kernel's tiles are 256 x 256
@@ -269,18 +293,19 @@ class StudentTrainer:
             dy2, dg2, db2, dz, sc2 = bn_bwd(dh, h_out, y2, st2, P[f"res_blocks.{i}.norm2.bn.weight"], want_dz=True)
             g[f"res_blocks.{i}.norm2.bn.weight"], g[f"res_blocks.{i}.norm2.bn.bias"] = dg2, db2
             gs2 = self._grad_split(dy2, sc2) if self.fast else None
-            g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, a1_s, dy2, ctx, self.hidden, gs2)
+            g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, a1_s, dy2, ctx, self.hidden, gs2, out=buf(f"res_blocks.{i}.conv2.kernel"))
             da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx, gs2)
             dy1, dg1, db1, _, sc1 = bn_bwd(da1, a1, y1, st1, P[f"res_blocks.{i}.norm1.bn.weight"])
             g[f"res_blocks.{i}.norm1.bn.weight"], g[f"res_blocks.{i}.norm1.bn.bias"] = dg1, db1
             gs1 = self._grad_split(dy1, sc1) if self.fast else None
-            g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1)
+            g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1, out=buf(f"res_blocks.{i}.conv1.kernel"))
             dh = self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1, residual=dz)
         h0 = blocks[0][0] if self.num_blocks else h
         dy0, dg0, db0, _, sc0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"])
         g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
-        g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad, self._grad_split(dy0, sc0) if self.fast else None)
-        return loss, g, E
+        g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad, self._grad_split(dy0, sc0) if self.fast else None,
+                                                out=buf("input_layer.0.kernel"))
+        return loss, dict(g), E
 
     # ---- optimizer ---------------------------------------------------------------------------------------
     def optimizer_step(self, grads):
@@ -296,7 +321,7 @@ class StudentTrainer:
 
     # ---- one scene of the reference's forward (everything after the lift) -------------------------------------
     def scene_step(self, F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, anchor_indices, num_negatives=63, K=96,
-                   optimize=True):
+                   optimize=True, grad_sink=None):
         """F_lift fp32 [N,D] lifted 2D features, gauss fp32 [N,6], inds_reconstruct i64 [N] point -> voxel row,
         coords_3d [Nv,3] integer voxel coordinates (float or int), xyz fp32 [N,3], F_teacher fp32 [N,Dt],
         anchor_indices i64 [A] (the reference's randperm draw).  Returns dict(loss, ...)."""
@@ -324,7 +349,9 @@ class StudentTrainer:
         ops.scatter_mean_csr(gauss[all_idx].contiguous(), GEO_DIM, order, seg, Nvs, X, col0=D)
         grid = ops.grid_build(cs)
         nbr_map = ops.kernel_map_build(grid, cs)
-        loss, grads, E = self.forward_backward(X, nbr_map, s2v, point_to_batch.contiguous(), A, num_negatives)
+        loss, grads, E = self.forward_backward(X, nbr_map, s2v, point_to_batch.contiguous(), A, num_negatives, grad_sink=grad_sink)
+        if grad_sink is not None:
+            grads = grad_sink.finish()                    # (averaged over the ranks; the all-reduces ran beside the backward pass)
         if optimize:
             self.optimizer_step(grads)
         return {"loss": loss, "grads": grads, "num_voxels": Nvs, "num_samples": int(all_idx.shape[0]), "positive": positive,
@@ -360,7 +387,12 @@ def training_forward(student_module, F_lift, gauss, inds_reconstruct, coords_3d,
     tr = StudentTrainer(student_module.state_dict(), dev, temperature=temperature,
                         bn_momentum=student_module.input_layer[1].bn.momentum, bn_eps=student_module.input_layer[1].bn.eps,
                         sync_bn=sharding._world() > 1)
-    out = tr.scene_step(F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, anchor_indices, num_negatives, K, optimize=False)
+    # data-parallel ranks (run/train.py:206 wraps the student in DDP): the gradients are averaged over the ranks by bucketed all-reduces
+    # launched INSIDE the backward pass (sharding.GradientBuckets); the loss tensor says so (`gradients_averaged`), train_driver.train
+    # then does not all-reduce again
+    sink = sharding.GradientBuckets(tr.gradient_order(), dev) if sharding._world() > 1 else None
+    out = tr.scene_step(F_lift, gauss, inds_reconstruct, coords_3d, xyz, F_teacher, anchor_indices, num_negatives, K, optimize=False,
+                        grad_sink=sink)
     names = [n for n in named if n in out["grads"]]
     grads = []
     for n in names:
@@ -374,7 +406,9 @@ def training_forward(student_module, F_lift, gauss, inds_reconstruct, coords_3d,
                 b.copy_(tr.buffers[k])
             elif k.endswith("num_batches_tracked"):
                 b += 1
-    return _LossWithGradients.apply(out["loss"], grads, *[named[n] for n in names])
+    loss = _LossWithGradients.apply(out["loss"], grads, *[named[n] for n in names])
+    loss.gradients_averaged = sink is not None
+    return loss
 
 
 class FusedAdamW(torch.optim.Optimizer):

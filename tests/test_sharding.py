@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -110,6 +111,61 @@ def test_two_rank_gradient_allreduce_is_the_mean():
     for r in range(2):
         for k in want:
             assert np.allclose(res[r][k], want[k], atol=1e-6)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    order = [("out.kernel", (8, 4)), ("b2.bn.weight", (8,)), ("b2.kernel", (27, 6, 8)), ("b1.bn.bias", (8,)), ("b1.kernel", (27, 6, 8)), ("in.kernel", (27, 5, 8))]
+    sink = sharding.GradientBuckets(order, "cpu", bucket_bytes=6000)          # 27*6*8*4 = 5184 bytes: several buckets
+    g = torch.Generator().manual_seed(200 + rank)
+    launched = []
+    for name, shape in order:
+        t = torch.randn(*shape, generator=g)
+        if name.endswith(".kernel") and name != "out.kernel":
+            sink.view(name).copy_(t)                                          # "the kernel wrote into the slice"
+            sink.ready(name)
+        else:
+            sink.put(name, t)
+        launched.append(sum(b["work"] is not None for b in sink.buckets))
+    out = sink.finish()
+    q.put((rank, len(sink.buckets), launched, {k: v.numpy().copy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_buckets_overlap_protocol():
+    """sharding.GradientBuckets: slices in backward order, a bucket's all-reduce launched the moment its last gradient is ready (before
+    the later gradients exist), finish() = the mean over the ranks; a gradient never announced is an error, one process is a pass-through."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    order = [("out.kernel", (8, 4)), ("b2.bn.weight", (8,)), ("b2.kernel", (27, 6, 8)), ("b1.bn.bias", (8,)), ("b1.kernel", (27, 6, 8)), ("in.kernel", (27, 5, 8))]
+    want = {}
+    for r in range(2):
+        g = torch.Generator().manual_seed(200 + r)
+        for k, shape in order:
+            want[k] = want.get(k, 0) + torch.randn(*shape, generator=g).numpy() / 2
+    for r in range(2):
+        assert res[r][1] >= 3                                                  # several buckets ...
+        assert res[r][2][-1] == res[r][1] and res[r][2][2] >= 1                 # ... the first launched while later gradients were still to come
+        for k in want:
+            assert res[r][3][k].shape == want[k].shape and np.allclose(res[r][3][k], want[k], atol=1e-6)
+    # one process: nothing to reduce, the slices come back as they were written; a forgotten gradient is an error
+    sink = sharding.GradientBuckets(order, "cpu")
+    for k, shape in order[:-1]:
+        sink.put(k, torch.full(shape, 2.0))
+    with pytest.raises(RuntimeError, match="never marked ready"):
+        sink.finish()
+    sink.put(order[-1][0], torch.full(order[-1][1], 3.0))
+    out = sink.finish()
+    assert float(out["b1.kernel"].sum()) == 2.0 * 27 * 6 * 8 and float(out["in.kernel"][0, 0, 0]) == 3.0
 
 
 def _syncbn_worker(rank, world, port, q):
