@@ -447,19 +447,35 @@ __device__ __forceinline__ unsigned long long sr_shfl_xor(unsigned long long v, 
     unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
-// f(index, key) over the elements of the groups whose minimum is at or below `bound`
-template <typename F>
-__device__ __forceinline__ void sr_walk(const float *__restrict__ row, int n, const unsigned *gmin, int ngroups, int lg, unsigned bound, F f) {
-    const int gsz = 4 << lg;
+// f(index, key) over the elements of the groups whose minimum is at or below `bound`; a group's float4s are loaded together
+template <int LG, typename F>
+__device__ __forceinline__ void sr_walk(const float *__restrict__ row, int n, bool vec, const unsigned *gmin, int ngroups, unsigned bound, F f) {
+    constexpr int gsz = 4 << LG, NB = (1 << LG) < 4 ? (1 << LG) : 4;             // float4s per batch
     for (int g = threadIdx.x; g < ngroups; g += SR_NT)
         if (gmin[g] <= bound) {
-            const int e0 = g * gsz, e1 = e0 + gsz < n ? e0 + gsz : n;
-            for (int i = e0; i < e1; ++i) f(i, sr_key(row[i]));
+            const int e0 = g * gsz;
+            if (vec && e0 + gsz <= n) {
+                for (int b = 0; b < (1 << LG); b += NB) {
+                    float4 a[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) a[u] = *reinterpret_cast<const float4 *>(row + e0 + 4 * (b + u));
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int i = e0 + 4 * (b + u);
+                        f(i, sr_key(a[u].x)); f(i + 1, sr_key(a[u].y)); f(i + 2, sr_key(a[u].z)); f(i + 3, sr_key(a[u].w));
+                    }
+                }
+            } else {
+                const int e1 = e0 + gsz < n ? e0 + gsz : n;
+                for (int i = e0; i < e1; ++i) f(i, sr_key(row[i]));
+            }
         }
 }
+template <int LG>
 __global__ void __launch_bounds__(SR_NT, 8)
-sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, const int64_t *__restrict__ anchor, int k,
+sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const int64_t *__restrict__ anchor, int k,
                       int64_t *__restrict__ positive, int64_t *__restrict__ macro) {
+    constexpr int lg = LG;
     __shared__ __align__(16) unsigned long long cand[SR_CAP];
     __shared__ unsigned gmin[SR_GROUPS];
     __shared__ __align__(16) unsigned s_min[SR_NT];
@@ -473,10 +489,39 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, 
     const int anc = (int)anchor[blockIdx.x];
     const int n4 = (n + 3) >> 2, ngroups = (n4 + (1 << lg) - 1) >> lg;
     // ---- the sweep
-    unsigned tmin = 0xffffffffu;
-    unsigned long long tmax = 0ull;
-#pragma unroll 4
-    for (int f0 = tid - lane; f0 < n4; f0 += SR_NT) {
+    unsigned tmin = 0xffffffffu, tmaxk = 0u;
+    int tmaxi = 0x7fffffff;                               // (a thread meets its elements in ascending index order: `>` keeps the lowest index)
+    auto slot = [&](int f, const float *v, bool full) {   // one float4 slot: elements 4 f .. 4 f + 3
+        const int i0 = 4 * f;
+        unsigned gk = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if ((full || i < n) && i != anc) {
+                const unsigned kx = sr_key(v[q]);
+                gk = kx < gk ? kx : gk;
+                if (kx > tmaxk) { tmaxk = kx; tmaxi = i; }
+            }
+        }
+        tmin = gk < tmin ? gk : tmin;
+#pragma unroll
+        for (int o = 1; o < (1 << LG); o <<= 1) { const unsigned t = __shfl_xor(gk, o, 64); gk = t < gk ? t : gk; }
+        if ((lane & ((1 << LG) - 1)) == 0 && (full || f < n4)) gmin[f >> LG] = gk;
+    };
+    int f0 = tid - lane;
+    if (vec) {
+        // four slots per thread and iteration, their loads issued together (one load in flight per wave left the sweep latency-bound:
+        // 2.1 TB/s); every slot of the iteration lies inside the row's complete float4s, so no element test
+        const int nfull = n >> 2;
+        for (; f0 + 3 * SR_NT + 64 <= nfull; f0 += 4 * SR_NT) {
+            float4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4 *>(row + 4 * (int64_t)(f0 + u * SR_NT + lane));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) slot(f0 + u * SR_NT + lane, reinterpret_cast<const float *>(&a[u]), true);
+        }
+    }
+    for (; f0 < n4; f0 += SR_NT) {                        // the row's end (and rows that cannot be read 16 bytes at a time)
         const int f = f0 + lane, i0 = 4 * f;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (vec && i0 + 3 < n) {
@@ -485,22 +530,10 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (i0 + q < n) v[q] = row[i0 + q];
         }
-        unsigned gk = 0xffffffffu;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q;
-            if (i < n && i != anc) {
-                const unsigned kx = sr_key(v[q]);
-                gk = kx < gk ? kx : gk;
-                const unsigned long long m = ((unsigned long long)kx << 32) | (unsigned)(0x7fffffff - i);
-                tmax = m > tmax ? m : tmax;
-            }
-        }
-        tmin = gk < tmin ? gk : tmin;
-        for (int o = 1; o < (1 << lg); o <<= 1) { const unsigned t = __shfl_xor(gk, o, 64); gk = t < gk ? t : gk; }
-        if ((lane & ((1 << lg) - 1)) == 0 && f < n4) gmin[f >> lg] = gk;
+        slot(f, v, false);
     }
     s_min[tid] = tmin;
+    unsigned long long tmax = ((unsigned long long)tmaxk << 32) | (unsigned)(0x7fffffff - tmaxi);     // highest key, then lowest index
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = sr_shfl_xor(tmax, o); tmax = t > tmax ? t : tmax; }
     if (lane == 0) s_red[tid >> 6] = tmax;
@@ -525,7 +558,7 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, 
     const int pos = s_pos;
     if (tid == 0) positive[blockIdx.x] = pos;
     // ---- collect the elements at or below the bound
-    sr_walk(row, n, gmin, ngroups, lg, bound, [&](int i, unsigned kx) {
+    sr_walk<LG>(row, n, vec, gmin, ngroups, bound, [&](int i, unsigned kx) {
         if (kx <= bound && i != anc && i != pos) {
             const int p = atomicAdd(&s_cnt, 1);
             if (p < SR_CAP) cand[p] = ((unsigned long long)kx << 32) | (unsigned)i;
@@ -542,7 +575,7 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, 
             shift -= width;
             for (int i = tid; i < SR_BINS; i += SR_NT) hist[i] = 0u;
             __syncthreads();
-            sr_walk(row, n, gmin, ngroups, lg, bound, [&](int i, unsigned kx) {
+            sr_walk<LG>(row, n, vec, gmin, ngroups, bound, [&](int i, unsigned kx) {
                 if (kx <= bound && i != anc && i != pos) {
                     const unsigned long long key = ((unsigned long long)kx << 32) | (unsigned)i;
                     if (level == 0 || (key >> (shift + width)) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & ((1u << width) - 1u)], 1u);
@@ -565,7 +598,7 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, int lg, 
             __syncthreads();                              // (the histogram shares the candidates' memory: everyone has read s_* before it is reused)
             if (done) break;                              // the last level's bins hold one key each: acc + 1 <= k
         }
-        sr_walk(row, n, gmin, ngroups, lg, bound, [&](int i, unsigned kx) {
+        sr_walk<LG>(row, n, vec, gmin, ngroups, bound, [&](int i, unsigned kx) {
             if (kx <= bound && i != anc && i != pos) {
                 const unsigned long long key = ((unsigned long long)kx << 32) | (unsigned)i;
                 if ((key >> shift) <= prefix) { const int p = atomicAdd(&s_cnt, 1); if (p < SR_CAP) cand[p] = key; }
@@ -801,7 +834,10 @@ extern "C" int gp_sampler_select(const float *sim, int64_t ld, int64_t num_ancho
                  "gp_sampler_select: k=%d, n=%lld out of range (1 <= k < %d, k + 2 <= n <= %d)", k, (long long)n, SR_NT, SR_GROUPS * 256);
     int lg = 0;                                             // 4 << lg elements per group: the fewest that fit the row's groups into LDS
     while ((((n + 3) >> 2) + (1 << lg) - 1) >> lg > SR_GROUPS) ++lg;
-    sampler_select_kernel<<<(unsigned)num_anchors, SR_NT, 0, gp_stream(stream_)>>>(sim, ld, (int)n, lg, anchor_idx, k, positive, macro);
+    hipStream_t s = gp_stream(stream_);
+#define SR_LAUNCH(L) case L: sampler_select_kernel<L><<<(unsigned)num_anchors, SR_NT, 0, s>>>(sim, ld, (int)n, anchor_idx, k, positive, macro); break;
+    switch (lg) { SR_LAUNCH(0) SR_LAUNCH(1) SR_LAUNCH(2) SR_LAUNCH(3) SR_LAUNCH(4) SR_LAUNCH(5) SR_LAUNCH(6) default: break; }
+#undef SR_LAUNCH
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
