@@ -57,12 +57,20 @@ def one_step(ev=None):
 out = one_step()
 torch.cuda.synchronize()
 print(f"N={N} sampled points={out['num_samples']} sampled voxels={out['num_voxels']} loss={float(out['loss']):.4f}", flush=True)
+for _ in range(2):                                   # the anchors -- and with them the voxel count and every buffer size -- change per step:
+    one_step()                                       # two more steps let the caching allocator see the sizes before the clock starts
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 ev = Ev()
+ends = []
 for _ in range(steps):
     out = one_step(ev if _ == steps - 1 else None)
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    ends.append(e)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f"{dt * 1e3:.1f} ms/step = {1 / dt:.2f} steps/s; last loss {float(out['loss']):.4f}")
+print("   per step (GPU clock between the steps' ends): " + " ".join(f"{a.elapsed_time(b):.1f}" for a, b in zip(ends[:-1], ends[1:])))
 for k, v in ev.table().items():
     print(f"   {k:40s} {v:8.2f} ms")
