@@ -101,6 +101,18 @@ __global__ void __launch_bounds__(CF_WAVES * 64) cs_final_kernel(const double *_
 }
 
 // ------------------------------------------------------------------------------------------------ BN forward / backward
+// Row sweeps of the BatchNorm kernels: the launch has a multiple of c / W threads, so a thread keeps ITS W columns for every row it visits --
+// the per-column constants (mean, 1/std, gamma, beta, the backward sums) are loaded once, the loop is loads, a few multiply-adds and stores.
+// (Per-element index arithmetic and per-element loads of the column vectors made bn_bwd_apply 390 us for 1.2 GB; this form: see DESIGN 10.)
+__host__ __device__ inline unsigned bn_sweep_blocks(int64_t nv, int cw) {
+    int g = 256, x = cw;
+    while (x) { const int t = g % x; g = x; x = t; }      // gcd(256, cw)
+    const int64_t m = cw / g;                             // blocks must be a multiple of m for 256 * blocks % cw == 0
+    int64_t want = (nv * cw + 255) / 256;
+    want = want < 4096 ? want : 4096;
+    int64_t blocks = want / m * m;
+    return (unsigned)(blocks < m ? m : blocks);
+}
 template <int W>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, const float *__restrict__ mean,
@@ -109,10 +121,13 @@ bn_apply_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, cons
                 _Float16 *__restrict__ out_hi, _Float16 *__restrict__ out_lo, int64_t ld_sp) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int cw = c / W;
-    const int64_t total = nv * cw;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / cw;
-        const int col = (int)(i - r * cw) * W;
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int col = (int)(t % cw) * W;
+    const int64_t rstep = nthreads / cw;
+    float mu[W], is[W], ga[W], be[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { mu[k] = mean[col + k]; is[k] = 1.0f / sqrtf(var[col + k] + eps); ga[k] = gamma[col + k]; be[k] = beta[col + k]; }
+    for (int64_t r = t / cw; r < nv; r += rstep) {
         float yv[W], rv[W], v[W];
         if (W == 4) {
             *reinterpret_cast<float4 *>(yv) = *reinterpret_cast<const float4 *>(y + r * ld + col);
@@ -123,13 +138,14 @@ bn_apply_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, cons
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const float invstd = 1.0f / sqrtf(var[col + k] + eps);
-            v[k] = (yv[k] - mean[col + k]) * invstd * gamma[col + k] + beta[col + k];
+            v[k] = (yv[k] - mu[k]) * is[k] * ga[k] + be[k];
             if (residual) v[k] += rv[k];
             if (relu) v[k] = v[k] > 0.f ? v[k] : 0.f;
         }
-        if (W == 4) *reinterpret_cast<float4 *>(out + r * ld_out + col) = *reinterpret_cast<const float4 *>(v);
-        else out[r * ld_out + col] = v[0];
+        if (out) {                                          // (nullptr: only the split planes -- a layer whose backward mask comes from y)
+            if (W == 4) *reinterpret_cast<float4 *>(out + r * ld_out + col) = *reinterpret_cast<const float4 *>(v);
+            else out[r * ld_out + col] = v[0];
+        }
         if (out_hi) {
             if (W == 4) {
                 f16x4 h, l;
@@ -153,14 +169,21 @@ __global__ void bn_running_kernel(const float *__restrict__ mean, const float *_
     running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mean[i];
     running_var[i] = (1.f - momentum) * running_var[i] + momentum * unbiased;
 }
-// dz = dout * (act > 0) (act == nullptr: no mask); sums of dz and dz * xhat
+// dz = dout * mask; sums of dz and dz * xhat.  The mask of the ReLU behind the layer: act > 0 (act = the layer's fp32 output), or -- act ==
+// nullptr and beta_m given, a layer WITHOUT a residual -- recomputed from y: (y - mean) * invstd * gamma + beta > 0, the expression
+// bn_apply_kernel evaluated (same operations in the same order: the same float), which saves reading the 232-MB activation here and in
+// bn_bwd_apply_kernel and lets the forward pass skip writing it; both nullptr: no mask.
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
                                                             const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean,
-                                                            const float *__restrict__ var, float eps, int64_t nv, int c, double *__restrict__ partial) {
+                                                            const float *__restrict__ var, float eps, const float *__restrict__ gamma_m,
+                                                            const float *__restrict__ beta_m, int64_t nv, int c, double *__restrict__ partial) {
     col_partial<2>(nv, c, partial, [&](int64_t r, int col, double *v) {
         float dz = dout[r * ld_d + col];
-        if (act && !(act[r * ld_a + col] > 0.f)) dz = 0.f;
-        float xhat = (y[r * ld_y + col] - mean[col]) * (1.0f / sqrtf(var[col] + eps));
+        const float invstd = 1.0f / sqrtf(var[col] + eps);
+        const float yv = y[r * ld_y + col];
+        if (act) { if (!(act[r * ld_a + col] > 0.f)) dz = 0.f; }
+        else if (beta_m) { if (!((yv - mean[col]) * invstd * gamma_m[col] + beta_m[col] > 0.f)) dz = 0.f; }
+        float xhat = (yv - mean[col]) * invstd;
         v[0] = (double)dz;
         v[1] = (double)dz * (double)xhat;
     });
@@ -171,15 +194,22 @@ template <int W>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
                     const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean, const float *__restrict__ var,
-                    float eps, const float *__restrict__ gamma, const float *__restrict__ sums, int64_t n_total, int64_t nv, int c,
-                    float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dz_out, int64_t ld_dz, unsigned *__restrict__ amax_bits) {
+                    float eps, const float *__restrict__ gamma, const float *__restrict__ beta_m, const float *__restrict__ sums, int64_t n_total,
+                    int64_t nv, int c, float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dz_out, int64_t ld_dz,
+                    unsigned *__restrict__ amax_bits) {
     const int cw = c / W;
-    const int64_t total = nv * cw;
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int col = (int)(t % cw) * W;
+    const int64_t rstep = nthreads / cw;
     const float inv_n = 1.0f / (float)n_total;
+    float mu[W], is[W], ga[W], be[W], s1[W], s2[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        mu[k] = mean[col + k]; is[k] = 1.0f / sqrtf(var[col + k] + eps); ga[k] = gamma[col + k]; be[k] = beta_m ? beta_m[col + k] : 0.f;
+        s1[k] = sums[col + k] * inv_n; s2[k] = sums[c + col + k] * inv_n;
+    }
     float m = 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / cw;
-        const int col = (int)(i - r * cw) * W;
+    for (int64_t r = t / cw; r < nv; r += rstep) {
         float dz[W], yv[W], av[W], o[W];
         if (W == 4) {
             *reinterpret_cast<float4 *>(dz) = *reinterpret_cast<const float4 *>(dout + r * ld_d + col);
@@ -192,10 +222,10 @@ bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d, const float *_
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            if (act && !(av[k] > 0.f)) dz[k] = 0.f;
-            const float invstd = 1.0f / sqrtf(var[col + k] + eps);
-            const float xhat = (yv[k] - mean[col + k]) * invstd;
-            o[k] = gamma[col + k] * invstd * (dz[k] - sums[col + k] * inv_n - xhat * sums[c + col + k] * inv_n);
+            if (act) { if (!(av[k] > 0.f)) dz[k] = 0.f; }
+            else if (beta_m) { if (!((yv[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f)) dz[k] = 0.f; }
+            const float xhat = (yv[k] - mu[k]) * is[k];
+            o[k] = ga[k] * is[k] * (dz[k] - s1[k] - xhat * s2[k]);
             m = fmaxf(m, fabsf(o[k]));
         }
         if (W == 4) {
@@ -224,17 +254,16 @@ __global__ void bn_scale2_kernel(float *__restrict__ scale2) {
     scale2[1] = 1.f / s;
 }
 static int bn_bwd_apply_launch(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y, const float *mean,
-                               const float *var, float eps, const float *gamma, const float *sums, int64_t n_total, int64_t nv, int c, float *dy,
+                               const float *var, float eps, const float *gamma, const float *beta_m, const float *sums, int64_t n_total, int64_t nv, int c, float *dy,
                                int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2, hipStream_t s) {
     if (dy_scale2) GP_CHECK_HIP(hipMemsetAsync(dy_scale2, 0, 8, s));
     unsigned *bits = reinterpret_cast<unsigned *>(dy_scale2);
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = c % 4 == 0 && ld_dout % 4 == 0 && ld_y % 4 == 0 && ld_dy % 4 == 0 && (!act || ld_act % 4 == 0) && (!dz_out || ld_dz % 4 == 0) &&
                      al16(dout) && al16(y) && al16(dy) && al16(act) && al16(dz_out);
-    const int64_t items = nv * (vec ? c / 4 : c);
-    const unsigned blocks = (unsigned)(items / 256 + 1 < 4096 ? items / 256 + 1 : 4096);
-    if (vec) bn_bwd_apply_kernel<4><<<blocks, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, bits);
-    else bn_bwd_apply_kernel<1><<<blocks, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, bits);
+    const unsigned blocks = bn_sweep_blocks(nv, vec ? c / 4 : c);
+    if (vec) bn_bwd_apply_kernel<4><<<blocks, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_m, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, bits);
+    else bn_bwd_apply_kernel<1><<<blocks, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_m, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, bits);
     if (dy_scale2) bn_scale2_kernel<<<1, 1, 0, s>>>(dy_scale2);
     return GP_OK;
 }
@@ -780,25 +809,28 @@ extern "C" int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c
 }
 // the two reduction vectors of the BatchNorm backward pass as fp64 sums: sums[0:c] = sum dz, sums[c:2c] = sum dz * xhat
 extern "C" int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
-                                  const float *mean, const float *var, float eps, int64_t nv, int32_t c, double *sums,
-                                  void *workspace, size_t workspace_bytes, void *stream_) {
+                                  const float *mean, const float *var, float eps, const float *gamma_mask, const float *beta_mask, int64_t nv,
+                                  int32_t c, double *sums, void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(dout && y && mean && var && sums && workspace && nv > 0 && c > 0, "gp_bn_bwd_sums_f64: null/empty argument");
+    GP_CHECK_ARG(!beta_mask || (gamma_mask && !act), "gp_bn_bwd_sums_f64: the mask comes from act OR from y (gamma_mask + beta_mask)");
     if (workspace_bytes < gp_col_stats_workspace_bytes(nv, c)) { gp_set_error("gp_bn_bwd_sums_f64: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     double *partial = static_cast<double *>(workspace);
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
+    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial);
     cs_final_f64_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, sums);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
 // dy = gamma/sqrt(var+eps) * (dz - sums[col]/n_total - xhat * sums[c+col]/n_total) with caller-supplied (all-reduced) sums
 extern "C" int gp_bn_bwd_apply(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
-                               const float *mean, const float *var, float eps, const float *gamma, const float *sums, int64_t n_total,
-                               int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2, void *stream_) {
+                               const float *mean, const float *var, float eps, const float *gamma, const float *beta_mask, const float *sums,
+                               int64_t n_total, int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2,
+                               void *stream_) {
     GP_CHECK_ARG(dout && y && mean && var && gamma && sums && dy && nv > 0 && c > 0 && n_total >= nv, "gp_bn_bwd_apply: bad argument");
-    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2,
+    GP_CHECK_ARG(!beta_mask || !act, "gp_bn_bwd_apply: the mask comes from act OR from y (beta_mask)");
+    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, sums, n_total, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2,
                                  gp_stream(stream_));
     if (rc != GP_OK) return rc;
     GP_CHECK_LAUNCH();
@@ -810,14 +842,13 @@ extern "C" int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t
                                  const float *gamma, const float *beta, float eps, const float *residual, int64_t ld_res,
                                  int32_t relu, float *out, int64_t ld_out, void *out_hi, void *out_lo, int64_t ld_split,
                                  float momentum, float *running_mean, float *running_var, void *stream_) {
-    GP_CHECK_ARG(y && mean && var && gamma && beta && out && nv > 0 && c > 0, "gp_bn_train_apply: null/empty argument");
+    GP_CHECK_ARG(y && mean && var && gamma && beta && (out || out_hi) && nv > 0 && c > 0, "gp_bn_train_apply: null/empty argument");
     GP_CHECK_ARG((out_hi == nullptr) == (out_lo == nullptr), "gp_bn_train_apply: split outputs come as a pair");
     hipStream_t s = gp_stream(stream_);
     auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    const bool vec = c % 4 == 0 && ld % 4 == 0 && ld_out % 4 == 0 && (!residual || ld_res % 4 == 0) && (!out_hi || ld_split % 4 == 0) && al(y, 16) &&
+    const bool vec = c % 4 == 0 && ld % 4 == 0 && (!out || ld_out % 4 == 0) && (!residual || ld_res % 4 == 0) && (!out_hi || ld_split % 4 == 0) && al(y, 16) &&
                      al(out, 16) && al(residual, 16) && al(out_hi, 8) && al(out_lo, 8);
-    const int64_t items = nv * (vec ? c / 4 : c);
-    const unsigned blocks = (unsigned)(items / 256 + 1 < 4096 ? items / 256 + 1 : 4096);
+    const unsigned blocks = bn_sweep_blocks(nv, vec ? c / 4 : c);
     if (vec) bn_apply_kernel<4><<<blocks, 256, 0, s>>>(y, ld, nv, c, mean, var, gamma, beta, eps, residual, ld_res, relu, out, ld_out,
                                                      static_cast<_Float16 *>(out_hi), static_cast<_Float16 *>(out_lo), ld_split);
     else bn_apply_kernel<1><<<blocks, 256, 0, s>>>(y, ld, nv, c, mean, var, gamma, beta, eps, residual, ld_res, relu, out, ld_out,
@@ -831,11 +862,12 @@ extern "C" int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t
 // dz = dout * (act > 0) (act NULL: dz = dout); dgamma = sum dz*xhat, dbeta = sum dz;
 // dy = gamma/sqrt(var+eps) * (dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) receives dz (identity branch)
 extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
-                                    const float *mean, const float *var, float eps, const float *gamma, int64_t nv, int32_t c,
+                                    const float *mean, const float *var, float eps, const float *gamma, const float *beta_mask, int64_t nv, int32_t c,
                                     float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dgamma, float *dbeta, float *dy_scale2,
                                     void *workspace, size_t workspace_bytes, void *stream_) {
     GP_CHECK_ARG(dout && y && mean && var && gamma && dy && dgamma && dbeta && workspace && nv > 0 && c > 0,
                  "gp_bn_train_backward: null/empty argument");
+    GP_CHECK_ARG(!beta_mask || !act, "gp_bn_train_backward: the mask comes from act OR from y (beta_mask)");
     size_t need = gp_col_stats_workspace_bytes(nv, c) + gp_align_up((size_t)2 * c * sizeof(float), 256);
     if (workspace_bytes < need) { gp_set_error("gp_bn_train_backward: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
@@ -843,9 +875,9 @@ extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const fl
     float *sums = reinterpret_cast<float *>(static_cast<char *>(workspace) + gp_col_stats_workspace_bytes(nv, c));
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, nv, c, partial);
+    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial);
     cs_final_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, 1.0, sums);
-    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, sums, nv, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2, s);
+    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, sums, nv, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2, s);
     if (rc != GP_OK) return rc;
     GP_CHECK_HIP(hipMemcpyAsync(dbeta, sums, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));
     GP_CHECK_HIP(hipMemcpyAsync(dgamma, sums + c, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));

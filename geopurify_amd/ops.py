@@ -1059,19 +1059,21 @@ def col_sums_f64(y, c=None, mean=None):
     return out
 
 
-def bn_bwd_sums_f64(dout, act, y, mean, var, eps):
-    """fp64 [2c]: sum dz | sum dz * xhat over this rank's rows (dz = dout masked by act > 0)."""
+def bn_bwd_sums_f64(dout, act, y, mean, var, eps, mask_affine=None):
+    """fp64 [2c]: sum dz | sum dz * xhat over this rank's rows (dz = dout masked by act > 0, or -- act None, mask_affine = (gamma, beta) --
+    by the sign of the normalised, affine y: see bn_train_backward)."""
     lib = _lib.load()
     nv, c = y.shape[0], mean.shape[0]
     ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c), y.device)
     sums = torch.empty(2 * c, dtype=torch.float64, device=y.device)
     check(lib.gp_bn_bwd_sums_f64(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y), y.stride(0),
-                                 _ptr(mean), _ptr(var), float(eps), nv, int(c), _ptr(sums), _ptr(ws), ws.numel(), _stream()),
+                                 _ptr(mean), _ptr(var), float(eps), _ptr(mask_affine[0]) if mask_affine else None,
+                                 _ptr(mask_affine[1]) if mask_affine else None, nv, int(c), _ptr(sums), _ptr(ws), ws.numel(), _stream()),
           "gp_bn_bwd_sums_f64")
     return sums
 
 
-def bn_bwd_apply(dout, act, y, mean, var, eps, gamma, sums_f32, n_total, want_dz=False, dy_scale2=None):
+def bn_bwd_apply(dout, act, y, mean, var, eps, gamma, sums_f32, n_total, want_dz=False, dy_scale2=None, beta_mask=None):
     """dy (and dz) of the BatchNorm backward pass from reduction vectors taken over n_total rows (all ranks).
     dy_scale2 (fp32 [2] device tensor): receives pow2_scale(dy) from the same sweep."""
     lib = _lib.load()
@@ -1079,29 +1081,33 @@ def bn_bwd_apply(dout, act, y, mean, var, eps, gamma, sums_f32, n_total, want_dz
     dy = torch.empty((nv, c), dtype=torch.float32, device=y.device)
     dz = torch.empty((nv, c), dtype=torch.float32, device=y.device) if want_dz else None
     check(lib.gp_bn_bwd_apply(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y), y.stride(0),
-                              _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(sums_f32), int(n_total), nv, int(c), _ptr(dy), dy.stride(0),
+                              _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(beta_mask), _ptr(sums_f32), int(n_total), nv, int(c), _ptr(dy), dy.stride(0),
                               _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dy_scale2), _stream()), "gp_bn_bwd_apply")
     return (dy, dz) if want_dz else dy
 
 
 def bn_train_apply(y, mean, var, gamma, beta, eps, residual=None, relu=True, want_split=False, momentum=0.1,
-                   running_mean=None, running_var=None):
+                   running_mean=None, running_var=None, want_f32=True):
+    """(out fp32 | None, (hi, lo) | None).  want_f32=False (with want_split): only the split planes are written -- for a layer whose
+    backward pass takes its ReLU mask from y (bn_train_backward(beta_mask=))."""
     lib = _lib.load()
     nv, c = y.shape[0], mean.shape[0]
-    out = torch.empty((nv, c), dtype=torch.float32, device=y.device)
+    assert want_f32 or want_split
+    out = torch.empty((nv, c), dtype=torch.float32, device=y.device) if want_f32 else None
     hi = lo = None
     if want_split:
         hi = torch.empty((nv, c), dtype=torch.float16, device=y.device)
         lo = torch.empty((nv, c), dtype=torch.float16, device=y.device)
     check(lib.gp_bn_train_apply(_ptr(y), y.stride(0), nv, int(c), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps),
                                 _ptr(residual), residual.stride(0) if residual is not None else 0, int(bool(relu)), _ptr(out),
-                                out.stride(0), _ptr(hi), _ptr(lo), hi.stride(0) if hi is not None else 0, float(momentum),
+                                out.stride(0) if out is not None else 0, _ptr(hi), _ptr(lo), hi.stride(0) if hi is not None else 0, float(momentum),
                                 _ptr(running_mean), _ptr(running_var), _stream()), "gp_bn_train_apply")
     return out, ((hi, lo) if want_split else None)
 
 
-def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False, dy_scale2=None):
-    """Returns dy, dgamma, dbeta (, dz).  act: post-ReLU activation (mask) or None.
+def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False, dy_scale2=None, beta_mask=None):
+    """Returns dy, dgamma, dbeta (, dz).  act: post-ReLU activation (mask) or None; act None and beta_mask = the layer's beta: the mask of a
+    layer WITHOUT a residual recomputed from y ((y - mean) * invstd * gamma + beta > 0: the float the forward pass evaluated).
     dy_scale2 (fp32 [2] device tensor): receives pow2_scale(dy) from the sweep that writes dy."""
     lib = _lib.load()
     nv, c = y.shape[0], mean.shape[0]
@@ -1112,7 +1118,7 @@ def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False, dy_sca
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c) + 2 * c * 4 + 512, dev)
     check(lib.gp_bn_train_backward(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y),
-                                   y.stride(0), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), nv, int(c), _ptr(dy), dy.stride(0),
+                                   y.stride(0), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(beta_mask), nv, int(c), _ptr(dy), dy.stride(0),
                                    _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dgamma), _ptr(dbeta), _ptr(dy_scale2), _ptr(ws),
                                    ws.numel(), _stream()), "gp_bn_train_backward")
     return (dy, dgamma, dbeta, dz) if want_dz else (dy, dgamma, dbeta)

@@ -212,32 +212,40 @@ class StudentTrainer:
         mom = self.bn_momentum
         n_all = sharding.sync_row_count(Nv, dev, self.group) if self.sync_bn else Nv       # one count per step, not one per layer
 
-        def bn_fwd(y, prefix, residual=None, want_split=True):
+        def bn_fwd(y, prefix, residual=None, want_split=True, want_f32=True):
+            """(out fp32 | None, planes, statistics).  want_f32=False: a layer without a residual whose fp32 output nothing reads -- the next
+            convolution and the weight gradient take the planes, the backward pass recomputes the ReLU mask from y (bn_bwd(beta=))"""
+            want_f32 = want_f32 or not (want_split and self.fast)
             rm, rv = (B[prefix + ".bn.running_mean"], B[prefix + ".bn.running_var"]) if update_running else (None, None)
             if self.sync_bn:
                 c = y.shape[1]
                 mean, var, n_tot = sharding.sync_batch_stats(lambda m: ops.col_sums_f64(y, c, m), y.shape[0], c, dev, self.group,
                                                              n_total=n_all)
                 out, sp = ops.bn_train_apply(y, mean, var, P[prefix + ".bn.weight"], P[prefix + ".bn.bias"], self.bn_eps, residual=residual,
-                                             relu=True, want_split=want_split and self.fast, momentum=mom)
+                                             relu=True, want_split=want_split and self.fast, momentum=mom, want_f32=want_f32)
                 if rm is not None:
                     sharding.sync_running_stats(rm, rv, mean, var, n_tot, mom)
                 return out, sp, (mean, var, n_tot)
             mean, var = ops.col_stats(y)
             out, sp = ops.bn_train_apply(y, mean, var, P[prefix + ".bn.weight"], P[prefix + ".bn.bias"], self.bn_eps, residual=residual,
-                                         relu=True, want_split=want_split and self.fast, momentum=mom, running_mean=rm, running_var=rv)
+                                         relu=True, want_split=want_split and self.fast, momentum=mom, running_mean=rm, running_var=rv,
+                                         want_f32=want_f32)
             return out, sp, (mean, var)
 
-        def bn_bwd(dout, act, y, st, gamma, want_dz=False):
-            """(dy, dgamma, dbeta, dz | None, scale2 of dy | None); with SyncBatchNorm the dy formula uses the reductions over all ranks"""
+        def bn_bwd(dout, act, y, st, gamma, want_dz=False, beta=None):
+            """(dy, dgamma, dbeta, dz | None, scale2 of dy | None); with SyncBatchNorm the dy formula uses the reductions over all ranks.
+            beta (a layer without a residual): the ReLU mask comes from y, act is not read"""
+            if beta is not None:
+                act = None
             sc2 = torch.empty(2, dtype=torch.float32, device=dev) if self.fast else None
             if self.sync_bn:
                 c = st[0].shape[0]
-                g_sums, l_sums = sharding.sync_bwd_sums(ops.bn_bwd_sums_f64(dout, act, y, st[0], st[1], self.bn_eps), self.group)
-                r = ops.bn_bwd_apply(dout, act, y, st[0], st[1], self.bn_eps, gamma, g_sums, st[2], want_dz=want_dz, dy_scale2=sc2)
+                g_sums, l_sums = sharding.sync_bwd_sums(ops.bn_bwd_sums_f64(dout, act, y, st[0], st[1], self.bn_eps,
+                                                                            mask_affine=(gamma, beta) if beta is not None else None), self.group)
+                r = ops.bn_bwd_apply(dout, act, y, st[0], st[1], self.bn_eps, gamma, g_sums, st[2], want_dz=want_dz, dy_scale2=sc2, beta_mask=beta)
                 dy, dz = r if want_dz else (r, None)
                 return dy, l_sums[c:].clone(), l_sums[:c].clone(), dz, sc2
-            r = ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz, dy_scale2=sc2)
+            r = ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz, dy_scale2=sc2, beta_mask=beta)
             return r[0], r[1], r[2], (r[3] if want_dz else None), sc2
 
         # ---------------- forward (activations kept for the backward pass)
@@ -248,7 +256,7 @@ class StudentTrainer:
         blocks = []
         for i in range(self.num_blocks):
             y1 = self._conv(h, hs, P[f"res_blocks.{i}.conv1.kernel"], ctx)
-            a1, a1s, st1 = bn_fwd(y1, f"res_blocks.{i}.norm1")
+            a1, a1s, st1 = bn_fwd(y1, f"res_blocks.{i}.norm1", want_f32=False)
             y2 = self._conv(a1, a1s, P[f"res_blocks.{i}.conv2.kernel"], ctx)
             h2, h2s, st2 = bn_fwd(y2, f"res_blocks.{i}.norm2", residual=h)
             blocks.append((h, y1, a1, st1, y2, st2, h2, hs, a1s))
@@ -295,13 +303,13 @@ class StudentTrainer:
             gs2 = self._grad_split(dy2, sc2) if self.fast else None
             g[f"res_blocks.{i}.conv2.kernel"] = self._wgrad(a1, a1_s, dy2, ctx, self.hidden, gs2, out=buf(f"res_blocks.{i}.conv2.kernel"))
             da1 = self._dgrad(dy2, P[f"res_blocks.{i}.conv2.kernel"], ctx, gs2)
-            dy1, dg1, db1, _, sc1 = bn_bwd(da1, a1, y1, st1, P[f"res_blocks.{i}.norm1.bn.weight"])
+            dy1, dg1, db1, _, sc1 = bn_bwd(da1, a1, y1, st1, P[f"res_blocks.{i}.norm1.bn.weight"], beta=P[f"res_blocks.{i}.norm1.bn.bias"])
             g[f"res_blocks.{i}.norm1.bn.weight"], g[f"res_blocks.{i}.norm1.bn.bias"] = dg1, db1
             gs1 = self._grad_split(dy1, sc1) if self.fast else None
             g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1, out=buf(f"res_blocks.{i}.conv1.kernel"))
             dh = self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1, residual=dz)
         h0 = blocks[0][0] if self.num_blocks else h
-        dy0, dg0, db0, _, sc0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"])
+        dy0, dg0, db0, _, sc0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"], beta=P["input_layer.1.bn.bias"])
         g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
         g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad, self._grad_split(dy0, sc0) if self.fast else None,
                                                 out=buf("input_layer.0.kernel"))

@@ -507,19 +507,21 @@ int gp_iou_hist_i64(const int64_t *pred, const int64_t *target, int64_t n, int32
 size_t gp_col_stats_workspace_bytes(int64_t nv, int32_t c);
 int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, float *mean, float *var,
                  void *workspace, size_t workspace_bytes, void *stream);
-/* out = [relu]((y-mean)/sqrt(var+eps)*gamma + beta [+ residual]); out_hi/out_lo: optional split f16 */
+/* out = [relu]((y-mean)/sqrt(var+eps)*gamma + beta [+ residual]) (out nullable when the planes are asked for); out_hi/out_lo: optional split f16 */
 /* copy for the next convolution; running_mean/var (nullable) <- (1-m)*running + m*batch (unbiased var). */
 int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, const float *var,
                       const float *gamma, const float *beta, float eps, const float *residual, int64_t ld_res,
                       int32_t relu, float *out, int64_t ld_out, void *out_hi, void *out_lo, int64_t ld_split,
                       float momentum, float *running_mean, float *running_var, void *stream);
-/* dz = dout*(act>0) (act NULL: no mask); dgamma = sum dz*xhat; dbeta = sum dz;                       */
+/* dz = dout*mask; dgamma = sum dz*xhat; dbeta = sum dz.  mask: act > 0 (act = the layer's fp32 output); or act NULL and beta_mask given -- a */
+/* layer without a residual -- recomputed from y as (y-mean)/sqrt(var+eps)*gamma + beta_mask > 0, the value gp_bn_train_apply evaluated (the  */
+/* same float: the activation is then neither read here nor, with out = NULL in gp_bn_train_apply, ever written); both NULL: no mask.        */
 /* dy = gamma/sqrt(var+eps)*(dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) <- dz.                */
 /* dy_scale2 (nullable, 2 floats on the device) <- [s, 1/s] of gp_pow2_scale(dy), taken inside the sweep that writes dy: */
 /* the scale of the gradient's f16 split (gp_split_f16_scaled) without another pass over it.                           */
 /* workspace: gp_col_stats_workspace_bytes(nv, c) + 2*c*4 (rounded up to 256).                        */
 int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y,
-                         int64_t ld_y, const float *mean, const float *var, float eps, const float *gamma,
+                         int64_t ld_y, const float *mean, const float *var, float eps, const float *gamma, const float *beta_mask,
                          int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz,
                          float *dgamma, float *dbeta, float *dy_scale2, void *workspace, size_t workspace_bytes, void *stream);
 /* SyncBatchNorm pieces (run/train.py:212-213 converts the student to MinkowskiSyncBatchNorm; geopurify_amd/sharding.py     */
@@ -530,11 +532,12 @@ int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, i
 int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c, const float *mean, double *out, void *workspace,
                     size_t workspace_bytes, void *stream);
 int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
-                       const float *mean, const float *var, float eps, int64_t nv, int32_t c, double *sums, void *workspace,
-                       size_t workspace_bytes, void *stream);
+                       const float *mean, const float *var, float eps, const float *gamma_mask, const float *beta_mask, int64_t nv, int32_t c,
+                       double *sums, void *workspace, size_t workspace_bytes, void *stream);
 int gp_bn_bwd_apply(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
-                    const float *mean, const float *var, float eps, const float *gamma, const float *sums, int64_t n_total,
-                    int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2, void *stream);
+                    const float *mean, const float *var, float eps, const float *gamma, const float *beta_mask, const float *sums,
+                    int64_t n_total, int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dy_scale2,
+                    void *stream);
 /* InfoNCE (affinity_module.py:1219-1233) forward + backward: samples s -> voxel rows sample_to_voxel[s]; */
 /* point_to_batch i64 [A*(2+Nn)] = sample ids of (anchors | positives | negatives row-major).           */
 /* loss f32 device scalar; de f32 [nv, d] = d loss / d e (overwritten).                                  */

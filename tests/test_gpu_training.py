@@ -70,6 +70,20 @@ def test_batchnorm_training_forward_backward(ops):
     hi, lo = ops.split_f16(dy, scale=sc2[0:1], extra_zero_rows=1)
     assert hi.shape[0] == nv + 1 and not hi[nv].any() and not lo[nv].any()
     assert ((hi[:nv].float() + lo[:nv].float()) * sc2[1] - dy).abs().max() <= dy.abs().max() * 2.0 ** -21
+    # a layer WITHOUT a residual: the ReLU mask recomputed from y (beta_mask) is the mask of its activation, bit for bit -- same dy, sums and dz;
+    # the forward pass then needs no fp32 output (want_f32=False writes the same planes)
+    out_n, sp_n = ops.bn_train_apply(dev(y), mean, var, dev(gamma), dev(beta), 1e-5, relu=True, want_split=True)
+    none, sp_p = ops.bn_train_apply(dev(y), mean, var, dev(gamma), dev(beta), 1e-5, relu=True, want_split=True, want_f32=False)
+    assert none is None and torch.equal(sp_p[0], sp_n[0]) and torch.equal(sp_p[1], sp_n[1])
+    ra = ops.bn_train_backward(dev(dout), out_n, dev(y), mean, var, 1e-5, dev(gamma), want_dz=True)
+    rb = ops.bn_train_backward(dev(dout), None, dev(y), mean, var, 1e-5, dev(gamma), want_dz=True, beta_mask=dev(beta))
+    assert all(torch.equal(a, b) for a, b in zip(ra, rb)) and 0.2 < float((ra[3] == 0).float().mean()) < 0.8
+    sa = ops.bn_bwd_sums_f64(dev(dout), out_n, dev(y), mean, var, 1e-5)
+    sb = ops.bn_bwd_sums_f64(dev(dout), None, dev(y), mean, var, 1e-5, mask_affine=(dev(gamma), dev(beta)))
+    assert torch.equal(sa, sb)
+    da = ops.bn_bwd_apply(dev(dout), out_n, dev(y), mean, var, 1e-5, dev(gamma), sa.float(), nv)
+    db_ = ops.bn_bwd_apply(dev(dout), None, dev(y), mean, var, 1e-5, dev(gamma), sa.float(), nv, beta_mask=dev(beta))
+    assert torch.equal(da, db_)
 
 
 def test_weight_split_transpose_flip_is_the_split_of_the_mirrored_transposed_weights(ops):
