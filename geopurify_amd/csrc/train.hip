@@ -15,42 +15,86 @@ namespace {
 constexpr int CS_ROWS = 256;      // rows per workgroup of the column reductions
 
 // ------------------------------------------------------------------------------------------------ column sums
-// partial[chunk][q][c] = sum over the chunk's rows of f_q(row, c), q < NQ; fp64 accumulation, fixed order.
-template <int NQ, typename F>
+// partial[chunk][q][c] = sum over the chunk's rows of f_q(row, c), q < NQ; fp64 accumulation, fixed order (a column's rows wv, wv + 4, ...
+// of the chunk in its wave wv, then the four waves in order).  W = 4: a lane owns four adjacent columns and reads them with one 16-byte
+// load per operand (a workgroup = 256 rows x 256 columns); W = 1: one column per lane (any c, any alignment).  Same sums either way.
+template <int W> __device__ __forceinline__ void cs_ld(const float *p, float *o) {
+    if (W == 4) *reinterpret_cast<float4 *>(o) = *reinterpret_cast<const float4 *>(p);
+    else o[0] = p[0];
+}
+template <int NQ, int W, typename F>
 __device__ __forceinline__ void col_partial(int64_t nv, int c, double *__restrict__ partial, F f) {
-    __shared__ double red[4][NQ][64];
+    __shared__ double red[4][NQ][64 * W];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = blockIdx.y * 64 + lane;
+    const int col = (blockIdx.y * 64 + lane) * W;
     const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
-    double acc[NQ];
+    double acc[W][NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[k][q] = 0.0;
     if (col < c)
         for (int64_t r = r0 + wv; r < r0 + CS_ROWS && r < nv; r += 4) {
-            double v[NQ];
+            double v[W][NQ];
             f(r, col, v);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] += v[q];
+            for (int k = 0; k < W; ++k)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[k][q] += v[k][q];
         }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) red[wv][q][lane] = acc[q];
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) red[wv][q][lane * W + k] = acc[k][q];
     __syncthreads();
     if (wv == 0 && col < c)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            partial[((int64_t)blockIdx.x * NQ + q) * c + col] = red[0][q][lane] + red[1][q][lane] + red[2][q][lane] + red[3][q][lane];
+        for (int k = 0; k < W; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int l = lane * W + k;
+                partial[((int64_t)blockIdx.x * NQ + q) * c + col + k] = red[0][q][l] + red[1][q][l] + red[2][q][l] + red[3][q][l];
+            }
+}
+// grid of a column reduction and whether the 16-byte form applies
+static inline bool cs_vec(int c, std::initializer_list<int64_t> lds, std::initializer_list<const void *> ptrs) {
+    bool ok = c % 4 == 0;
+    for (int64_t l : lds) ok = ok && l % 4 == 0;
+    for (const void *p : ptrs) ok = ok && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    return ok;
+}
+static inline dim3 cs_grid(int64_t nv, int c, bool vec) {
+    return dim3((unsigned)((nv + CS_ROWS - 1) / CS_ROWS), (unsigned)((c + (vec ? 255 : 63)) / (vec ? 256 : 64)));
 }
 
+template <int W>
 __global__ void __launch_bounds__(256) cs_sum_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, double *__restrict__ partial) {
-    col_partial<1>(nv, c, partial, [&](int64_t r, int col, double *v) { v[0] = (double)y[r * ld + col]; });
+    col_partial<1, W>(nv, c, partial, [&](int64_t r, int col, double (*v)[1]) {
+        float x[W];
+        cs_ld<W>(y + r * ld + col, x);
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k][0] = (double)x[k];
+    });
 }
 // sums of x and x^2 in one sweep (gp_col_stats)
+template <int W>
 __global__ void __launch_bounds__(256) cs_sum2_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c, double *__restrict__ partial) {
-    col_partial<2>(nv, c, partial, [&](int64_t r, int col, double *v) { const double x = (double)y[r * ld + col]; v[0] = x; v[1] = x * x; });
+    col_partial<2, W>(nv, c, partial, [&](int64_t r, int col, double (*v)[2]) {
+        float x[W];
+        cs_ld<W>(y + r * ld + col, x);
+#pragma unroll
+        for (int k = 0; k < W; ++k) { const double d = (double)x[k]; v[k][0] = d; v[k][1] = d * d; }
+    });
 }
+template <int W>
 __global__ void __launch_bounds__(256) cs_var_kernel(const float *__restrict__ y, int64_t ld, int64_t nv, int c,
                                                      const float *__restrict__ mean, double *__restrict__ partial) {
-    col_partial<1>(nv, c, partial, [&](int64_t r, int col, double *v) { double d = (double)y[r * ld + col] - (double)mean[col]; v[0] = d * d; });
+    col_partial<1, W>(nv, c, partial, [&](int64_t r, int col, double (*v)[1]) {
+        float x[W];
+        cs_ld<W>(y + r * ld + col, x);
+#pragma unroll
+        for (int k = 0; k < W; ++k) { const double d = (double)x[k] - (double)mean[col + k]; v[k][0] = d * d; }
+    });
 }
 // out[q][c] = scale * sum over chunks: one workgroup per 64 columns, the chunks strided over CF_WAVES waves (fixed order).  16 waves:
 // with 4 the 8-16 workgroups of a 512-column layer each walked 110 dependent loads (40 us per call, 27 calls per training step).
@@ -173,19 +217,32 @@ __global__ void bn_running_kernel(const float *__restrict__ mean, const float *_
 // nullptr and beta_m given, a layer WITHOUT a residual -- recomputed from y: (y - mean) * invstd * gamma + beta > 0, the expression
 // bn_apply_kernel evaluated (same operations in the same order: the same float), which saves reading the 232-MB activation here and in
 // bn_bwd_apply_kernel and lets the forward pass skip writing it; both nullptr: no mask.
+template <int W>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
                                                             const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean,
                                                             const float *__restrict__ var, float eps, const float *__restrict__ gamma_m,
                                                             const float *__restrict__ beta_m, int64_t nv, int c, double *__restrict__ partial) {
-    col_partial<2>(nv, c, partial, [&](int64_t r, int col, double *v) {
-        float dz = dout[r * ld_d + col];
-        const float invstd = 1.0f / sqrtf(var[col] + eps);
-        const float yv = y[r * ld_y + col];
-        if (act) { if (!(act[r * ld_a + col] > 0.f)) dz = 0.f; }
-        else if (beta_m) { if (!((yv - mean[col]) * invstd * gamma_m[col] + beta_m[col] > 0.f)) dz = 0.f; }
-        float xhat = (yv - mean[col]) * invstd;
-        v[0] = (double)dz;
-        v[1] = (double)dz * (double)xhat;
+    const int col0 = (blockIdx.y * 64 + (threadIdx.x & 63)) * W;
+    float mu[W], is[W], ga[W], be[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const bool in = col0 + k < c;
+        mu[k] = in ? mean[col0 + k] : 0.f; is[k] = in ? 1.0f / sqrtf(var[col0 + k] + eps) : 0.f;
+        ga[k] = (in && beta_m) ? gamma_m[col0 + k] : 0.f; be[k] = (in && beta_m) ? beta_m[col0 + k] : 0.f;
+    }
+    col_partial<2, W>(nv, c, partial, [&](int64_t r, int col, double (*v)[2]) {
+        float dz[W], yv[W], av[W];
+        cs_ld<W>(dout + r * ld_d + col, dz);
+        cs_ld<W>(y + r * ld_y + col, yv);
+        if (act) cs_ld<W>(act + r * ld_a + col, av);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            if (act) { if (!(av[k] > 0.f)) dz[k] = 0.f; }
+            else if (beta_m) { if (!((yv[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f)) dz[k] = 0.f; }
+            const float xhat = (yv[k] - mu[k]) * is[k];
+            v[k][0] = (double)dz[k];
+            v[k][1] = (double)dz[k] * (double)xhat;
+        }
     });
 }
 // W = 4: c and every leading dimension are multiples of 4 (16-byte accesses); amax_bits (nullable): atomicMax of |dy| as the uint image of a
@@ -780,8 +837,9 @@ extern "C" int gp_col_stats(const float *y, int64_t ld, int64_t nv, int32_t c, f
     hipStream_t s = gp_stream(stream_);
     double *partial = static_cast<double *>(workspace);
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    cs_sum2_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
+    const bool vec = cs_vec(c, {ld}, {y});
+    if (vec) cs_sum2_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(y, ld, nv, c, partial);
+    else cs_sum2_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(y, ld, nv, c, partial);
     cs_meanvar_final_kernel<<<(c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, c, 1.0 / (double)nv, mean, var);
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -800,9 +858,14 @@ extern "C" int gp_col_sums_f64(const float *y, int64_t ld, int64_t nv, int32_t c
     hipStream_t s = gp_stream(stream_);
     double *partial = static_cast<double *>(workspace);
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    if (mean) cs_var_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, mean, partial);
-    else cs_sum_kernel<<<grid, 256, 0, s>>>(y, ld, nv, c, partial);
+    const bool vec = cs_vec(c, {ld}, {y});
+    if (mean) {
+        if (vec) cs_var_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(y, ld, nv, c, mean, partial);
+        else cs_var_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(y, ld, nv, c, mean, partial);
+    } else {
+        if (vec) cs_sum_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(y, ld, nv, c, partial);
+        else cs_sum_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(y, ld, nv, c, partial);
+    }
     cs_final_f64_kernel<<<(c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 1, c, out);
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -817,8 +880,9 @@ extern "C" int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const floa
     hipStream_t s = gp_stream(stream_);
     double *partial = static_cast<double *>(workspace);
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial);
+    const bool vec = cs_vec(c, {ld_dout, ld_y, act ? ld_act : 0}, {dout, y, act});
+    if (vec) bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial);
+    else bn_bwd_reduce_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial);
     cs_final_f64_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, sums);
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -874,8 +938,9 @@ extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const fl
     double *partial = static_cast<double *>(workspace);
     float *sums = reinterpret_cast<float *>(static_cast<char *>(workspace) + gp_col_stats_workspace_bytes(nv, c));
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((unsigned)nch, (unsigned)((c + 63) / 64));
-    bn_bwd_reduce_kernel<<<grid, 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial);
+    const bool vec = cs_vec(c, {ld_dout, ld_y, act ? ld_act : 0}, {dout, y, act});
+    if (vec) bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial);
+    else bn_bwd_reduce_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial);
     cs_final_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, 1.0, sums);
     int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, sums, nv, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2, s);
     if (rc != GP_OK) return rc;
