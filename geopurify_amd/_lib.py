@@ -113,8 +113,9 @@ SIGNATURES = {
     "gp_col_stats": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
     "gp_bn_train_apply": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_float, _P, c_int64, c_int32, _P, c_int64,
                                     _P, _P, c_int64, c_float, _P, _P, _P]),
+    "gp_bn_train_backward_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "gp_bn_train_backward": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, _P, _P, c_int64, c_int32, _P, c_int64,
-                                       _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+                                       _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_size_t, _P]),
     "gp_col_sums_f64": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
     "gp_bn_bwd_sums_f64": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, _P, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "gp_bn_bwd_apply": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_float, _P, _P, _P, c_int64, c_int64, c_int32, _P, c_int64,

@@ -221,14 +221,16 @@ template <int W>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
                                                             const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean,
                                                             const float *__restrict__ var, float eps, const float *__restrict__ gamma_m,
-                                                            const float *__restrict__ beta_m, int64_t nv, int c, double *__restrict__ partial) {
+                                                            const float *__restrict__ beta_m, int64_t nv, int c, double *__restrict__ partial,
+                                                            float *__restrict__ pmax /*nullable: [chunk][2][c] max |dz|, max |xhat|*/) {
     const int col0 = (blockIdx.y * 64 + (threadIdx.x & 63)) * W;
-    float mu[W], is[W], ga[W], be[W];
+    float mu[W], is[W], ga[W], be[W], mdz[W], mxh[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         const bool in = col0 + k < c;
         mu[k] = in ? mean[col0 + k] : 0.f; is[k] = in ? 1.0f / sqrtf(var[col0 + k] + eps) : 0.f;
         ga[k] = (in && beta_m) ? gamma_m[col0 + k] : 0.f; be[k] = (in && beta_m) ? beta_m[col0 + k] : 0.f;
+        mdz[k] = mxh[k] = 0.f;
     }
     col_partial<2, W>(nv, c, partial, [&](int64_t r, int col, double (*v)[2]) {
         float dz[W], yv[W], av[W];
@@ -242,8 +244,62 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *__restr
             const float xhat = (yv[k] - mu[k]) * is[k];
             v[k][0] = (double)dz[k];
             v[k][1] = (double)dz[k] * (double)xhat;
+            mdz[k] = fmaxf(mdz[k], fabsf(dz[k]));
+            mxh[k] = fmaxf(mxh[k], fabsf(xhat));
         }
     });
+    if (pmax) {                                           // (uniform) the chunk's column maxima: what bounds |dy| before dy exists
+        __shared__ float rmax[4][2][64 * W];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < W; ++k) { rmax[wv][0][lane * W + k] = mdz[k]; rmax[wv][1][lane * W + k] = mxh[k]; }
+        __syncthreads();
+        if (wv == 0 && col0 < c)
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int l = lane * W + k;
+                    pmax[((int64_t)blockIdx.x * 2 + q) * c + col0 + k] = fmaxf(fmaxf(rmax[0][q][l], rmax[1][q][l]), fmaxf(rmax[2][q][l], rmax[3][q][l]));
+                }
+    }
+}
+// sums[0:c] = sum dz, sums[c:2c] = sum dz * xhat (fp64, the chunks in cs_final_kernel's order) and, from the chunks' column maxima, a bound
+// of max |dy|: |dy| = |gamma| invstd |dz - s1 / n - xhat s2 / n| <= |gamma| invstd (max |dz| + |s1| / n + max |xhat| |s2| / n) per column; the
+// largest goes to amax_bits (the uint image of a non-negative float, atomicMax) -- the scale of the gradient's f16 split, known BEFORE the sweep
+// that computes dy, which can therefore write the split planes itself (no fp32 dy, no separate split pass).  The bound is within a small factor
+// of the true maximum (it is attained when the largest |dz| meets opposite-signed means): the split loses a fraction of a bit of head room.
+__global__ void __launch_bounds__(CF_WAVES * 64)
+bn_bwd_final_bound_kernel(const double *__restrict__ partial, const float *__restrict__ pmax, int64_t nchunks, int c, const float *__restrict__ var,
+                          float eps, const float *__restrict__ gamma, int64_t n_total, float *__restrict__ sums, unsigned *__restrict__ amax_bits) {
+    __shared__ double red[2][CF_WAVES][64];
+    __shared__ float rmx[2][CF_WAVES][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0;
+    float m0 = 0.f, m1 = 0.f;
+    if (col < c)
+        for (int64_t k = wv; k < nchunks; k += CF_WAVES) {
+            s0 += partial[(k * 2) * c + col]; s1 += partial[(k * 2 + 1) * c + col];
+            m0 = fmaxf(m0, pmax[(k * 2) * c + col]); m1 = fmaxf(m1, pmax[(k * 2 + 1) * c + col]);
+        }
+    red[0][wv][lane] = s0; red[1][wv][lane] = s1; rmx[0][wv][lane] = m0; rmx[1][wv][lane] = m1;
+    __syncthreads();
+    if (wv == 0) {
+        float b = 0.f;
+        if (col < c) {
+            double t0 = 0.0, t1 = 0.0;
+            float x0 = 0.f, x1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < CF_WAVES; ++w) { t0 += red[0][w][lane]; t1 += red[1][w][lane]; x0 = fmaxf(x0, rmx[0][w][lane]); x1 = fmaxf(x1, rmx[1][w][lane]); }
+            const float f0 = (float)t0, f1 = (float)t1, inv_n = 1.0f / (float)n_total;
+            sums[col] = f0;
+            sums[c + col] = f1;
+            b = fabsf(gamma[col]) * (1.0f / sqrtf(var[col] + eps)) * (x0 + fabsf(f0) * inv_n + x1 * fabsf(f1) * inv_n);
+        }
+        b = gp_wave_max(b);
+        if (lane == 0) atomicMax(amax_bits, __float_as_uint(b));
+    }
 }
 // W = 4: c and every leading dimension are multiples of 4 (16-byte accesses); amax_bits (nullable): atomicMax of |dy| as the uint image of a
 // non-negative float, one atomic per workgroup -- the power-of-two scale of the gradient's f16 split without another sweep over dy.
@@ -302,6 +358,52 @@ bn_bwd_apply_kernel(const float *__restrict__ dout, int64_t ld_d, const float *_
             m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
             atomicMax(amax_bits, __float_as_uint(m));
         }
+    }
+}
+// the same sweep writing dy * s as f16 hi / lo planes (s = scale2[0], from bn_bwd_final_bound_kernel) instead of fp32 rows; row nv of the planes
+// (the weight gradient's padded pairs point there) is zeroed by the first threads.  c % 4 == 0, 16-byte aligned rows.
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_split_kernel(const float *__restrict__ dout, int64_t ld_d, const float *__restrict__ act, int64_t ld_a,
+                          const float *__restrict__ y, int64_t ld_y, const float *__restrict__ mean, const float *__restrict__ var,
+                          float eps, const float *__restrict__ gamma, const float *__restrict__ beta_m, const float *__restrict__ sums, int64_t n_total,
+                          int64_t nv, int c, const float *__restrict__ scale2, _Float16 *__restrict__ dy_hi, _Float16 *__restrict__ dy_lo, int64_t ld_h,
+                          float *__restrict__ dz_out, int64_t ld_dz) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    constexpr int W = 4;
+    const int cw = c / W;
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int col = (int)(t % cw) * W;
+    const int64_t rstep = nthreads / cw;
+    const float inv_n = 1.0f / (float)n_total, sc = scale2[0];
+    float mu[W], is[W], ga[W], be[W], s1[W], s2[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        mu[k] = mean[col + k]; is[k] = 1.0f / sqrtf(var[col + k] + eps); ga[k] = gamma[col + k]; be[k] = beta_m ? beta_m[col + k] : 0.f;
+        s1[k] = sums[col + k] * inv_n; s2[k] = sums[c + col + k] * inv_n;
+    }
+    if (t < cw) {
+        f16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        *reinterpret_cast<f16x4 *>(dy_hi + nv * ld_h + col) = z;
+        *reinterpret_cast<f16x4 *>(dy_lo + nv * ld_h + col) = z;
+    }
+    for (int64_t r = t / cw; r < nv; r += rstep) {
+        float dz[W], yv[W], av[W];
+        *reinterpret_cast<float4 *>(dz) = *reinterpret_cast<const float4 *>(dout + r * ld_d + col);
+        *reinterpret_cast<float4 *>(yv) = *reinterpret_cast<const float4 *>(y + r * ld_y + col);
+        if (act) *reinterpret_cast<float4 *>(av) = *reinterpret_cast<const float4 *>(act + r * ld_a + col);
+        f16x4 h, l;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            if (act) { if (!(av[k] > 0.f)) dz[k] = 0.f; }
+            else if (beta_m) { if (!((yv[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f)) dz[k] = 0.f; }
+            const float xhat = (yv[k] - mu[k]) * is[k];
+            const float o = ga[k] * is[k] * (dz[k] - s1[k] - xhat * s2[k]) * sc;
+            h[k] = (_Float16)o;
+            l[k] = (_Float16)(o - (float)h[k]);
+        }
+        *reinterpret_cast<f16x4 *>(dy_hi + r * ld_h + col) = h;
+        *reinterpret_cast<f16x4 *>(dy_lo + r * ld_h + col) = l;
+        if (dz_out) *reinterpret_cast<float4 *>(dz_out + r * ld_dz + col) = *reinterpret_cast<const float4 *>(dz);
     }
 }
 // scale2[0] holds the amax bits on entry; [s, 1/s] on exit
@@ -881,8 +983,8 @@ extern "C" int gp_bn_bwd_sums_f64(const float *dout, int64_t ld_dout, const floa
     double *partial = static_cast<double *>(workspace);
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     const bool vec = cs_vec(c, {ld_dout, ld_y, act ? ld_act : 0}, {dout, y, act});
-    if (vec) bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial);
-    else bn_bwd_reduce_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial);
+    if (vec) bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial, nullptr);
+    else bn_bwd_reduce_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma_mask, beta_mask, nv, c, partial, nullptr);
     cs_final_f64_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, sums);
     GP_CHECK_LAUNCH();
     return GP_OK;
@@ -925,25 +1027,43 @@ extern "C" int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t
 
 // dz = dout * (act > 0) (act NULL: dz = dout); dgamma = sum dz*xhat, dbeta = sum dz;
 // dy = gamma/sqrt(var+eps) * (dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) receives dz (identity branch)
+extern "C" size_t gp_bn_train_backward_workspace_bytes(int64_t nv, int32_t c) {
+    const int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
+    return gp_col_stats_workspace_bytes(nv, c) + gp_align_up((size_t)2 * c * sizeof(float), 256) + gp_align_up((size_t)nch * 2 * c * sizeof(float), 256);
+}
+
 extern "C" int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y, int64_t ld_y,
                                     const float *mean, const float *var, float eps, const float *gamma, const float *beta_mask, int64_t nv, int32_t c,
                                     float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz, float *dgamma, float *dbeta, float *dy_scale2,
-                                    void *workspace, size_t workspace_bytes, void *stream_) {
-    GP_CHECK_ARG(dout && y && mean && var && gamma && dy && dgamma && dbeta && workspace && nv > 0 && c > 0,
+                                    void *dy_hi, void *dy_lo, int64_t ld_h, void *workspace, size_t workspace_bytes, void *stream_) {
+    GP_CHECK_ARG(dout && y && mean && var && gamma && (dy || dy_hi) && dgamma && dbeta && workspace && nv > 0 && c > 0,
                  "gp_bn_train_backward: null/empty argument");
     GP_CHECK_ARG(!beta_mask || !act, "gp_bn_train_backward: the mask comes from act OR from y (beta_mask)");
-    size_t need = gp_col_stats_workspace_bytes(nv, c) + gp_align_up((size_t)2 * c * sizeof(float), 256);
-    if (workspace_bytes < need) { gp_set_error("gp_bn_train_backward: workspace too small"); return GP_ENOMEM; }
+    if (workspace_bytes < gp_bn_train_backward_workspace_bytes(nv, c)) { gp_set_error("gp_bn_train_backward: workspace too small"); return GP_ENOMEM; }
     hipStream_t s = gp_stream(stream_);
     double *partial = static_cast<double *>(workspace);
     float *sums = reinterpret_cast<float *>(static_cast<char *>(workspace) + gp_col_stats_workspace_bytes(nv, c));
+    float *pmax = reinterpret_cast<float *>(reinterpret_cast<char *>(sums) + gp_align_up((size_t)2 * c * sizeof(float), 256));
     int64_t nch = (nv + CS_ROWS - 1) / CS_ROWS;
     const bool vec = cs_vec(c, {ld_dout, ld_y, act ? ld_act : 0}, {dout, y, act});
-    if (vec) bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial);
-    else bn_bwd_reduce_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial);
-    cs_final_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, 1.0, sums);
-    int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, sums, nv, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2, s);
-    if (rc != GP_OK) return rc;
+    if (dy_hi) {
+        // the split planes of dy * s straight from the sweep (s from a bound of max |dy| taken in the reduction pass): no fp32 dy, no split pass
+        GP_CHECK_ARG(!dy && dy_lo && dy_scale2 && vec && ld_h % 4 == 0 && ld_h >= c && (!dz_out || ld_dz % 4 == 0) &&
+                         ((uintptr_t)dy_hi & 7) == 0 && ((uintptr_t)dy_lo & 7) == 0 && ((uintptr_t)dz_out & 15) == 0,
+                     "gp_bn_train_backward: the split form (dy_hi / dy_lo [nv + 1 rows] + dy_scale2, dy = NULL) needs c %% 4 == 0 and 16-byte aligned rows");
+        GP_CHECK_HIP(hipMemsetAsync(dy_scale2, 0, 8, s));
+        bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial, pmax);
+        bn_bwd_final_bound_kernel<<<(c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, pmax, nch, c, var, eps, gamma, nv, sums, reinterpret_cast<unsigned *>(dy_scale2));
+        bn_scale2_kernel<<<1, 1, 0, s>>>(dy_scale2);
+        bn_bwd_apply_split_kernel<<<bn_sweep_blocks(nv, c / 4), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, sums, nv, nv, c,
+                                                                             dy_scale2, static_cast<_Float16 *>(dy_hi), static_cast<_Float16 *>(dy_lo), ld_h, dz_out, ld_dz);
+    } else {
+        if (vec) bn_bwd_reduce_kernel<4><<<cs_grid(nv, c, true), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial, nullptr);
+        else bn_bwd_reduce_kernel<1><<<cs_grid(nv, c, false), 256, 0, s>>>(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, nv, c, partial, nullptr);
+        cs_final_kernel<<<(2 * c + 63) / 64, CF_WAVES * 64, 0, s>>>(partial, nch, 2, c, 1.0, sums);
+        int rc = bn_bwd_apply_launch(dout, ld_dout, act, ld_act, y, ld_y, mean, var, eps, gamma, beta_mask, sums, nv, nv, c, dy, ld_dy, dz_out, ld_dz, dy_scale2, s);
+        if (rc != GP_OK) return rc;
+    }
     GP_CHECK_HIP(hipMemcpyAsync(dbeta, sums, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));
     GP_CHECK_HIP(hipMemcpyAsync(dgamma, sums + c, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, s));
     GP_CHECK_LAUNCH();

@@ -1105,22 +1105,32 @@ def bn_train_apply(y, mean, var, gamma, beta, eps, residual=None, relu=True, wan
     return out, ((hi, lo) if want_split else None)
 
 
-def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False, dy_scale2=None, beta_mask=None):
+def bn_train_backward(dout, act, y, mean, var, eps, gamma, want_dz=False, dy_scale2=None, beta_mask=None, split=False):
     """Returns dy, dgamma, dbeta (, dz).  act: post-ReLU activation (mask) or None; act None and beta_mask = the layer's beta: the mask of a
     layer WITHOUT a residual recomputed from y ((y - mean) * invstd * gamma + beta > 0: the float the forward pass evaluated).
-    dy_scale2 (fp32 [2] device tensor): receives pow2_scale(dy) from the sweep that writes dy."""
+    dy_scale2 (fp32 [2] device tensor): receives pow2_scale(dy) from the sweep that writes dy.
+    split=True (needs dy_scale2): dy comes back as ((hi, lo) f16 [nv + 1, c] with a zero last row) holding dy * dy_scale2[0] -- written by
+    the sweep itself, the scale from a bound of max |dy| taken in the reduction pass (no fp32 dy, no split pass)."""
     lib = _lib.load()
     nv, c = y.shape[0], mean.shape[0]
     dev = y.device
-    dy = torch.empty((nv, c), dtype=torch.float32, device=dev)
+    hi = lo = dy = None
+    if split:
+        assert dy_scale2 is not None
+        hi = torch.empty((nv + 1, c), dtype=torch.float16, device=dev)
+        lo = torch.empty((nv + 1, c), dtype=torch.float16, device=dev)
+    else:
+        dy = torch.empty((nv, c), dtype=torch.float32, device=dev)
     dz = torch.empty((nv, c), dtype=torch.float32, device=dev) if want_dz else None
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    ws = _ws(lib.gp_col_stats_workspace_bytes(nv, c) + 2 * c * 4 + 512, dev)
+    ws = _ws(lib.gp_bn_train_backward_workspace_bytes(nv, int(c)), dev)
     check(lib.gp_bn_train_backward(_ptr(dout), dout.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(y),
-                                   y.stride(0), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(beta_mask), nv, int(c), _ptr(dy), dy.stride(0),
-                                   _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dgamma), _ptr(dbeta), _ptr(dy_scale2), _ptr(ws),
+                                   y.stride(0), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(beta_mask), nv, int(c), _ptr(dy),
+                                   dy.stride(0) if dy is not None else 0, _ptr(dz), dz.stride(0) if dz is not None else 0, _ptr(dgamma),
+                                   _ptr(dbeta), _ptr(dy_scale2), _ptr(hi), _ptr(lo), hi.stride(0) if hi is not None else 0, _ptr(ws),
                                    ws.numel(), _stream()), "gp_bn_train_backward")
+    dy = (hi, lo) if split else dy
     return (dy, dgamma, dbeta, dz) if want_dz else (dy, dgamma, dbeta)
 
 

@@ -145,6 +145,8 @@ class StudentTrainer:
         power of two of gp_pow2_scale (max |dY| * s in [2^13, 2^14): 1e-6-sized gradients become normal f16 numbers), a device scalar --
         no host sync.  scale2 = [s, 1/s] when the producer of dY took it in its own sweep (bn_train_backward(dy_scale2=)), else one
         amax pass here.  Returns ((hi, lo) [nv+1, c], 1/s as a 1-element device tensor)."""
+        if isinstance(dy, tuple):                        # bn_train_backward(split=True) wrote the planes already
+            return dy, scale2[1:2]
         if scale2 is None:
             scale2 = ops.pow2_scale(dy)
         return ops.split_f16(dy, scale=scale2[0:1], extra_zero_rows=1), scale2[1:2]
@@ -153,7 +155,7 @@ class StudentTrainer:
         """dx = sum_k dy[nbr_k] @ w[26-k]^T (+ residual: the identity branch's gradient, added in the operator's output pass)."""
         if self.fast and w.shape[1] % 256 == 0:
             (hi_y, lo_y), inv_s = gs if gs is not None else self._grad_split(dy)
-            nv = dy.shape[0]
+            nv = hi_y.shape[0] - 1
             hi, lo = ops.conv_weights_split(w, W_POW2, transpose_flip=True)
             scale = (ctx["inv_pow2"][w.shape[1]] * inv_s).contiguous()
             return ops.sparse_conv_f16x3(None, ctx["pairs"], hi, lo, scale, None, residual=residual, relu=False, x_split=(hi_y[:nv], lo_y[:nv]))
@@ -163,7 +165,7 @@ class StudentTrainer:
     def _wgrad(self, x, x_split, dy, ctx, cin, gs=None, out=None):
         """dW[k] = x[in_k]^T @ dy[out_k]: matrix-core kernel (gp_conv_wgrad_f16x3) when the shapes allow (cin >= 256,
         cout a multiple of 256), else library GEMMs on gathered rows.  out: the buffer to write it into (a gradient bucket's slice)."""
-        cout = dy.shape[1]
+        cout = (dy[0] if isinstance(dy, tuple) else dy).shape[1]
         if self.fast and x_split is not None and cin >= 256 and cout % 256 == 0:
             ysplit, inv_s = gs if gs is not None else self._grad_split(dy)
             return ops.conv_wgrad_f16x3(x_split, ysplit, ctx["wgrad_plan"], cin, cin, cout, inv_scale=inv_s, out=out)
@@ -232,7 +234,7 @@ class StudentTrainer:
                                          want_f32=want_f32)
             return out, sp, (mean, var)
 
-        def bn_bwd(dout, act, y, st, gamma, want_dz=False, beta=None):
+        def bn_bwd(dout, act, y, st, gamma, want_dz=False, beta=None, allow_split=True):
             """(dy, dgamma, dbeta, dz | None, scale2 of dy | None); with SyncBatchNorm the dy formula uses the reductions over all ranks.
             beta (a layer without a residual): the ReLU mask comes from y, act is not read"""
             if beta is not None:
@@ -245,7 +247,9 @@ class StudentTrainer:
                 r = ops.bn_bwd_apply(dout, act, y, st[0], st[1], self.bn_eps, gamma, g_sums, st[2], want_dz=want_dz, dy_scale2=sc2, beta_mask=beta)
                 dy, dz = r if want_dz else (r, None)
                 return dy, l_sums[c:].clone(), l_sums[:c].clone(), dz, sc2
-            r = ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz, dy_scale2=sc2, beta_mask=beta)
+            # one process: the sweep writes the gradient's split planes itself (scale from a bound taken in the reduction pass)
+            r = ops.bn_train_backward(dout, act, y, st[0], st[1], self.bn_eps, gamma, want_dz=want_dz, dy_scale2=sc2, beta_mask=beta,
+                                      split=allow_split and self.fast and y.shape[1] % 256 == 0)
             return r[0], r[1], r[2], (r[3] if want_dz else None), sc2
 
         # ---------------- forward (activations kept for the backward pass)
@@ -309,7 +313,8 @@ class StudentTrainer:
             g[f"res_blocks.{i}.conv1.kernel"] = self._wgrad(h_in, h_in_s, dy1, ctx, self.hidden, gs1, out=buf(f"res_blocks.{i}.conv1.kernel"))
             dh = self._dgrad(dy1, P[f"res_blocks.{i}.conv1.kernel"], ctx, gs1, residual=dz)
         h0 = blocks[0][0] if self.num_blocks else h
-        dy0, dg0, db0, _, sc0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"], beta=P["input_layer.1.bn.bias"])
+        dy0, dg0, db0, _, sc0 = bn_bwd(dh, h0, y0, st0, P["input_layer.1.bn.weight"], beta=P["input_layer.1.bn.bias"],
+                                       allow_split=self.cin_pad >= 256)          # (a narrow input layer's weight gradient takes fp32 rows)
         g["input_layer.1.bn.weight"], g["input_layer.1.bn.bias"] = dg0, db0
         g["input_layer.0.kernel"] = self._wgrad(X, xs, dy0, ctx, self.cin_pad, self._grad_split(dy0, sc0) if self.fast else None,
                                                 out=buf("input_layer.0.kernel"))

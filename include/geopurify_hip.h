@@ -519,11 +519,17 @@ int gp_bn_train_apply(const float *y, int64_t ld, int64_t nv, int32_t c, const f
 /* dy = gamma/sqrt(var+eps)*(dz - dbeta/nv - xhat*dgamma/nv); dz_out (nullable) <- dz.                */
 /* dy_scale2 (nullable, 2 floats on the device) <- [s, 1/s] of gp_pow2_scale(dy), taken inside the sweep that writes dy: */
 /* the scale of the gradient's f16 split (gp_split_f16_scaled) without another pass over it.                           */
-/* workspace: gp_col_stats_workspace_bytes(nv, c) + 2*c*4 (rounded up to 256).                        */
+/* SPLIT FORM (dy = NULL, dy_hi / dy_lo f16 [nv + 1, ld_h] and dy_scale2 given; c % 4 == 0, 16-byte aligned rows): the sweep writes    */
+/* hi + lo = dy * s itself, row nv zeroed (the weight gradient's padded pairs), dy_scale2 = [s, 1/s] with s the power of two of a BOUND  */
+/* of max |dy| -- |gamma| / std x (max |dz| + |sum dz| / n + max |xhat| |sum dz xhat| / n) per column, from maxima taken in the           */
+/* reduction pass -- so that no fp32 dy is written and no separate split pass reads it (bound / true maximum: a small factor).          */
+/* workspace: gp_bn_train_backward_workspace_bytes(nv, c).                                            */
+size_t gp_bn_train_backward_workspace_bytes(int64_t nv, int32_t c);
 int gp_bn_train_backward(const float *dout, int64_t ld_dout, const float *act, int64_t ld_act, const float *y,
                          int64_t ld_y, const float *mean, const float *var, float eps, const float *gamma, const float *beta_mask,
                          int64_t nv, int32_t c, float *dy, int64_t ld_dy, float *dz_out, int64_t ld_dz,
-                         float *dgamma, float *dbeta, float *dy_scale2, void *workspace, size_t workspace_bytes, void *stream);
+                         float *dgamma, float *dbeta, float *dy_scale2, void *dy_hi, void *dy_lo, int64_t ld_h,
+                         void *workspace, size_t workspace_bytes, void *stream);
 /* SyncBatchNorm pieces (run/train.py:212-213 converts the student to MinkowskiSyncBatchNorm; geopurify_amd/sharding.py     */
 /* all-reduces these small vectors over the ranks).  gp_col_sums_f64: mean == NULL -> out[col] = sum_r y[r][col], else         */
 /* out[col] = sum_r (y[r][col] - mean[col])^2 (fp64, fixed order).  gp_bn_bwd_sums_f64: sums[0:c] = sum dz,                    */

@@ -81,6 +81,21 @@ def test_batchnorm_training_forward_backward(ops):
     sa = ops.bn_bwd_sums_f64(dev(dout), out_n, dev(y), mean, var, 1e-5)
     sb = ops.bn_bwd_sums_f64(dev(dout), None, dev(y), mean, var, 1e-5, mask_affine=(dev(gamma), dev(beta)))
     assert torch.equal(sa, sb)
+    # SPLIT FORM: the sweep writes hi + lo = dy * s with s from a BOUND of max |dy| taken in the reduction pass (no fp32 dy): the bound holds,
+    # stays within a small factor of the true maximum, the planes carry dy to 2^-21 of that maximum, row nv is zero, sums and dz are the same
+    for a_, b_ in ((out, None), (None, dev(beta))):
+        yy, oo = (dev(y), a_) if a_ is not None else (dev(y), None)
+        ref_r = ops.bn_train_backward(dev(dout), oo if a_ is not None else None, yy, mean, var, 1e-5, dev(gamma), want_dz=True,
+                                      beta_mask=b_) if a_ is None else (dy, dg, db, dz)
+        sc3 = torch.empty(2, device="cuda")
+        (sh, sl), dg3, db3, dz3 = ops.bn_train_backward(dev(dout), oo, yy, mean, var, 1e-5, dev(gamma), want_dz=True, dy_scale2=sc3,
+                                                        beta_mask=b_, split=True)
+        dyr = ref_r[0]
+        top = float(dyr.abs().max() * sc3[0])
+        assert 2.0 ** 10 <= top < 2.0 ** 14, top                                  # bound >= true max, looser by less than 2^3
+        assert float(sc3[0] * sc3[1]) == 1.0 and sh.shape == (nv + 1, c) and not sh[nv].any() and not sl[nv].any()
+        assert ((sh[:nv].float() + sl[:nv].float()) * sc3[1] - dyr).abs().max() <= dyr.abs().max() * 2.0 ** -18
+        assert torch.equal(dg3, ref_r[1]) and torch.equal(db3, ref_r[2]) and torch.equal(dz3, ref_r[3])
     da = ops.bn_bwd_apply(dev(dout), out_n, dev(y), mean, var, 1e-5, dev(gamma), sa.float(), nv)
     db_ = ops.bn_bwd_apply(dev(dout), None, dev(y), mean, var, 1e-5, dev(gamma), sa.float(), nv, beta_mask=dev(beta))
     assert torch.equal(da, db_)
