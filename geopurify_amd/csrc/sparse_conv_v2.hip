@@ -1187,22 +1187,36 @@ __global__ void weight_split_kernel(const float *__restrict__ w, int kv, int cin
 // column tile = its column (rho & 128) | (rho & 15) << 3 | (rho >> 4 & 7) (the LDS row the LDS-DMA kernel stages it in)
 // transpose_flip: the operand of the DATA-GRADIENT convolution V[k] = W[kv - 1 - k]^T taken straight from w ([kv][cout][cin] of V's
 // dimensions: the forward layer's [kv][its cin][its cout]) -- no flipped / transposed fp32 copy in between, and reads along w's rows.
-__global__ void weight_split_blocked_kernel(const float *__restrict__ w, int kv, int cin, int cout, float s,
-                                            _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, int transpose_flip) {
-    const int64_t total = (int64_t)kv * cin * cout;
+// One workgroup per (offset, column tile, K step) = one 16-KiB block of each output; thread c owns column c of the tile: it reads the step's
+// 32 values of its column (forward: one coalesced 1-KiB row of w per value across the workgroup; transposed: 128 contiguous bytes of its own
+// row) and writes them as ONE 64-byte run per half into row rho(c) = (c & 128) | (c >> 3 & 15) | (c & 7) << 4 of the block.  (The element-
+// per-thread form this replaces read w with a 2-KiB stride between neighbouring lanes: 34 us per 28-MB layer, 17 layers per training step.)
+__global__ void __launch_bounds__(256)
+weight_split_blocked_kernel(const float *__restrict__ w, int kv, int cin, int cout, float s,
+                            _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, int transpose_flip) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     const int steps = cin / TK, nt = cout / TN;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(i % TK);
-        const int rho = (int)((i / TK) % TN);
-        const int st = (int)((i / ((int64_t)TK * TN)) % steps);
-        const int t = (int)((i / ((int64_t)TK * TN * steps)) % nt);
-        const int64_t k = i / ((int64_t)TK * TN * steps * nt);
-        const int c = (rho & 128) | ((rho & 15) << 3) | ((rho >> 4) & 7);
-        const float v = (transpose_flip ? w[((kv - 1 - k) * cout + t * TN + c) * cin + st * TK + kk]
-                                        : w[(k * cin + st * TK + kk) * cout + t * TN + c]) * s;
-        const _Float16 h = (_Float16)v;
-        hi[i] = h;
-        lo[i] = (_Float16)(v - (float)h);
+    const int st = blockIdx.x % steps, t = (blockIdx.x / steps) % nt, k = blockIdx.x / (steps * nt);
+    const int c = threadIdx.x;
+    const int rho = (c & 128) | ((c >> 3) & 15) | ((c & 7) << 4);
+    float v[TK];
+    if (transpose_flip) {
+        const float *src = w + ((int64_t)(kv - 1 - k) * cout + t * TN + c) * cin + st * TK;
+#pragma unroll
+        for (int q = 0; q < TK / 4; ++q) *reinterpret_cast<float4 *>(v + 4 * q) = *reinterpret_cast<const float4 *>(src + 4 * q);
+    } else {
+        const float *src = w + ((int64_t)k * cin + st * TK) * cout + t * TN + c;
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) v[kk] = src[(int64_t)kk * cout];
+    }
+    const int64_t o = ((((int64_t)k * nt + t) * steps + st) * TN + rho) * TK;
+#pragma unroll
+    for (int q = 0; q < TK / 8; ++q) {
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float x = v[q * 8 + j] * s; h[j] = (_Float16)x; l[j] = (_Float16)(x - (float)h[j]); }
+        *reinterpret_cast<f16x8 *>(hi + o + q * 8) = h;
+        *reinterpret_cast<f16x8 *>(lo + o + q * 8) = l;
     }
 }
 
@@ -1289,8 +1303,9 @@ extern "C" int gp_conv_weights_split_blocked(const float *w, int32_t kv, int32_t
                                              void *w_lo, int32_t transpose_flip, void *stream_) {
     GP_CHECK_ARG(w && w_hi && w_lo && kv > 0 && cin > 0 && cout > 0, "gp_conv_weights_split_blocked: null/empty argument");
     GP_CHECK_ARG(cin % TK == 0 && cout % TN == 0, "gp_conv_weights_split_blocked: cin=%d must be a multiple of %d and cout=%d of %d", cin, TK, cout, TN);
-    weight_split_blocked_kernel<<<2048, 256, 0, gp_stream(stream_)>>>(w, kv, cin, cout, scale_pow2, static_cast<_Float16 *>(w_hi),
-                                                                      static_cast<_Float16 *>(w_lo), transpose_flip);
+    GP_CHECK_ARG(!transpose_flip || ((reinterpret_cast<uintptr_t>(w) & 15) == 0), "gp_conv_weights_split_blocked: w must be 16-byte aligned");
+    weight_split_blocked_kernel<<<(unsigned)((int64_t)kv * (cout / TN) * (cin / TK)), 256, 0, gp_stream(stream_)>>>(
+        w, kv, cin, cout, scale_pow2, static_cast<_Float16 *>(w_hi), static_cast<_Float16 *>(w_lo), transpose_flip);
     GP_CHECK_LAUNCH();
     return GP_OK;
 }
