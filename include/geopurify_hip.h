@@ -574,7 +574,7 @@ int gp_knn_points_f32(const float *xyz, int64_t n, const int64_t *queries, int64
 /* per row a of sim fp32 [num_anchors, >= n] (leading dimension ld): positive[a] = arg-max over the points other than anchor_idx[a]   */
 /* (ties: the lowest index -- torch.argmax after the -inf mark); macro[a, 0:k] = the k points of lowest similarity other than the     */
 /* anchor and the positive, ascending by (value, index) (torch.topk(largest=False) after the two +inf marks).  sim is not written.    */
-/* 1 <= k < 1024, n >= k + 2.  -0 counts as +0; NaNs order above +inf.                                                               */
+/* 1 <= k < 1024, k + 2 <= n <= 3 145 728 (12 288 groups of at most 256 elements in LDS).  -0 counts as +0; NaNs order above +inf.        */
 int gp_sampler_select(const float *sim, int64_t ld, int64_t num_anchors, int64_t n, const int64_t *anchor_idx, int32_t k,
                       int64_t *positive, int64_t *macro, void *stream);
 /* F.normalize(x, p=2, dim=1) (affinity_module.py:1114) written as the f16 hi/lo planes of the similarity GEMM's operands:            */
