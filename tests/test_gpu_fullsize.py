@@ -422,6 +422,73 @@ def test_config_s_full_size_properties():
     assert bool((nrm > 0).all()) and bool((nrm < 1 + 1e-4).all())
 
 
+def test_training_step_full_size_properties():
+    """BASELINE config 5 -- the student's training step at its full size (150k points, 4096 anchors x (1 + 63), teacher [N, 1088], student
+    518 -> 512 x 9 -> 128) under pytest, through size-independent properties of the pieces the oracle cannot run at this size:
+    the anchors' 96 nearest points (exact against a brute-force fp64 distance matrix on a sample of anchors), the sampler (positive = the
+    arg-max of the fp64 similarity other than the anchor, the 48 global negatives = the 48 lowest other than anchor and positive, up to
+    near ties of the fp32-class GEMM; 15 local ones among the neighbours), a second step from the same state and anchors (same loss and
+    gradients up to the fp32 atomics of the InfoNCE scatter), the gradient's split planes, and an optimizer step that moves every tensor."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from geopurify_amd import pipeline as pl, synthetic as syn, training
+    cfg = syn.CONFIGS["S"]
+    scene = syn.make_scene(cfg, 5557)
+    rigid = pl.scene_rigid_transform(cfg.voxel_size, 5557)
+    batch = pl.build_scene_batch(pl.upload_scene(scene, "cuda"), rigid, "cuda")
+    N = batch.scene_coords.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    F_lift = torch.nn.functional.normalize(torch.randn(N, 512, device="cuda", generator=g), dim=1)
+    F_teacher = torch.randn(N, 1088, device="cuda", generator=g)
+    sd = pl.random_student_state_dict(512 + pl.GEO_DIM, hidden=512, embed=128, num_blocks=4, seed=0)
+    xyz = batch.scene_coords.float().contiguous()
+    anchors = torch.randperm(N, device="cuda", generator=g)[:4096]
+
+    def step():
+        tr = training.StudentTrainer(sd, "cuda", base_lr=1e-4, weight_decay=1e-5)
+        out = tr.scene_step(F_lift, batch.scene_gauss_features, batch.scene_inds_reconstruct, batch.scene_coords_3d, xyz, F_teacher,
+                            anchors, num_negatives=63, K=96, optimize=False)
+        return tr, out
+    tr, out = step()
+    assert N == 150_000 and out["num_voxels"] > 100_000 and torch.isfinite(out["loss"])
+    pos, neg, nbrs = out["positive"], out["negative"], out["neighbors"]
+    assert neg.shape == (4096, 63) and nbrs.shape == (4096, 96) and not bool((pos == anchors).any())
+    sample = torch.arange(0, 4096, 128, device="cuda")                               # 32 anchors
+    # ---- point kNN: exact, ordered by (d^2 in fp64, id), self dropped
+    d2 = ((xyz[anchors[sample]].double()[:, None, :] - xyz.double()[None, :, :]) ** 2).sum(-1)        # [32, N]
+    order = torch.argsort(d2, dim=1, stable=True)[:, 1:97]                           # stable: ties by id
+    assert torch.equal(order, nbrs[sample])
+    # ---- sampler: fp64 similarities of the sampled anchors
+    Fn = torch.nn.functional.normalize(F_teacher.double(), dim=1)
+    sim = Fn[anchors[sample]] @ Fn.t()
+    r = torch.arange(len(sample), device="cuda")
+    sim[r, anchors[sample]] = -float("inf")
+    best = sim.max(dim=1).values
+    assert bool((sim[r, pos[sample]] >= best - 2e-6).all())                          # the arg-max, up to a near tie of the fp32-class GEMM
+    sim[r, anchors[sample]] = float("inf")
+    sim[r, pos[sample]] = float("inf")
+    kth = torch.topk(sim, 48, dim=1, largest=False).values[:, -1]
+    macro = neg[sample, :48]
+    assert bool((torch.gather(sim, 1, macro) <= kth[:, None] + 2e-6).all())          # each is among the 48 lowest (up to near ties) ...
+    assert all(len(set(row.tolist())) == 48 for row in macro.cpu())                  # ... and they are 48 distinct points
+    micro = neg[sample, 48:]
+    assert bool(((micro[:, :, None] == nbrs[sample][:, None, :]).any(-1)).all())     # the local ones come from the anchors' neighbours
+    loc = torch.gather(sim, 1, nbrs[sample])
+    kth_l = torch.topk(loc, 15, dim=1, largest=False).values[:, -1]
+    assert bool((torch.gather(sim, 1, micro) <= kth_l[:, None] + 2e-6).all())
+    # ---- the same step again: same loss, same gradients (up to the InfoNCE scatter's fp32 atomics)
+    tr2, out2 = step()
+    assert abs(float(out2["loss"]) - float(out["loss"])) <= 1e-5 * abs(float(out["loss"]))
+    for k_, g1 in out["grads"].items():
+        g2 = out2["grads"][k_]
+        assert torch.isfinite(g1).all() and float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max()) + 1e-12, k_
+    assert float(out["grads"]["res_blocks.0.conv1.kernel"].abs().max()) > 0
+    # ---- an optimizer step moves every parameter tensor
+    before = {k_: v.clone() for k_, v in tr.params.items()}
+    tr.optimizer_step(out["grads"])
+    assert all(not torch.equal(before[k_], tr.params[k_]) for k_ in before)
+
+
 def test_config_p_full_size_properties():
     """BASELINE configs[0] at its full size: 50k points, ONE view, 64-d dense features (lift a5), T = 19; the D = 64 tiled
     pooling kernel (pool_tiles64_kernel, round 6; rounds 1-5: the generic ELL kernel) and the f16x3 student with a 70-channel input layer."""
