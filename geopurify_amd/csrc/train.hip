@@ -644,13 +644,35 @@ knn_points_multi_kernel(const float *__restrict__ xyz, int64_t n, const int64_t 
     for (int j = 0; j < KQ; ++j) s_tm[j][tid] = tmin[j];
     if (tid < KQ) s_cnt[tid] = 0;
     __syncthreads();
-    {
-        int rank[KQ] = {0, 0, 0, 0};
-        for (int u = 0; u < 256; ++u)
+    {   // the (k+1)-th lowest of the 256 thread minima of every query: bitonic sorts (shuffles inside a wave, LDS across waves)
+        double v[KQ];
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) { const double m = s_tm[j][u]; rank[j] += (m < tmin[j]) || (m == tmin[j] && u < tid); }
+        for (int j = 0; j < KQ; ++j) v[j] = tmin[j];
+        for (int kk = 2; kk <= 256; kk <<= 1)
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                const bool keep_low = ((tid & jj) == 0) == ((tid & kk) == 0);
+                if (jj >= 64) {
+                    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) if (rank[j] == k) s_bound[j] = tmin[j];
+                    for (int j = 0; j < KQ; ++j) s_tm[j][tid] = v[j];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) {
+                    double o;
+                    if (jj >= 64) {
+                        o = s_tm[j][tid ^ jj];
+                    } else {
+                        const unsigned long long b = (unsigned long long)__double_as_longlong(v[j]);
+                        const unsigned lo = __shfl_xor((unsigned)b, jj, 64), hi = __shfl_xor((unsigned)(b >> 32), jj, 64);
+                        o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                    }
+                    v[j] = keep_low ? (o < v[j] ? o : v[j]) : (o > v[j] ? o : v[j]);
+                }
+            }
+        if (tid == k)
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) s_bound[j] = v[j];
     }
     __syncthreads();
     double bound[KQ];
@@ -815,14 +837,24 @@ sampler_select_kernel(const float *__restrict__ sim, int64_t ld, int n, const in
         for (int w = 1; w < SR_NT / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
         s_pos = 0x7fffffff - (int)(unsigned)(m & 0xffffffffu);
     }
-    {   // the thread whose minimum has rank k among the 1024 (ties by thread id) publishes the bound
-        int rank = 0;
-        for (int u = 0; u < SR_NT; u += 4) {
-            const uint4 m4 = *reinterpret_cast<const uint4 *>(&s_min[u]);
-            rank += (m4.x < tmin || (m4.x == tmin && u < tid)) + (m4.y < tmin || (m4.y == tmin && u + 1 < tid)) +
-                    (m4.z < tmin || (m4.z == tmin && u + 2 < tid)) + (m4.w < tmin || (m4.w == tmin && u + 3 < tid));
-        }
-        if (rank == k) s_bound = tmin;
+    {   // the (k+1)-th lowest of the 1024 thread minima: a bitonic sort, exchanges inside a wave by shuffles, across waves through LDS
+        // (ranking every minimum against all 1024 by counting -- the first form -- was 1 M compares per row: 65 of a row's ~110 us)
+        unsigned v = tmin;
+        for (int kk = 2; kk <= SR_NT; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                unsigned o;
+                if (j >= 64) {
+                    __syncthreads();
+                    s_min[tid] = v;
+                    __syncthreads();
+                    o = s_min[tid ^ j];
+                } else {
+                    o = __shfl_xor(v, j, 64);
+                }
+                const bool keep_low = ((tid & j) == 0) == ((tid & kk) == 0);
+                v = keep_low ? (o < v ? o : v) : (o > v ? o : v);
+            }
+        if (tid == k) s_bound = v;                        // ascending order: position k holds the (k+1)-th lowest
     }
     __syncthreads();
     const unsigned bound = s_bound;
