@@ -611,20 +611,26 @@ knn_points_kernel(const float *__restrict__ xyz, int64_t n, const int64_t *__res
 
 // KQ queries per workgroup: the coordinates of a point are loaded once for KQ distances (one query per workgroup reads the 1.8 MB of
 // coordinates 2 x 4096 times from L2: 14.7 GB, which is what bounded it at 1.18 ms), the same thread-minimum bounds, KQ_CAP candidates per query.
-// A query with more candidates than that under its bound gets -1 in its first output column and is redone by knn_points_kernel (marked_only).
+// The two sweeps work in FP32 and only the candidates' distances are taken in fp64 (the order the result is defined in): with s32 the fp32
+// evaluation of a squared distance, |s32 - d^2| <= eps d^2, eps = 2^-21 (three subtractions, three squares, two additions of non-negative
+// terms: 5.1 x 2^-24).  B32 = the (k+1)-th lowest thread minimum of s32: k + 1 points have s32 <= B32, hence d^2 <= B32 (1 + 2 eps) =: B64 --
+// an upper bound of the (k+1)-th lowest true distance; a point with d^2 <= B64 has s32 <= B32 (1 + 4 eps).  Sweep 2 therefore tests
+// s32 <= B32 (1 + 2^-18) in fp32 and, for the few that pass, d^2 <= B32 (1 + 2^-19) in fp64 -- every true neighbour is collected, with its fp64
+// distance.  (A bound below 1e-30 -- k + 1 points within 1e-15 of the query, where fp32 squares underflow -- hands the query back.)
+// A query with more candidates than KQ_CAP under its bound gets -1 in its first output column and is redone by knn_points_kernel (marked_only).
 constexpr int KQ = 4, KQ_CAP = 512;
 __global__ void __launch_bounds__(256)
 knn_points_multi_kernel(const float *__restrict__ xyz, int64_t n, const int64_t *__restrict__ queries, int64_t num_queries, int k,
                         int64_t *__restrict__ out) {
     __shared__ double cd[KQ][KQ_CAP];
     __shared__ int ci[KQ][KQ_CAP];
-    __shared__ double s_tm[KQ][256];
-    __shared__ double s_bound[KQ];
+    __shared__ float s_tm[KQ][256];
+    __shared__ float s_bound[KQ];
     __shared__ int s_cnt[KQ];
     const int tid = threadIdx.x;
     const int64_t q0 = (int64_t)blockIdx.x * KQ;
     const int nq = (int)(num_queries - q0 < KQ ? num_queries - q0 : KQ);
-    double qx[KQ], qy[KQ], qz[KQ], tmin[KQ];
+    float qx[KQ], qy[KQ], qz[KQ], tmin[KQ];
 #pragma unroll
     for (int j = 0; j < KQ; ++j) {
         const int64_t q = queries[q0 + (j < nq ? j : 0)];
@@ -632,20 +638,17 @@ knn_points_multi_kernel(const float *__restrict__ xyz, int64_t n, const int64_t 
         tmin[j] = INFINITY;
     }
     for (int64_t i = tid; i < n; i += 256) {
-        const double px = xyz[i * 3], py = xyz[i * 3 + 1], pz = xyz[i * 3 + 2];
+        const float px = xyz[i * 3], py = xyz[i * 3 + 1], pz = xyz[i * 3 + 2];
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
-            const double dx = px - qx[j], dy = py - qy[j], dz = pz - qz[j];
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            tmin[j] = d2 < tmin[j] ? d2 : tmin[j];
+            const float dx = px - qx[j], dy = py - qy[j], dz = pz - qz[j];
+            const float s32 = dx * dx + dy * dy + dz * dz;
+            tmin[j] = s32 < tmin[j] ? s32 : tmin[j];
         }
     }
-#pragma unroll
-    for (int j = 0; j < KQ; ++j) s_tm[j][tid] = tmin[j];
     if (tid < KQ) s_cnt[tid] = 0;
-    __syncthreads();
     {   // the (k+1)-th lowest of the 256 thread minima of every query: bitonic sorts (shuffles inside a wave, LDS across waves)
-        double v[KQ];
+        float v[KQ];
 #pragma unroll
         for (int j = 0; j < KQ; ++j) v[j] = tmin[j];
         for (int kk = 2; kk <= 256; kk <<= 1)
@@ -659,14 +662,7 @@ knn_points_multi_kernel(const float *__restrict__ xyz, int64_t n, const int64_t 
                 }
 #pragma unroll
                 for (int j = 0; j < KQ; ++j) {
-                    double o;
-                    if (jj >= 64) {
-                        o = s_tm[j][tid ^ jj];
-                    } else {
-                        const unsigned long long b = (unsigned long long)__double_as_longlong(v[j]);
-                        const unsigned lo = __shfl_xor((unsigned)b, jj, 64), hi = __shfl_xor((unsigned)(b >> 32), jj, 64);
-                        o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-                    }
+                    const float o = jj >= 64 ? s_tm[j][tid ^ jj] : __shfl_xor(v[j], jj, 64);
                     v[j] = keep_low ? (o < v[j] ? o : v[j]) : (o > v[j] ? o : v[j]);
                 }
             }
@@ -675,16 +671,25 @@ knn_points_multi_kernel(const float *__restrict__ xyz, int64_t n, const int64_t 
             for (int j = 0; j < KQ; ++j) s_bound[j] = v[j];
     }
     __syncthreads();
-    double bound[KQ];
+    float f32[KQ];
+    double b64[KQ], qxd[KQ], qyd[KQ], qzd[KQ];
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) bound[j] = s_bound[j];
+    for (int j = 0; j < KQ; ++j) {
+        f32[j] = s_bound[j] * (1.0f + 0x1p-18f);
+        b64[j] = (double)s_bound[j] * (1.0 + 0x1p-19);
+        qxd[j] = qx[j]; qyd[j] = qy[j]; qzd[j] = qz[j];
+    }
     for (int64_t i = tid; i < n; i += 256) {
-        const double px = xyz[i * 3], py = xyz[i * 3 + 1], pz = xyz[i * 3 + 2];
+        const float px = xyz[i * 3], py = xyz[i * 3 + 1], pz = xyz[i * 3 + 2];
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
-            const double dx = px - qx[j], dy = py - qy[j], dz = pz - qz[j];
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 <= bound[j]) { const int pos = atomicAdd(&s_cnt[j], 1); if (pos < KQ_CAP) { cd[j][pos] = d2; ci[j][pos] = (int)i; } }
+            const float dx = px - qx[j], dy = py - qy[j], dz = pz - qz[j];
+            const float s32 = dx * dx + dy * dy + dz * dz;
+            if (s32 <= f32[j]) {
+                const double ex = (double)px - qxd[j], ey = (double)py - qyd[j], ez = (double)pz - qzd[j];
+                const double d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 <= b64[j]) { const int pos = atomicAdd(&s_cnt[j], 1); if (pos < KQ_CAP) { cd[j][pos] = d2; ci[j][pos] = (int)i; } }
+            }
         }
     }
     __syncthreads();
@@ -708,7 +713,7 @@ knn_points_multi_kernel(const float *__restrict__ xyz, int64_t n, const int64_t 
             __syncthreads();
         }
     for (int j = 0; j < nq; ++j) {
-        const bool over = s_cnt[j] > KQ_CAP;
+        const bool over = s_cnt[j] > KQ_CAP || !(s_bound[j] >= 1e-30f);
         for (int t = tid; t < k; t += 256) out[(q0 + j) * k + t] = over ? (int64_t)-1 : (int64_t)ci[j][t + 1];      // column 0 (the point itself) dropped
     }
 }
